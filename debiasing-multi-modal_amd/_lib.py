@@ -1,0 +1,133 @@
+"""ctypes binding of libdbmm_hip.so (the C ABI declared in include/dbmm.h).
+
+The product path has no CPU fallback: if the library is missing or a call fails, an
+exception is raised.  `build()` compiles the HIP sources in-tree with hipcc for gfx950
+(cross-compiles without a GPU).
+"""
+import ctypes
+import glob
+import os
+import subprocess
+from ctypes import c_float, c_int, c_int64, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(_HERE, "libdbmm_hip.so")
+INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
+
+_lib = None
+
+
+def sources():
+    return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+
+
+def build(force=False, verbose=False):
+    """hipcc --offload-arch=gfx950 -> libdbmm_hip.so (in-tree, so it travels with the repo)."""
+    srcs = sources()
+    deps = srcs + glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(INCLUDE, "dbmm.h")]
+    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
+        return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    objs = []
+    procs = []
+    os.makedirs(os.path.join(_HERE, "build"), exist_ok=True)
+    for s in srcs:
+        o = os.path.join(_HERE, "build", os.path.basename(s) + ".o")
+        objs.append(o)
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", INCLUDE, "-c", s, "-o", o]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for cmd, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError("hipcc failed: %s\n%s" % (" ".join(cmd), out.decode()))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs
+    subprocess.run(cmd, check=True)
+    return LIB_PATH
+
+
+_F, _I, _L, _P, _Z = c_float, c_int, c_int64, c_void_p, c_size_t
+
+# name -> argtypes (restype is int unless listed in _RESTYPES)
+_SIGS = {
+    "dbmm_version": [],
+    "dbmm_error_string": [_I],
+    "dbmm_conv_bn_act": [_P, _P, _P, _P, _P, _L, _L, _L, _L, _L, _L, _L, _L, _L, _I, _P],
+    "dbmm_conv1x1_bn_act": [_P, _P, _P, _P, _P, _L, _L, _L, _L, _L, _I, _P],
+    "dbmm_conv3x3_bn_act": [_P, _P, _P, _P, _P, _L, _L, _L, _L, _L, _I, _P],
+    "dbmm_gemm_bias_act": [_P, _L, _I, _P, _L, _I, _P, _P, _L, _P, _L, _L, _L, _L, _F, _I, _P],
+    "dbmm_conv_stem_s2": [_P, _P, _P, _P, _L, _L, _L, _L, _P],
+    "dbmm_avgpool2d": [_P, _P, _L, _L, _L, _L, _L, _P],
+    "dbmm_workspace_bytes_attnpool": [_L, _L, _L],
+    "dbmm_attnpool": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _L, _L, _L, _L, _P, _Z, _P],
+    "dbmm_layernorm": [_P, _L, _P, _P, _P, _L, _L, _L, _F, _P],
+    "dbmm_mha_core": [_P, _P, _L, _L, _L, _L, _I, _P],
+    "dbmm_embed_gather": [_P, _P, _P, _P, _L, _L, _L, _L, _P],
+    "dbmm_im2col_patch": [_P, _P, _L, _L, _L, _P],
+    "dbmm_vit_tokens": [_P, _P, _P, _P, _L, _L, _L, _P],
+    "dbmm_gather_eot": [_P, _P, _P, _L, _L, _L, _P],
+    "dbmm_bn1d_stats": [_P, _L, _L, _F, _F, _P, _P, _P, _P, _P, _P],
+    "dbmm_bn1d_relu": [_P, _P, _P, _P, _P, _P, _L, _L, _I, _F, _P],
+    "dbmm_adapter_fwd": [_P] * 15 + [_L, _L, _L, _I, _F, _F, _P],
+    "dbmm_workspace_bytes_adapter_bwd": [_L, _L, _L],
+    "dbmm_adapter_bwd": [_P] * 15 + [_L, _L, _L, _P, _Z, _P],
+    "dbmm_text_colnorm": [_P, _P, _L, _L, _P],
+    "dbmm_l2norm_sim_ce_fwd": [_P, _P, _F, _P, _P, _F, _P, _P, _P, _P, _P, _L, _L, _L, _P],
+    "dbmm_l2norm_sim_ce_bwd": [_P, _P, _F, _I, _P, _P, _P, _P, _F, _F, _P, _L, _L, _L, _P],
+    "dbmm_sgd_momentum": [_L, _P, _P, _P, _P, _F, _F, _F, _I, _P],
+    "dbmm_group_count": [_P, _P, _P, _P, _L, _L, _L, _P],
+    "dbmm_group_loss_sum": [_P, _P, _P, _L, _L, _P],
+}
+_RESTYPES = {
+    "dbmm_error_string": ctypes.c_char_p,
+    "dbmm_workspace_bytes_attnpool": c_size_t,
+    "dbmm_workspace_bytes_adapter_bwd": c_size_t,
+}
+
+EXPORTS = tuple(_SIGS)
+
+
+def lib():
+    """The loaded library; raises (never falls back) when it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback for the dbmm_amd hot path.")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, argtypes in _SIGS.items():
+            fn = getattr(L, name)          # AttributeError if the symbol is not exported
+            fn.argtypes = argtypes
+            fn.restype = _RESTYPES.get(name, c_int)
+        _lib = L
+    return _lib
+
+
+class DbmmError(RuntimeError):
+    pass
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().dbmm_error_string(rc).decode()
+        raise DbmmError(f"{what or 'dbmm call'} failed with code {rc}: {msg}")
+
+
+def ptr(t):
+    """data pointer of a tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def stream():
+    import torch
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise DbmmError("dbmm_amd kernels need CUDA/HIP tensors (MI355X); got a CPU tensor. "
+                            "There is no CPU fallback on the product path.")

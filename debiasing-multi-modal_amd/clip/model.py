@@ -1,0 +1,357 @@
+"""CLIP model surface of the reference (`/root/reference/clip/model.py`) over MI355X kernels.
+
+What is kept: the OpenAI state-dict key names, `build_model`
+inferring the architecture from key shapes (clip/model.py:399-436), `CLIP.encode_image`,
+`CLIP.encode_text`, `CLIP.forward`, `.dtype`, `.visual.input_resolution`, `.logit_scale`
+(clip/model.py:336-372), and the nn.Module protocol (`.cuda()`, `.eval()`, `state_dict()`).
+
+What is different: modules here are *parameter holders*; there is no per-layer forward.
+Each tower compiles an execution plan on first use -- BatchNorm folded into the conv
+weights in fp64, conv weights repacked to [Cout][kh][kw][Cin] for the NHWC implicit-GEMM
+kernel, k/v projection weights concatenated -- and `forward` walks that plan calling the
+C ABI (ops.py).  Activations are fp32 NHWC / batch-first tokens.  Compute dtype is fp32
+(fp32-input MFMA), which is what the 1e-3 logit parity against the reference's CPU path
+needs; there is no fp16 cast of the weights, `.dtype` reports float32.
+"""
+from collections import OrderedDict
+from typing import Tuple, Union
+
+import numpy as np
+import torch
+from torch import nn
+
+from .. import ops
+
+
+# ---------------------------------------------------------------------------------------
+# parameter holders (names = the reference's state-dict keys)
+# ---------------------------------------------------------------------------------------
+
+class _ConvW(nn.Module):
+    def __init__(self, cin, cout, k):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(cout, cin, k, k))
+
+
+class _BNParams(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(c))
+        self.bias = nn.Parameter(torch.zeros(c))
+        self.register_buffer("running_mean", torch.zeros(c))
+        self.register_buffer("running_var", torch.ones(c))
+        self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+        self.eps = 1e-5
+
+
+class _LinearW(nn.Module):
+    def __init__(self, fin, fout):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(fout, fin))
+        self.bias = nn.Parameter(torch.zeros(fout))
+        self.in_features, self.out_features = fin, fout
+
+
+class _LNParams(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(c))
+        self.bias = nn.Parameter(torch.zeros(c))
+        self.eps = 1e-5
+
+
+class _AttnParams(nn.Module):
+    def __init__(self, d):
+        super().__init__()
+        self.in_proj_weight = nn.Parameter(torch.empty(3 * d, d))
+        self.in_proj_bias = nn.Parameter(torch.zeros(3 * d))
+        self.out_proj = _LinearW(d, d)
+
+
+class _Downsample(nn.Module):
+    """keys downsample.0.weight / downsample.1.* (clip/model.py:36-40)."""
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.add_module("0", _ConvW(cin, cout, 1))
+        self.add_module("1", _BNParams(cout))
+
+
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1):
+        super().__init__()
+        self.conv1, self.bn1 = _ConvW(inplanes, planes, 1), _BNParams(planes)
+        self.conv2, self.bn2 = _ConvW(planes, planes, 3), _BNParams(planes)
+        self.conv3, self.bn3 = _ConvW(planes, planes * 4, 1), _BNParams(planes * 4)
+        self.stride = stride
+        self.downsample = _Downsample(inplanes, planes * 4) if (stride > 1 or inplanes != planes * 4) else None
+
+
+class AttentionPool2d(nn.Module):
+    def __init__(self, spacial_dim, embed_dim, num_heads, output_dim=None):
+        super().__init__()
+        self.positional_embedding = nn.Parameter(torch.randn(spacial_dim ** 2 + 1, embed_dim) / embed_dim ** 0.5)
+        self.k_proj = _LinearW(embed_dim, embed_dim)
+        self.q_proj = _LinearW(embed_dim, embed_dim)
+        self.v_proj = _LinearW(embed_dim, embed_dim)
+        self.c_proj = _LinearW(embed_dim, output_dim or embed_dim)
+        self.num_heads = num_heads
+
+
+def _fold_bn(conv_w, bn):
+    """conv (bias-free) followed by eval-mode BN == conv with w*s and bias beta - mu*s."""
+    s = bn.weight.double() / torch.sqrt(bn.running_var.double() + bn.eps)
+    w = conv_w.double() * s.reshape(-1, 1, 1, 1)
+    b = bn.bias.double() - bn.running_mean.double() * s
+    return w, b
+
+
+def _pack_conv(w64):
+    """[Cout][Cin][kh][kw] -> [Cout][kh][kw][Cin] fp32 contiguous (K order of the igemm kernel)."""
+    return w64.permute(0, 2, 3, 1).contiguous().float()
+
+
+class ModifiedResNet(nn.Module):
+    """Parameter layout of clip/model.py:94-136; forward = compiled plan over HIP kernels."""
+
+    def __init__(self, layers, output_dim, heads, input_resolution=224, width=64):
+        super().__init__()
+        self.output_dim, self.input_resolution = output_dim, input_resolution
+        self.conv1, self.bn1 = _ConvW(3, width // 2, 3), _BNParams(width // 2)
+        self.conv2, self.bn2 = _ConvW(width // 2, width // 2, 3), _BNParams(width // 2)
+        self.conv3, self.bn3 = _ConvW(width // 2, width, 3), _BNParams(width)
+        inplanes = width
+        for li, (n, mul) in enumerate(zip(layers, (1, 2, 4, 8)), start=1):
+            blocks = []
+            for bi in range(n):
+                blocks.append(Bottleneck(inplanes, width * mul, 2 if (li > 1 and bi == 0) else 1))
+                inplanes = width * mul * 4
+            setattr(self, f"layer{li}", nn.Sequential(*blocks))
+        self.attnpool = AttentionPool2d(input_resolution // 32, width * 32, heads, output_dim)
+        self._plan = None
+
+    def refresh_plan(self):
+        """Re-fold the weights (call after loading new parameters)."""
+        self._plan = None
+
+    def _apply(self, fn, *a, **k):
+        self._plan = None
+        return super()._apply(fn, *a, **k)
+
+    @torch.no_grad()
+    def _compile(self):
+        P = {}
+        w, b = _fold_bn(self.conv1.weight, self.bn1)
+        P["stem1"] = (w.permute(2, 3, 1, 0).contiguous().float(), b.float().contiguous())   # [kh][kw][cin][cout]
+        for i in (2, 3):
+            w, b = _fold_bn(getattr(self, f"conv{i}").weight, getattr(self, f"bn{i}"))
+            P[f"stem{i}"] = (_pack_conv(w), b.float().contiguous())
+        blocks = []
+        for li in (1, 2, 3, 4):
+            for blk in getattr(self, f"layer{li}"):
+                e = {"stride": blk.stride}
+                for i in (1, 2, 3):
+                    w, b = _fold_bn(getattr(blk, f"conv{i}").weight, getattr(blk, f"bn{i}"))
+                    e[f"c{i}"] = (_pack_conv(w), b.float().contiguous())
+                if blk.downsample is not None:
+                    w, b = _fold_bn(getattr(blk.downsample, "0").weight, getattr(blk.downsample, "1"))
+                    e["ds"] = (_pack_conv(w), b.float().contiguous())
+                blocks.append(e)
+        P["blocks"] = blocks
+        ap = self.attnpool
+        P["attn"] = dict(
+            pos=ap.positional_embedding.detach().float().contiguous(),
+            wq=ap.q_proj.weight.detach().float().contiguous(), bq=ap.q_proj.bias.detach().float().contiguous(),
+            wkv=torch.cat([ap.k_proj.weight, ap.v_proj.weight], 0).detach().float().contiguous(),
+            bkv=torch.cat([ap.k_proj.bias, ap.v_proj.bias], 0).detach().float().contiguous(),
+            wc=ap.c_proj.weight.detach().float().contiguous(), bc=ap.c_proj.bias.detach().float().contiguous())
+        self._plan = P
+        return P
+
+    @torch.no_grad()
+    def forward(self, x, return_stages=False):
+        P = self._plan or self._compile()
+        x = x.float().contiguous()                      # NCHW image at the boundary
+        x = ops.conv_stem_s2(x, *P["stem1"])            # -> NHWC from here on
+        x = ops.conv_bn_act(x, P["stem2"][0], P["stem2"][1], None, 3, 3, 1, 1, ops.ACT_RELU)
+        x = ops.conv_bn_act(x, P["stem3"][0], P["stem3"][1], None, 3, 3, 1, 1, ops.ACT_RELU)
+        x = ops.avgpool2d(x, 2)
+        stages = {"stem": x}
+        bi = 0
+        for li in (1, 2, 3, 4):
+            for _ in getattr(self, f"layer{li}"):
+                e = P["blocks"][bi]; bi += 1
+                out = ops.conv_bn_act(x, e["c1"][0], e["c1"][1], None, 1, 1, 1, 0, ops.ACT_RELU)
+                out = ops.conv_bn_act(out, e["c2"][0], e["c2"][1], None, 3, 3, 1, 1, ops.ACT_RELU)
+                if e["stride"] > 1:
+                    out = ops.avgpool2d(out, e["stride"])
+                identity = x
+                if "ds" in e:
+                    if e["stride"] > 1:
+                        identity = ops.avgpool2d(x, e["stride"])
+                    identity = ops.conv_bn_act(identity, e["ds"][0], e["ds"][1], None, 1, 1, 1, 0, ops.ACT_NONE)
+                # conv3 + bn3, residual add and the final ReLU fused into one epilogue
+                x = ops.conv_bn_act(out, e["c3"][0], e["c3"][1], identity, 1, 1, 1, 0, ops.ACT_RELU)
+            stages[f"layer{li}"] = x
+        a = P["attn"]
+        out = ops.attnpool(x, a["pos"], a["wq"], a["bq"], a["wkv"], a["bkv"], a["wc"], a["bc"], self.attnpool.num_heads)
+        return (out, stages) if return_stages else out
+
+
+# ---------------------------------------------------------------------------------------
+# transformer towers
+# ---------------------------------------------------------------------------------------
+
+class _MLP(nn.Module):
+    def __init__(self, d):
+        super().__init__()
+        self.c_fc = _LinearW(d, 4 * d)
+        self.c_proj = _LinearW(4 * d, d)
+
+
+class ResidualAttentionBlock(nn.Module):
+    def __init__(self, d_model, n_head, attn_mask=None):
+        super().__init__()
+        self.attn = _AttnParams(d_model)
+        self.ln_1 = _LNParams(d_model)
+        self.mlp = _MLP(d_model)
+        self.ln_2 = _LNParams(d_model)
+        self.n_head = n_head
+
+
+class Transformer(nn.Module):
+    def __init__(self, width, layers, heads, attn_mask=None):
+        super().__init__()
+        self.width, self.layers, self.heads = width, layers, heads
+        self.causal = attn_mask is not None
+        self.resblocks = nn.Sequential(*[ResidualAttentionBlock(width, heads) for _ in range(layers)])
+
+    @torch.no_grad()
+    def run(self, x, B, L):
+        """x [B*L, E] batch-first rows.  Pre-LN blocks (clip/model.py:189-192): the residual
+        adds and QuickGELU are GEMM epilogues."""
+        E = self.width
+        for blk in self.resblocks:
+            h = ops.layernorm(x, blk.ln_1.weight, blk.ln_1.bias)
+            qkv = ops.gemm(h, blk.attn.in_proj_weight, blk.attn.in_proj_bias)
+            o = ops.mha_core(qkv, B, L, E, self.heads, self.causal)
+            x = ops.gemm(o, blk.attn.out_proj.weight, blk.attn.out_proj.bias, residual=x)
+            h = ops.layernorm(x, blk.ln_2.weight, blk.ln_2.bias)
+            h = ops.gemm(h, blk.mlp.c_fc.weight, blk.mlp.c_fc.bias, act=ops.ACT_QUICKGELU)
+            x = ops.gemm(h, blk.mlp.c_proj.weight, blk.mlp.c_proj.bias, residual=x)
+        return x
+
+
+class VisionTransformer(nn.Module):
+    def __init__(self, input_resolution, patch_size, width, layers, heads, output_dim):
+        super().__init__()
+        self.input_resolution, self.output_dim, self.patch_size = input_resolution, output_dim, patch_size
+        self.conv1 = _ConvW(3, width, patch_size)
+        scale = width ** -0.5
+        self.class_embedding = nn.Parameter(scale * torch.randn(width))
+        self.positional_embedding = nn.Parameter(scale * torch.randn((input_resolution // patch_size) ** 2 + 1, width))
+        self.ln_pre = _LNParams(width)
+        self.transformer = Transformer(width, layers, heads)
+        self.ln_post = _LNParams(width)
+        self.proj = nn.Parameter(scale * torch.randn(width, output_dim))
+
+    @torch.no_grad()
+    def forward(self, x):
+        x = x.float().contiguous()
+        B = x.shape[0]
+        W = self.conv1.weight.shape[0]
+        L = self.positional_embedding.shape[0]
+        cols = ops.im2col_patch(x, self.patch_size)                       # [B*g*g, 3*P*P]
+        patches = ops.gemm(cols, self.conv1.weight.reshape(W, -1))        # conv1 has no bias
+        t = ops.vit_tokens(patches, self.class_embedding, self.positional_embedding, B)
+        t = ops.layernorm(t, self.ln_pre.weight, self.ln_pre.bias)        # [B*L, W]
+        t = self.transformer.run(t, B, L)
+        c = ops.layernorm(t, self.ln_post.weight, self.ln_post.bias, rows=B, ldx=L * W)   # token 0 only
+        return ops.gemm(c, self.proj, trans_w=True)
+
+
+class CLIP(nn.Module):
+    def __init__(self, embed_dim: int, image_resolution: int, vision_layers: Union[Tuple[int, int, int, int], int],
+                 vision_width: int, vision_patch_size: int, context_length: int, vocab_size: int,
+                 transformer_width: int, transformer_heads: int, transformer_layers: int):
+        super().__init__()
+        self.context_length = context_length
+        if isinstance(vision_layers, (tuple, list)):
+            self.visual = ModifiedResNet(layers=vision_layers, output_dim=embed_dim, heads=vision_width * 32 // 64,
+                                         input_resolution=image_resolution, width=vision_width)
+        else:
+            self.visual = VisionTransformer(input_resolution=image_resolution, patch_size=vision_patch_size,
+                                            width=vision_width, layers=vision_layers, heads=vision_width // 64,
+                                            output_dim=embed_dim)
+        self.transformer = Transformer(width=transformer_width, layers=transformer_layers, heads=transformer_heads,
+                                       attn_mask=True)
+        self.vocab_size = vocab_size
+        self.token_embedding = nn.Embedding(vocab_size, transformer_width)
+        self.positional_embedding = nn.Parameter(torch.empty(context_length, transformer_width))
+        self.ln_final = _LNParams(transformer_width)
+        self.text_projection = nn.Parameter(torch.empty(transformer_width, embed_dim))
+        self.logit_scale = nn.Parameter(torch.ones([]) * np.log(1 / 0.07))
+
+    @property
+    def dtype(self):
+        return self.visual.conv1.weight.dtype
+
+    def encode_image(self, image):
+        return self.visual(image.type(self.dtype))
+
+    @torch.no_grad()
+    def encode_text(self, text):
+        x, tok = ops.embed_gather(text, self.token_embedding.weight, self.positional_embedding)
+        n, L, W = x.shape
+        x = self.transformer.run(x.view(n * L, W), n, L)
+        # LayerNorm is per row, so gather the EOT row first and normalise only that row
+        e = ops.gather_eot(tok, x.view(n, L, W))
+        e = ops.layernorm(e, self.ln_final.weight, self.ln_final.bias)
+        return ops.gemm(e, self.text_projection, trans_w=True)
+
+    def forward(self, image, text):
+        image_features = self.encode_image(image)
+        text_features = self.encode_text(text)
+        image_features = image_features / image_features.norm(dim=1, keepdim=True)
+        text_features = text_features / text_features.norm(dim=1, keepdim=True)
+        logit_scale = self.logit_scale.exp()
+        logits_per_image = logit_scale * image_features @ text_features.t()
+        return logits_per_image, logits_per_image.t()
+
+
+def convert_weights(model: nn.Module):
+    """No-op kept for API compatibility: this build computes in fp32 (see module docstring);
+    the reference's fp16 weight cast (clip/model.py:375-396) is not applied."""
+    return model
+
+
+def build_model(state_dict: dict):
+    """Infer the architecture from key shapes exactly as clip/model.py:399-436 does."""
+    vit = "visual.proj" in state_dict
+    if vit:
+        vision_width = state_dict["visual.conv1.weight"].shape[0]
+        vision_layers = len([k for k in state_dict if k.startswith("visual.") and k.endswith(".attn.in_proj_weight")])
+        vision_patch_size = state_dict["visual.conv1.weight"].shape[-1]
+        grid = round((state_dict["visual.positional_embedding"].shape[0] - 1) ** 0.5)
+        image_resolution = vision_patch_size * grid
+    else:
+        vision_layers = tuple(len({k.split(".")[2] for k in state_dict if k.startswith(f"visual.layer{b}")})
+                              for b in (1, 2, 3, 4))
+        vision_width = state_dict["visual.layer1.0.conv1.weight"].shape[0]
+        out_w = round((state_dict["visual.attnpool.positional_embedding"].shape[0] - 1) ** 0.5)
+        vision_patch_size = None
+        if out_w ** 2 + 1 != state_dict["visual.attnpool.positional_embedding"].shape[0]:
+            raise RuntimeError("attnpool.positional_embedding is not (n*n + 1) rows")
+        image_resolution = out_w * 32
+    embed_dim = state_dict["text_projection"].shape[1]
+    context_length = state_dict["positional_embedding"].shape[0]
+    vocab_size = state_dict["token_embedding.weight"].shape[0]
+    transformer_width = state_dict["ln_final.weight"].shape[0]
+    transformer_layers = len({k.split(".")[2] for k in state_dict if k.startswith("transformer.resblocks")})
+    model = CLIP(embed_dim, image_resolution, vision_layers, vision_width, vision_patch_size, context_length,
+                 vocab_size, transformer_width, transformer_width // 64, transformer_layers)
+    sd = OrderedDict((k, v.float() if v.is_floating_point() else v) for k, v in state_dict.items()
+                     if k not in ("input_resolution", "context_length", "vocab_size"))
+    model.load_state_dict(sd)
+    return model.eval()

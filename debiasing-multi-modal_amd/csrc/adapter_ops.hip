@@ -1,0 +1,523 @@
+// Debiasing-adapter step kernels (final_main.py:53-174, 426-496; demo/util.py:118-136):
+// BatchNorm1d batch statistics / apply / backward, fused row-L2-norm + image x text logits +
+// cross-entropy forward and backward, column reductions for bias gradients, a multi-tensor
+// SGD-momentum update and the per-group accuracy counters.  These are HBM/launch-bound
+// (arithmetic intensity ~1 FLOP/B); the four GEMM-shaped products go through
+// dbmm_gemm_bias_act (fp32 MFMA).
+#include "common.h"
+
+namespace {
+
+// ---- BatchNorm1d(H) statistics over the batch: 8 columns x 32 row-lanes per block ---------
+__global__ __launch_bounds__(256) void bn1d_stats_kernel(const float* __restrict__ h, int B, int H, float eps,
+                                                         float momentum, float* __restrict__ mean_o,
+                                                         float* __restrict__ invstd_o, float* __restrict__ rmean,
+                                                         float* __restrict__ rvar, long long* __restrict__ nbt) {
+    __shared__ float red[32][9];
+    const int cl = threadIdx.x & 7, rl = threadIdx.x >> 3;
+    const int j = blockIdx.x * 8 + cl;
+    const bool ok = j < H;
+    float s = 0.f;
+    if (ok) for (int b = rl; b < B; b += 32) s += h[(long long)b * H + j];
+    red[rl][cl] = s;
+    __syncthreads();
+    float mean = 0.f;
+    for (int r = 0; r < 32; ++r) mean += red[r][cl];
+    mean /= (float)B;
+    __syncthreads();
+    float q = 0.f;
+    if (ok) for (int b = rl; b < B; b += 32) { const float d = h[(long long)b * H + j] - mean; q = fmaf(d, d, q); }
+    red[rl][cl] = q;
+    __syncthreads();
+    if (rl == 0 && ok) {
+        float var = 0.f;
+        for (int r = 0; r < 32; ++r) var += red[r][cl];
+        var /= (float)B;
+        mean_o[j] = mean;
+        invstd_o[j] = rsqrtf(var + eps);
+        if (rmean) rmean[j] = (1.f - momentum) * rmean[j] + momentum * mean;
+        if (rvar) rvar[j] = (1.f - momentum) * rvar[j] + momentum * (var * (float)B / (float)(B - 1));
+    }
+    if (nbt && blockIdx.x == 0 && threadIdx.x == 0) *nbt += 1;
+}
+
+__global__ __launch_bounds__(256) void bn1d_relu_kernel(const float* __restrict__ h, const float* __restrict__ mean,
+                                                        const float* __restrict__ invstd,
+                                                        const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float* __restrict__ r,
+                                                        int H4, int var_mode, float eps, long long total) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % H4);
+        f32x4 is = ((const f32x4*)invstd)[c];
+        if (var_mode) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) is[k] = rsqrtf(is[k] + eps);
+        }
+        f32x4 v = (((const f32x4*)h)[i] - ((const f32x4*)mean)[c]) * is * ((const f32x4*)gamma)[c] +
+                  ((const f32x4*)beta)[c];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
+        ((f32x4*)r)[i] = v;
+    }
+}
+
+// dhn = dr * (hn > 0);  dbeta_j = sum_b dhn;  dgamma_j = sum_b dhn * xhat
+__global__ __launch_bounds__(256) void bn1d_bwd_reduce_kernel(const float* __restrict__ dr,
+                                                              const float* __restrict__ h,
+                                                              const float* __restrict__ mean,
+                                                              const float* __restrict__ invstd,
+                                                              const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, int B, int H,
+                                                              float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    __shared__ float red[2][32][9];
+    const int cl = threadIdx.x & 7, rl = threadIdx.x >> 3;
+    const int j = blockIdx.x * 8 + cl;
+    const bool ok = j < H;
+    float sb = 0.f, sg = 0.f;
+    if (ok) {
+        const float mu = mean[j], is = invstd[j], ga = gamma[j], be = beta[j];
+        for (int b = rl; b < B; b += 32) {
+            const float xh = (h[(long long)b * H + j] - mu) * is;
+            const float d = (fmaf(ga, xh, be) > 0.f) ? dr[(long long)b * H + j] : 0.f;
+            sb += d;
+            sg = fmaf(d, xh, sg);
+        }
+    }
+    red[0][rl][cl] = sb; red[1][rl][cl] = sg;
+    __syncthreads();
+    if (rl == 0 && ok) {
+        float a = 0.f, g = 0.f;
+        for (int r = 0; r < 32; ++r) { a += red[0][r][cl]; g += red[1][r][cl]; }
+        dbeta[j] = a; dgamma[j] = g;
+    }
+}
+
+// dh = gamma * invstd * (dhn - dbeta/B - xhat * dgamma/B)      (train-mode BN backward)
+__global__ __launch_bounds__(256) void bn1d_bwd_apply_kernel(const float* __restrict__ dr,
+                                                             const float* __restrict__ h,
+                                                             const float* __restrict__ mean,
+                                                             const float* __restrict__ invstd,
+                                                             const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta,
+                                                             const float* __restrict__ dgamma,
+                                                             const float* __restrict__ dbeta, float* __restrict__ dh,
+                                                             int H, float invB, long long total) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int j = (int)(i % H);
+        const float is = invstd[j], ga = gamma[j];
+        const float xh = (h[i] - mean[j]) * is;
+        const float d = (fmaf(ga, xh, beta[j]) > 0.f) ? dr[i] : 0.f;
+        dh[i] = ga * is * (d - dbeta[j] * invB - xh * dgamma[j] * invB);
+    }
+}
+
+// out[j] = sum_b x[b][j]: 64 columns x 4 row-lanes per block, deterministic order
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, int B, int N,
+                                                     float* __restrict__ out) {
+    __shared__ float red[4][64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int j = blockIdx.x * 64 + cl;
+    float s = 0.f;
+    if (j < N) for (int b = rl; b < B; b += 4) s += x[(long long)b * N + j];
+    red[rl][cl] = s;
+    __syncthreads();
+    if (rl == 0 && j < N) out[j] = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+}
+
+// tn[c][:] = text[:, c] / ||text[:, c]||
+__global__ __launch_bounds__(256) void text_colnorm_kernel(const float* __restrict__ text, float* __restrict__ tn,
+                                                           int D, int C) {
+    __shared__ float red[4];
+    const int c = blockIdx.x;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < D; i += 256) { const float v = text[(long long)i * C + c]; s = fmaf(v, v, s); }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    const float inv = 1.f / sqrtf((red[0] + red[1]) + (red[2] + red[3]));
+    for (int i = threadIdx.x; i < D; i += 256) tn[(long long)c * D + i] = text[(long long)i * C + c] * inv;
+}
+
+// ---- fused row L2-norm + logits + CE: one wave per row -------------------------------------
+template <int CMAX>
+__global__ __launch_bounds__(256) void l2norm_sim_ce_fwd_kernel(
+    const float* __restrict__ z, const float* __restrict__ z_old, float w_old, const float* __restrict__ tn,
+    const long long* __restrict__ labels, float invT, float* __restrict__ logits, float* __restrict__ loss_rows,
+    long long* __restrict__ pred, float* __restrict__ inv_norm, int B, int D4, int C) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= B) return;
+    const f32x4* zr = (const f32x4*)z + (long long)row * D4;
+    const f32x4* zo = z_old ? (const f32x4*)z_old + (long long)row * D4 : nullptr;
+    float ss = 0.f, sso = 0.f, dot[CMAX], doto[CMAX];
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c) { dot[c] = 0.f; doto[c] = 0.f; }
+    for (int i = lane; i < D4; i += 64) {
+        const f32x4 v = zr[i];
+        ss += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+        f32x4 vo = {0.f, 0.f, 0.f, 0.f};
+        if (zo) { vo = zo[i]; sso += (vo[0] * vo[0] + vo[1] * vo[1]) + (vo[2] * vo[2] + vo[3] * vo[3]); }
+#pragma unroll
+        for (int c = 0; c < CMAX; ++c) {
+            if (c < C) {
+                const f32x4 t = ((const f32x4*)tn)[(long long)c * D4 + i];
+                dot[c] += (v[0] * t[0] + v[1] * t[1]) + (v[2] * t[2] + v[3] * t[3]);
+                if (zo) doto[c] += (vo[0] * t[0] + vo[1] * t[1]) + (vo[2] * t[2] + vo[3] * t[3]);
+            }
+        }
+    }
+    ss = wave_sum(ss);
+    const float inv = 1.f / sqrtf(ss);
+    float invo = 0.f;
+    if (zo) invo = 1.f / sqrtf(wave_sum(sso));
+    float lg[CMAX];
+    float mx = -INFINITY;
+    int am = 0;
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c) {
+        lg[c] = -INFINITY;
+        if (c < C) {
+            const float d = wave_sum(dot[c]) * inv;
+            float f = d;
+            if (zo) f = w_old * (wave_sum(doto[c]) * invo) + (1.f - w_old) * d;
+            lg[c] = f * invT;
+            if (lg[c] > mx) { mx = lg[c]; am = c; }
+        }
+    }
+    if (lane == 0) {
+        if (inv_norm) inv_norm[row] = inv;
+        if (logits) for (int c = 0; c < C; ++c) logits[(long long)row * C + c] = lg[c];
+        if (pred) pred[row] = am;
+        if (loss_rows && labels) {
+            float se = 0.f;
+#pragma unroll
+            for (int c = 0; c < CMAX; ++c) if (c < C) se += expf(lg[c] - mx);
+            const int y = (int)labels[row];
+            float ly = 0.f;
+#pragma unroll
+            for (int c = 0; c < CMAX; ++c) if (c == y) ly = lg[c];
+            loss_rows[row] = (mx + logf(se)) - ly;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void mean_reduce_kernel(const float* __restrict__ x, int n, float* __restrict__ out) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) s += x[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) *out = ((red[0] + red[1]) + (red[2] + red[3])) / (float)n;
+}
+
+template <int CMAX>
+__global__ __launch_bounds__(256) void l2norm_sim_ce_bwd_kernel(
+    const float* __restrict__ z, const float* __restrict__ inv_norm, float w_new, const float* __restrict__ tn,
+    const float* __restrict__ logits, const long long* __restrict__ labels, const float* __restrict__ dlogits,
+    float invT, float gscale, float* __restrict__ dz, int B, int D4, int C) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= B) return;
+    float dl[CMAX];
+    if (dlogits) {   // upstream gradient given (autograd path): dl = dlogits / T * blend weight
+#pragma unroll
+        for (int c = 0; c < CMAX; ++c) dl[c] = (c < C) ? dlogits[(long long)row * C + c] * invT * w_new : 0.f;
+    } else {
+        float mx = -INFINITY;
+#pragma unroll
+        for (int c = 0; c < CMAX; ++c) { dl[c] = (c < C) ? logits[(long long)row * C + c] : -INFINITY; mx = fmaxf(mx, dl[c]); }
+        float se = 0.f;
+#pragma unroll
+        for (int c = 0; c < CMAX; ++c) { dl[c] = (c < C) ? expf(dl[c] - mx) : 0.f; se += dl[c]; }
+        const int y = (int)labels[row];
+        const float k = gscale * invT * w_new;   // d loss / d (feat . tn[c]) incl. blend weight
+#pragma unroll
+        for (int c = 0; c < CMAX; ++c) dl[c] = (dl[c] / se - (c == y ? 1.f : 0.f)) * k;
+    }
+    const float inv = inv_norm[row];
+    const f32x4* zr = (const f32x4*)z + (long long)row * D4;
+    float fd = 0.f;
+    for (int i = lane; i < D4; i += 64) {
+        f32x4 df = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < CMAX; ++c) if (c < C) df += dl[c] * ((const f32x4*)tn)[(long long)c * D4 + i];
+        const f32x4 f = zr[i] * inv;
+        fd += (f[0] * df[0] + f[1] * df[1]) + (f[2] * df[2] + f[3] * df[3]);
+    }
+    fd = wave_sum(fd);
+    f32x4* dzr = (f32x4*)dz + (long long)row * D4;
+    for (int i = lane; i < D4; i += 64) {
+        f32x4 df = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < CMAX; ++c) if (c < C) df += dl[c] * ((const f32x4*)tn)[(long long)c * D4 + i];
+        const f32x4 f = zr[i] * inv;
+        dzr[i] = (df - f * fd) * inv;
+    }
+}
+
+// ---- multi-tensor SGD with momentum ---------------------------------------------------------
+struct SgdArgs {
+    float* p[16];
+    const float* g[16];
+    float* m[16];
+    long long n[16];
+};
+__global__ __launch_bounds__(256) void sgd_kernel(const SgdArgs a, float lr, float mu, float wd, int first) {
+    const int t = blockIdx.y;
+    float* p = a.p[t]; const float* g = a.g[t]; float* m = a.m[t];
+    const long long n = a.n[t];
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float w = p[i];
+        const float gi = fmaf(wd, w, g[i]);
+        const float b = first ? gi : fmaf(mu, m[i], gi);
+        m[i] = b;
+        p[i] = w - lr * b;
+    }
+}
+
+// ---- update_dict counters --------------------------------------------------------------------
+__global__ __launch_bounds__(256) void group_count_kernel(const float* __restrict__ logits,
+                                                          const long long* __restrict__ y,
+                                                          const long long* __restrict__ g,
+                                                          unsigned long long* __restrict__ counts, int B, int C, int G) {
+    __shared__ unsigned int sc[64][2];
+    if (threadIdx.x < 64) { sc[threadIdx.x][0] = 0; sc[threadIdx.x][1] = 0; }
+    __syncthreads();
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B) {
+        int am = 0; float mx = logits[(long long)b * C];
+        for (int c = 1; c < C; ++c) { const float v = logits[(long long)b * C + c]; if (v > mx) { mx = v; am = c; } }
+        const int gi = (int)g[b];
+        if (gi >= 0 && gi < G) {
+            atomicAdd(&sc[gi][0], 1u);
+            if ((long long)am == y[b]) atomicAdd(&sc[gi][1], 1u);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < G) {
+        if (sc[threadIdx.x][0]) atomicAdd(&counts[threadIdx.x * 2], (unsigned long long)sc[threadIdx.x][0]);
+        if (sc[threadIdx.x][1]) atomicAdd(&counts[threadIdx.x * 2 + 1], (unsigned long long)sc[threadIdx.x][1]);
+    }
+}
+
+// sums[g] += sum of loss_rows over group g; single block, fixed order => deterministic
+__global__ __launch_bounds__(256) void group_loss_sum_kernel(const float* __restrict__ loss,
+                                                             const long long* __restrict__ g,
+                                                             float* __restrict__ sums, int B, int G) {
+    __shared__ float red[256];
+    for (int gi = 0; gi < G; ++gi) {
+        float s = 0.f;
+        for (int b = threadIdx.x; b < B; b += 256) if ((int)g[b] == gi) s += loss[b];
+        red[threadIdx.x] = s;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+        if (threadIdx.x == 0) sums[gi] += red[0];
+        __syncthreads();
+    }
+}
+
+inline unsigned grid_for(long long total) {
+    const long long blocks = (total + 255) / 256;
+    return (unsigned)(blocks < 8192 ? (blocks > 0 ? blocks : 1) : 8192);
+}
+
+}  // namespace
+
+extern "C" int dbmm_bn1d_stats(const float* h, int64_t B, int64_t H, float eps, float momentum, float* mean,
+                               float* invstd, float* running_mean, float* running_var, int64_t* nbt, void* stream) {
+    if (!h || !mean || !invstd) return DBMM_E_ARG;
+    if (B < 2 || H <= 0 || B > INT32_MAX || H > INT32_MAX) return DBMM_E_SHAPE;  // torch raises for B == 1 too
+    hipLaunchKernelGGL(bn1d_stats_kernel, dim3((unsigned)((H + 7) / 8)), dim3(256), 0, (hipStream_t)stream, h, (int)B,
+                       (int)H, eps, momentum, mean, invstd, running_mean, running_var, (long long*)nbt);
+    DBMM_CHECK_LAUNCH();
+    return DBMM_OK;
+}
+
+extern "C" int dbmm_bn1d_relu(const float* h, const float* mean, const float* invstd, const float* gamma,
+                              const float* beta, float* r, int64_t B, int64_t H, int var_mode, float eps,
+                              void* stream) {
+    if (!h || !mean || !invstd || !gamma || !beta || !r) return DBMM_E_ARG;
+    if (B <= 0 || H <= 0 || (H & 3)) return DBMM_E_SHAPE;
+    if (!dbmm_aligned16(h) || !dbmm_aligned16(r) || !dbmm_aligned16(mean) || !dbmm_aligned16(invstd) ||
+        !dbmm_aligned16(gamma) || !dbmm_aligned16(beta))
+        return DBMM_E_ALIGN;
+    const long long total = (long long)B * (H / 4);
+    hipLaunchKernelGGL(bn1d_relu_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, h, mean, invstd,
+                       gamma, beta, r, (int)(H / 4), var_mode, eps, total);
+    DBMM_CHECK_LAUNCH();
+    return DBMM_OK;
+}
+
+extern "C" int dbmm_adapter_fwd(const float* x, const float* w1, const float* b1, const float* gamma,
+                                const float* beta, float* running_mean, float* running_var, int64_t* nbt,
+                                const float* w2, const float* b2, float* h, float* mean, float* invstd, float* r,
+                                float* z, int64_t B, int64_t D, int64_t H, int train, float eps, float momentum,
+                                void* stream) {
+    if (!x || !w1 || !b1 || !gamma || !beta || !w2 || !b2 || !h || !r || !z) return DBMM_E_ARG;
+    if (!running_mean || !running_var) return DBMM_E_ARG;
+    if (train && (!mean || !invstd)) return DBMM_E_ARG;
+    int rc = dbmm_gemm_bias_act(x, D, 0, w1, D, 0, b1, nullptr, 0, h, H, B, H, D, 1.f, DBMM_ACT_NONE, stream);
+    if (rc) return rc;
+    if (train) {
+        rc = dbmm_bn1d_stats(h, B, H, eps, momentum, mean, invstd, running_mean, running_var, nbt, stream);
+        if (rc) return rc;
+        rc = dbmm_bn1d_relu(h, mean, invstd, gamma, beta, r, B, H, 0, eps, stream);
+    } else {
+        rc = dbmm_bn1d_relu(h, running_mean, running_var, gamma, beta, r, B, H, 1, eps, stream);
+    }
+    if (rc) return rc;
+    return dbmm_gemm_bias_act(r, H, 0, w2, H, 0, b2, nullptr, 0, z, D, B, D, H, 1.f, DBMM_ACT_NONE, stream);
+}
+
+extern "C" size_t dbmm_workspace_bytes_adapter_bwd(int64_t B, int64_t D, int64_t H) {
+    (void)D;
+    return (size_t)(2 * B * H) * sizeof(float);
+}
+
+extern "C" int dbmm_adapter_bwd(const float* x, const float* dz, const float* h, const float* mean,
+                                const float* invstd, const float* r, const float* gamma, const float* beta,
+                                const float* w2, float* dw1, float* db1, float* dgamma, float* dbeta, float* dw2,
+                                float* db2, int64_t B, int64_t D, int64_t H, void* workspace, size_t workspace_bytes,
+                                void* stream) {
+    if (!x || !dz || !h || !mean || !invstd || !r || !gamma || !beta || !w2 || !dw1 || !db1 || !dgamma || !dbeta ||
+        !dw2 || !db2 || !workspace)
+        return DBMM_E_ARG;
+    if (B < 2 || D <= 0 || H <= 0 || (D & 3) || (H & 3)) return DBMM_E_SHAPE;
+    if (workspace_bytes < dbmm_workspace_bytes_adapter_bwd(B, D, H)) return DBMM_E_WORKSPACE;
+    if (!dbmm_aligned16(workspace)) return DBMM_E_ALIGN;
+    hipStream_t s = (hipStream_t)stream;
+    float* dr = (float*)workspace;
+    float* dh = dr + B * H;
+    int rc;
+    // dW2[D][H] = dz^T r   (reduction over the batch: both operands K-major)
+    rc = dbmm_gemm_bias_act(dz, D, 1, r, H, 1, nullptr, nullptr, 0, dw2, H, D, H, B, 1.f, DBMM_ACT_NONE, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((D + 63) / 64)), dim3(256), 0, s, dz, (int)B, (int)D, db2);
+    DBMM_CHECK_LAUNCH();
+    // dr[B][H] = dz W2   (W2 is [D][H]: K-major weight operand)
+    rc = dbmm_gemm_bias_act(dz, D, 0, w2, H, 1, nullptr, nullptr, 0, dr, H, B, H, D, 1.f, DBMM_ACT_NONE, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(bn1d_bwd_reduce_kernel, dim3((unsigned)((H + 7) / 8)), dim3(256), 0, s, dr, h, mean, invstd,
+                       gamma, beta, (int)B, (int)H, dgamma, dbeta);
+    DBMM_CHECK_LAUNCH();
+    const long long total = (long long)B * H;
+    hipLaunchKernelGGL(bn1d_bwd_apply_kernel, dim3(grid_for(total)), dim3(256), 0, s, dr, h, mean, invstd, gamma, beta,
+                       dgamma, dbeta, dh, (int)H, 1.f / (float)B, total);
+    DBMM_CHECK_LAUNCH();
+    // dW1[H][D] = dh^T x
+    rc = dbmm_gemm_bias_act(dh, H, 1, x, D, 1, nullptr, nullptr, 0, dw1, D, H, D, B, 1.f, DBMM_ACT_NONE, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((H + 63) / 64)), dim3(256), 0, s, dh, (int)B, (int)H, db1);
+    DBMM_CHECK_LAUNCH();
+    return DBMM_OK;
+}
+
+extern "C" int dbmm_text_colnorm(const float* text, float* tn, int64_t D, int64_t C, void* stream) {
+    if (!text || !tn) return DBMM_E_ARG;
+    if (D <= 0 || C <= 0 || C > 65535) return DBMM_E_SHAPE;
+    hipLaunchKernelGGL(text_colnorm_kernel, dim3((unsigned)C), dim3(256), 0, (hipStream_t)stream, text, tn, (int)D, (int)C);
+    DBMM_CHECK_LAUNCH();
+    return DBMM_OK;
+}
+
+extern "C" int dbmm_l2norm_sim_ce_fwd(const float* z, const float* z_old, float ebd_weight, const float* tn,
+                                      const int64_t* labels, float temperature, float* logits, float* loss_rows,
+                                      float* loss_mean, int64_t* pred, float* inv_norm, int64_t B, int64_t D,
+                                      int64_t C, void* stream) {
+    if (!z || !tn) return DBMM_E_ARG;
+    if (B <= 0 || D <= 0 || (D & 3) || C <= 0 || C > 8 || B > INT32_MAX) return DBMM_E_SHAPE;
+    if (loss_mean && !(loss_rows && labels)) return DBMM_E_ARG;
+    if (!dbmm_aligned16(z) || !dbmm_aligned16(tn) || (z_old && !dbmm_aligned16(z_old))) return DBMM_E_ALIGN;
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid((unsigned)((B + 3) / 4));
+    if (C <= 4)
+        hipLaunchKernelGGL(l2norm_sim_ce_fwd_kernel<4>, grid, dim3(256), 0, s, z, z_old, ebd_weight, tn,
+                           (const long long*)labels, 1.f / temperature, logits, loss_rows, (long long*)pred, inv_norm,
+                           (int)B, (int)(D / 4), (int)C);
+    else
+        hipLaunchKernelGGL(l2norm_sim_ce_fwd_kernel<8>, grid, dim3(256), 0, s, z, z_old, ebd_weight, tn,
+                           (const long long*)labels, 1.f / temperature, logits, loss_rows, (long long*)pred, inv_norm,
+                           (int)B, (int)(D / 4), (int)C);
+    DBMM_CHECK_LAUNCH();
+    if (loss_mean) {
+        hipLaunchKernelGGL(mean_reduce_kernel, dim3(1), dim3(256), 0, s, loss_rows, (int)B, loss_mean);
+        DBMM_CHECK_LAUNCH();
+    }
+    return DBMM_OK;
+}
+
+extern "C" int dbmm_l2norm_sim_ce_bwd(const float* z, const float* inv_norm, float ebd_weight, int blended,
+                                      const float* tn, const float* logits, const int64_t* labels,
+                                      const float* dlogits, float temperature, float grad_scale, float* dz,
+                                      int64_t B, int64_t D, int64_t C, void* stream) {
+    if (!z || !inv_norm || !tn || !dz) return DBMM_E_ARG;
+    if (!dlogits && (!logits || !labels)) return DBMM_E_ARG;
+    if (B <= 0 || D <= 0 || (D & 3) || C <= 0 || C > 8 || B > INT32_MAX) return DBMM_E_SHAPE;
+    if (!dbmm_aligned16(z) || !dbmm_aligned16(tn) || !dbmm_aligned16(dz)) return DBMM_E_ALIGN;
+    const float w_new = blended ? (1.f - ebd_weight) : 1.f;
+    const float gs = grad_scale / (float)B;
+    const dim3 grid((unsigned)((B + 3) / 4));
+    hipStream_t s = (hipStream_t)stream;
+    if (C <= 4)
+        hipLaunchKernelGGL(l2norm_sim_ce_bwd_kernel<4>, grid, dim3(256), 0, s, z, inv_norm, w_new, tn, logits,
+                           (const long long*)labels, dlogits, 1.f / temperature, gs, dz, (int)B, (int)(D / 4), (int)C);
+    else
+        hipLaunchKernelGGL(l2norm_sim_ce_bwd_kernel<8>, grid, dim3(256), 0, s, z, inv_norm, w_new, tn, logits,
+                           (const long long*)labels, dlogits, 1.f / temperature, gs, dz, (int)B, (int)(D / 4), (int)C);
+    DBMM_CHECK_LAUNCH();
+    return DBMM_OK;
+}
+
+extern "C" int dbmm_sgd_momentum(int64_t n, float* const* params, const float* const* grads, float* const* bufs,
+                                 const int64_t* sizes, float lr, float momentum, float weight_decay, int first_step,
+                                 void* stream) {
+    if (!params || !grads || !bufs || !sizes) return DBMM_E_ARG;
+    if (n <= 0 || n > 16) return DBMM_E_SHAPE;
+    SgdArgs a{};
+    long long mx = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!params[i] || !grads[i] || !bufs[i] || sizes[i] <= 0) return DBMM_E_ARG;
+        a.p[i] = params[i]; a.g[i] = grads[i]; a.m[i] = bufs[i]; a.n[i] = sizes[i];
+        if (sizes[i] > mx) mx = sizes[i];
+    }
+    long long bx = (mx + 1023) / 1024;
+    if (bx > 1024) bx = 1024;
+    hipLaunchKernelGGL(sgd_kernel, dim3((unsigned)bx, (unsigned)n), dim3(256), 0, (hipStream_t)stream, a, lr, momentum,
+                       weight_decay, first_step);
+    DBMM_CHECK_LAUNCH();
+    return DBMM_OK;
+}
+
+extern "C" int dbmm_group_count(const float* logits, const int64_t* y, const int64_t* g, int64_t* counts, int64_t B,
+                                int64_t C, int64_t G, void* stream) {
+    if (!logits || !y || !g || !counts) return DBMM_E_ARG;
+    if (B <= 0 || C <= 0 || G <= 0 || G > 64 || B > INT32_MAX) return DBMM_E_SHAPE;
+    hipLaunchKernelGGL(group_count_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, (hipStream_t)stream, logits,
+                       (const long long*)y, (const long long*)g, (unsigned long long*)counts, (int)B, (int)C, (int)G);
+    DBMM_CHECK_LAUNCH();
+    return DBMM_OK;
+}
+
+extern "C" int dbmm_group_loss_sum(const float* loss_rows, const int64_t* g, float* sums, int64_t B, int64_t G,
+                                   void* stream) {
+    if (!loss_rows || !g || !sums) return DBMM_E_ARG;
+    if (B <= 0 || G <= 0 || G > 64 || B > INT32_MAX) return DBMM_E_SHAPE;
+    hipLaunchKernelGGL(group_loss_sum_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, loss_rows,
+                       (const long long*)g, sums, (int)B, (int)G);
+    DBMM_CHECK_LAUNCH();
+    return DBMM_OK;
+}
+
+extern "C" int dbmm_version(void) { return 100; }
+
+extern "C" const char* dbmm_error_string(int code) {
+    switch (code) {
+        case DBMM_OK: return "ok";
+        case DBMM_E_SHAPE: return "unsupported or inconsistent dimensions";
+        case DBMM_E_ALIGN: return "pointer or leading dimension not 16-byte aligned";
+        case DBMM_E_WORKSPACE: return "workspace too small";
+        case DBMM_E_ARG: return "null pointer or bad enum";
+        default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown dbmm error";
+    }
+}

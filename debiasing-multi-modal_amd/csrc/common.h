@@ -1,0 +1,37 @@
+// Shared helpers for the gfx950 kernels of libdbmm_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/dbmm.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define DBMM_CHECK_LAUNCH()                      \
+    do {                                         \
+        hipError_t e__ = hipGetLastError();      \
+        if (e__ != hipSuccess) return (int)e__;  \
+    } while (0)
+
+static inline bool dbmm_aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
+
+// wave64 butterfly sum / max (all lanes get the result)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// Bijective XCD-aware remap of a linear workgroup id: blocks are dealt round-robin over the
+// 8 XCDs, so give each XCD a contiguous range of tile ids (neighbouring tiles share operand
+// panels in that XCD's L2).  Speed only, never correctness.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}

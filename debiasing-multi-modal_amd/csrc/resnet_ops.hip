@@ -1,0 +1,193 @@
+// ModifiedResNet kernels that are not GEMM-shaped: stem conv (Cin = 3), average pooling,
+// attention-pool token assembly and its one-query attention core.  All HBM-bound
+// (coalesced, float4 where the layout allows); the heavy projections go through
+// dbmm_gemm_bias_act.
+#include "common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------
+// stem conv1: 3x3, stride 2, pad 1, Cin = 3, NCHW image -> NHWC, + bias (folded BN) + ReLU.
+// One thread per output pixel: its 27 input taps live in registers, weights [27][Cout] are
+// broadcast from LDS in groups of 8 output channels.  0.2 % of the network's FLOPs.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void stem_s2_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                      const float* __restrict__ bias, float* __restrict__ y,
+                                                      int B, int H, int W, int Ho, int Wo, int Cout) {
+    extern __shared__ __attribute__((aligned(16))) float sw[];  // [27][Cout] then bias[Cout]
+    for (int i = threadIdx.x; i < 27 * Cout; i += blockDim.x) sw[i] = w[i];
+    for (int i = threadIdx.x; i < Cout; i += blockDim.x) sw[27 * Cout + i] = bias ? bias[i] : 0.f;
+    __syncthreads();
+    const long long m = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long M = (long long)B * Ho * Wo;
+    if (m >= M) return;
+    const int wo = (int)(m % Wo), ho = (int)((m / Wo) % Ho), n = (int)(m / ((long long)Wo * Ho));
+    float xin[27];
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+            const int hi = ho * 2 - 1 + kh, wi = wo * 2 - 1 + kw;
+            const bool ok = hi >= 0 && hi < H && wi >= 0 && wi < W;
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                xin[(kh * 3 + kw) * 3 + c] = ok ? x[(((long long)n * 3 + c) * H + hi) * W + wi] : 0.f;
+        }
+    float* yo = y + m * Cout;
+    for (int c0 = 0; c0 < Cout; c0 += 8) {
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+#pragma unroll
+        for (int t = 0; t < 27; ++t) {
+            const f32x4 w0 = *(const f32x4*)(sw + t * Cout + c0);
+            const f32x4 w1 = *(const f32x4*)(sw + t * Cout + c0 + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc[j] = fmaf(xin[t], w0[j], acc[j]);
+                acc[4 + j] = fmaf(xin[t], w1[j], acc[4 + j]);
+            }
+        }
+        f32x4 o0, o1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            o0[j] = fmaxf(acc[j] + sw[27 * Cout + c0 + j], 0.f);
+            o1[j] = fmaxf(acc[4 + j] + sw[27 * Cout + c0 + 4 + j], 0.f);
+        }
+        *(f32x4*)(yo + c0) = o0;
+        *(f32x4*)(yo + c0 + 4) = o1;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// AvgPool2d(k), kernel = stride = k, NHWC, one float4 of channels per thread.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void avgpool_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                      int H, int W, int C4, int Ho, int Wo, int k,
+                                                      long long total) {
+    const float inv = 1.f / (float)(k * k);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4);
+        long long t = i / C4;
+        const int wo = (int)(t % Wo); t /= Wo;
+        const int ho = (int)(t % Ho);
+        const long long n = t / Ho;
+        const f32x4* src = (const f32x4*)x + ((n * H + (long long)ho * k) * W + (long long)wo * k) * C4 + c;
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        for (int a = 0; a < k; ++a)
+            for (int b = 0; b < k; ++b) s += src[((long long)a * W + b) * C4];
+        ((f32x4*)y)[i] = s * inv;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// attention-pool tokens: t[b][0] = mean_j x[b][j] + pos[0]; t[b][1+j] = x[b][j] + pos[1+j]
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attnpool_tokens_kernel(const float* __restrict__ x,
+                                                              const float* __restrict__ pos,
+                                                              float* __restrict__ t, int HW, int C4) {
+    const int b = blockIdx.y;
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C4) return;
+    const f32x4* xb = (const f32x4*)x + (long long)b * HW * C4 + c;
+    const f32x4* pp = (const f32x4*)pos + c;
+    f32x4* tb = (f32x4*)t + (long long)b * (HW + 1) * C4 + c;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < HW; ++j) {
+        const f32x4 v = xb[(long long)j * C4];
+        s += v;
+        tb[(long long)(j + 1) * C4] = v + pp[(long long)(j + 1) * C4];
+    }
+    tb[0] = s * (1.f / (float)HW) + pp[0];
+}
+
+// ---------------------------------------------------------------------------------------
+// one-query attention: per (image, head) one wave; q already scaled by hd^-0.5.
+// kv[b*L + j][0..C) = k, [C..2C) = v.  Lane d of the wave owns head dim d (hd = 64).
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void attnpool_core_kernel(const float* __restrict__ q,
+                                                           const float* __restrict__ kv,
+                                                           float* __restrict__ out, int L, int C) {
+    const int h = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+    const float qd = q[(long long)b * C + h * 64 + lane];
+    const float* kb = kv + (long long)b * L * 2 * C + h * 64 + lane;
+    float m = -INFINITY, l = 0.f, o = 0.f;
+    for (int j = 0; j < L; ++j) {
+        const float s = wave_sum(qd * kb[(long long)j * 2 * C]);
+        const float vj = kb[(long long)j * 2 * C + C];
+        const float mn = fmaxf(m, s);
+        const float sc = expf(m - mn), pj = expf(s - mn);
+        l = l * sc + pj;
+        o = o * sc + pj * vj;
+        m = mn;
+    }
+    out[(long long)b * C + h * 64 + lane] = o / l;
+}
+
+}  // namespace
+
+extern "C" int dbmm_conv_stem_s2(const float* x_nchw, const float* w, const float* bias, float* y_nhwc,
+                                 int64_t B, int64_t H, int64_t W, int64_t Cout, void* stream) {
+    if (!x_nchw || !w || !y_nhwc) return DBMM_E_ARG;
+    if (B <= 0 || H <= 0 || W <= 0 || Cout <= 0 || (Cout & 7) || Cout > 512) return DBMM_E_SHAPE;
+    if (!dbmm_aligned16(y_nhwc)) return DBMM_E_ALIGN;
+    const int64_t Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    const int64_t M = B * Ho * Wo;
+    if (M > INT32_MAX) return DBMM_E_SHAPE;
+    const size_t smem = (size_t)(28 * Cout) * sizeof(float);
+    hipLaunchKernelGGL(stem_s2_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), smem, (hipStream_t)stream,
+                       x_nchw, w, bias, y_nhwc, (int)B, (int)H, (int)W, (int)Ho, (int)Wo, (int)Cout);
+    DBMM_CHECK_LAUNCH();
+    return DBMM_OK;
+}
+
+extern "C" int dbmm_avgpool2d(const float* x, float* y, int64_t B, int64_t H, int64_t W, int64_t C, int64_t k,
+                              void* stream) {
+    if (!x || !y) return DBMM_E_ARG;
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || k <= 0 || (C & 3) || H % k || W % k) return DBMM_E_SHAPE;
+    if (!dbmm_aligned16(x) || !dbmm_aligned16(y)) return DBMM_E_ALIGN;
+    const int64_t Ho = H / k, Wo = W / k, C4 = C / 4;
+    const long long total = (long long)B * Ho * Wo * C4;
+    const long long blocks = (total + 255) / 256;
+    const unsigned grid = (unsigned)(blocks < 16384 ? blocks : 16384);
+    hipLaunchKernelGGL(avgpool_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, y, (int)H, (int)W,
+                       (int)C4, (int)Ho, (int)Wo, (int)k, total);
+    DBMM_CHECK_LAUNCH();
+    return DBMM_OK;
+}
+
+extern "C" size_t dbmm_workspace_bytes_attnpool(int64_t B, int64_t HW, int64_t C) {
+    // tokens [B][HW+1][C] + kv [B][HW+1][2C] + q [B][C] + o [B][C]
+    return (size_t)(B * (HW + 1) * C * 3 + 2 * B * C) * sizeof(float);
+}
+
+extern "C" int dbmm_attnpool(const float* x, const float* pos, const float* wq, const float* bq,
+                             const float* wkv, const float* bkv, const float* wc, const float* bc, float* out,
+                             int64_t B, int64_t HW, int64_t C, int64_t heads, int64_t Dout, void* workspace,
+                             size_t workspace_bytes, void* stream) {
+    if (!x || !pos || !wq || !wkv || !wc || !out || !workspace) return DBMM_E_ARG;
+    if (B <= 0 || HW <= 0 || C <= 0 || heads <= 0 || C != heads * 64 || (C & 3) || Dout <= 0) return DBMM_E_SHAPE;
+    if (workspace_bytes < dbmm_workspace_bytes_attnpool(B, HW, C)) return DBMM_E_WORKSPACE;
+    if (!dbmm_aligned16(x) || !dbmm_aligned16(pos) || !dbmm_aligned16(workspace)) return DBMM_E_ALIGN;
+    const int64_t L = HW + 1;
+    float* tok = (float*)workspace;
+    float* kv = tok + B * L * C;
+    float* q = kv + B * L * 2 * C;
+    float* o = q + B * C;
+    hipStream_t s = (hipStream_t)stream;
+    const int C4 = (int)(C / 4);
+    hipLaunchKernelGGL(attnpool_tokens_kernel, dim3((C4 + 255) / 256, (unsigned)B), dim3(256), 0, s, x, pos, tok,
+                       (int)HW, C4);
+    DBMM_CHECK_LAUNCH();
+    int rc;
+    // k and v projections of every token in one GEMM: [B*L, C] x [2C, C]^T
+    rc = dbmm_gemm_bias_act(tok, C, 0, wkv, C, 0, bkv, nullptr, 0, kv, 2 * C, B * L, 2 * C, C, 1.f, DBMM_ACT_NONE, stream);
+    if (rc) return rc;
+    // q projection of token 0 only (row stride L*C), scaled by head_dim^-0.5 after the bias
+    rc = dbmm_gemm_bias_act(tok, L * C, 0, wq, C, 0, bq, nullptr, 0, q, C, B, C, C, 0.125f, DBMM_ACT_NONE, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(attnpool_core_kernel, dim3((unsigned)heads, (unsigned)B), dim3(64), 0, s, q, kv, o, (int)L, (int)C);
+    DBMM_CHECK_LAUNCH();
+    return dbmm_gemm_bias_act(o, C, 0, wc, C, 0, bc, nullptr, 0, out, Dout, B, Dout, C, 1.f, DBMM_ACT_NONE, stream);
+}

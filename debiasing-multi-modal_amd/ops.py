@@ -1,0 +1,251 @@
+"""Tensor-level wrappers over the C ABI (include/dbmm.h).  Plumbing only: allocate outputs
+with torch's caching allocator, pass raw pointers + the current HIP stream, raise on error.
+Every function requires HIP tensors -- there is no CPU path here.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import check, ptr, require_cuda, stream
+
+ACT_NONE, ACT_RELU, ACT_QUICKGELU = 0, 1, 2
+
+
+def _f32c(t):
+    if t.dtype != torch.float32 or not t.is_contiguous():
+        raise _lib.DbmmError(f"expected a contiguous float32 tensor, got {t.dtype} contiguous={t.is_contiguous()}")
+    return t
+
+
+def gemm(a, w, bias=None, residual=None, act=ACT_NONE, alpha=1.0, trans_a=False, trans_w=False,
+         M=None, N=None, K=None, lda=None, out=None):
+    """c = act(alpha * (op(a) @ op(w)^T + bias) + residual); see dbmm_gemm_bias_act."""
+    require_cuda(a, w)
+    _f32c(w)
+    if a.dtype != torch.float32:
+        raise _lib.DbmmError("gemm needs float32")
+    if lda is None:
+        _f32c(a)
+        lda = a.shape[-1]
+    if M is None:
+        M = a.shape[-1] if trans_a else a.numel() // a.shape[-1]
+    if K is None:
+        K = a.numel() // a.shape[-1] if trans_a else a.shape[-1]
+    if N is None:
+        N = w.shape[1] if trans_w else w.shape[0]
+    if out is None:
+        out = torch.empty((M, N), device=a.device, dtype=torch.float32)
+    ldr = residual.shape[-1] if residual is not None else 0
+    check(_lib.lib().dbmm_gemm_bias_act(ptr(a), lda, int(trans_a), ptr(w), w.shape[-1], int(trans_w), ptr(bias),
+                                        ptr(residual), ldr, ptr(out), out.shape[-1], M, N, K, float(alpha), act,
+                                        stream()), "gemm_bias_act")
+    return out
+
+
+def conv_bn_act(x, w, bias, residual, kh, kw, stride, pad, act):
+    """x NHWC [B,H,W,Cin]; w packed [Cout][kh][kw][Cin] (BN folded); returns NHWC."""
+    require_cuda(x, w)
+    _f32c(x); _f32c(w)
+    B, H, W, Cin = x.shape
+    Cout = w.shape[0]
+    Ho = (H + 2 * pad - kh) // stride + 1
+    Wo = (W + 2 * pad - kw) // stride + 1
+    y = torch.empty((B, Ho, Wo, Cout), device=x.device, dtype=torch.float32)
+    check(_lib.lib().dbmm_conv_bn_act(ptr(x), ptr(w), ptr(bias), ptr(residual), ptr(y), B, H, W, Cin, Cout, kh, kw,
+                                      stride, pad, act, stream()), "conv_bn_act")
+    return y
+
+
+def conv_stem_s2(x_nchw, w, bias):
+    require_cuda(x_nchw, w)
+    _f32c(x_nchw); _f32c(w)
+    B, C, H, W = x_nchw.shape
+    if C != 3:
+        raise _lib.DbmmError("stem conv expects 3 input channels")
+    Cout = w.shape[-1]
+    y = torch.empty((B, (H - 1) // 2 + 1, (W - 1) // 2 + 1, Cout), device=x_nchw.device, dtype=torch.float32)
+    check(_lib.lib().dbmm_conv_stem_s2(ptr(x_nchw), ptr(w), ptr(bias), ptr(y), B, H, W, Cout, stream()), "conv_stem_s2")
+    return y
+
+
+def avgpool2d(x, k):
+    require_cuda(x)
+    _f32c(x)
+    B, H, W, C = x.shape
+    y = torch.empty((B, H // k, W // k, C), device=x.device, dtype=torch.float32)
+    check(_lib.lib().dbmm_avgpool2d(ptr(x), ptr(y), B, H, W, C, k, stream()), "avgpool2d")
+    return y
+
+
+def attnpool(x, pos, wq, bq, wkv, bkv, wc, bc, heads):
+    """x NHWC [B,h,w,C] feature map -> [B, Dout]."""
+    require_cuda(x)
+    _f32c(x)
+    B, H, W, C = x.shape
+    HW = H * W
+    Dout = wc.shape[0]
+    nbytes = _lib.lib().dbmm_workspace_bytes_attnpool(B, HW, C)
+    ws = torch.empty(nbytes // 4, device=x.device, dtype=torch.float32)
+    out = torch.empty((B, Dout), device=x.device, dtype=torch.float32)
+    check(_lib.lib().dbmm_attnpool(ptr(x), ptr(pos), ptr(wq), ptr(bq), ptr(wkv), ptr(bkv), ptr(wc), ptr(bc),
+                                   ptr(out), B, HW, C, heads, Dout, ptr(ws), nbytes, stream()), "attnpool")
+    return out
+
+
+def layernorm(x, gamma, beta, rows=None, ldx=None, eps=1e-5):
+    require_cuda(x)
+    E = gamma.numel()
+    if rows is None:
+        rows = x.numel() // E
+    if ldx is None:
+        ldx = E
+    y = torch.empty((rows, E), device=x.device, dtype=torch.float32)
+    check(_lib.lib().dbmm_layernorm(ptr(x), ldx, ptr(gamma), ptr(beta), ptr(y), E, rows, E, eps, stream()), "layernorm")
+    return y
+
+
+def mha_core(qkv, B, L, E, heads, causal):
+    require_cuda(qkv)
+    out = torch.empty((B * L, E), device=qkv.device, dtype=torch.float32)
+    check(_lib.lib().dbmm_mha_core(ptr(qkv), ptr(out), B, L, E, heads, int(causal), stream()), "mha_core")
+    return out
+
+
+def embed_gather(tokens, table, pos):
+    require_cuda(tokens, table)
+    if tokens.dtype != torch.int32:
+        tokens = tokens.to(torch.int32)
+    tokens = tokens.contiguous()
+    n, L = tokens.shape
+    W = table.shape[1]
+    out = torch.empty((n, L, W), device=table.device, dtype=torch.float32)
+    check(_lib.lib().dbmm_embed_gather(ptr(tokens), ptr(table), ptr(pos), ptr(out), n, L, W, table.shape[0], stream()),
+          "embed_gather")
+    return out, tokens
+
+
+def im2col_patch(x_nchw, P):
+    require_cuda(x_nchw)
+    _f32c(x_nchw)
+    B, C, R, _ = x_nchw.shape
+    g = R // P
+    out = torch.empty((B * g * g, 3 * P * P), device=x_nchw.device, dtype=torch.float32)
+    check(_lib.lib().dbmm_im2col_patch(ptr(x_nchw), ptr(out), B, R, P, stream()), "im2col_patch")
+    return out
+
+
+def vit_tokens(patches, cls, pos, B):
+    L, W = pos.shape
+    out = torch.empty((B, L, W), device=patches.device, dtype=torch.float32)
+    check(_lib.lib().dbmm_vit_tokens(ptr(patches), ptr(cls), ptr(pos), ptr(out), B, L, W, stream()), "vit_tokens")
+    return out
+
+
+def gather_eot(tokens_i32, x):
+    n, L, W = x.shape
+    out = torch.empty((n, W), device=x.device, dtype=torch.float32)
+    check(_lib.lib().dbmm_gather_eot(ptr(tokens_i32), ptr(x), ptr(out), n, L, W, stream()), "gather_eot")
+    return out
+
+
+def text_colnorm(text):
+    """[D, C] -> normalised, transposed [C, D]."""
+    require_cuda(text)
+    _f32c(text)
+    D, C = text.shape
+    tn = torch.empty((C, D), device=text.device, dtype=torch.float32)
+    check(_lib.lib().dbmm_text_colnorm(ptr(text), ptr(tn), D, C, stream()), "text_colnorm")
+    return tn
+
+
+def l2norm_sim_ce_fwd(z, tn, temperature, labels=None, z_old=None, ebd_weight=0.5, want_loss=True, want_pred=False):
+    require_cuda(z, tn)
+    _f32c(z)
+    B, D = z.shape
+    C = tn.shape[0]
+    dev = z.device
+    logits = torch.empty((B, C), device=dev, dtype=torch.float32)
+    inv_norm = torch.empty((B,), device=dev, dtype=torch.float32)
+    loss_rows = loss_mean = pred = None
+    if labels is not None and want_loss:
+        loss_rows = torch.empty((B,), device=dev, dtype=torch.float32)
+        loss_mean = torch.empty((), device=dev, dtype=torch.float32)
+    if want_pred:
+        pred = torch.empty((B,), device=dev, dtype=torch.int64)
+    check(_lib.lib().dbmm_l2norm_sim_ce_fwd(ptr(z), ptr(z_old), float(ebd_weight), ptr(tn), ptr(labels),
+                                            float(temperature), ptr(logits), ptr(loss_rows), ptr(loss_mean), ptr(pred),
+                                            ptr(inv_norm), B, D, C, stream()), "l2norm_sim_ce_fwd")
+    return logits, loss_rows, loss_mean, pred, inv_norm
+
+
+def l2norm_sim_ce_bwd(z, inv_norm, tn, temperature, logits=None, labels=None, dlogits=None, blended=False,
+                      ebd_weight=0.5, grad_scale=1.0):
+    B, D = z.shape
+    C = tn.shape[0]
+    dz = torch.empty_like(z)
+    check(_lib.lib().dbmm_l2norm_sim_ce_bwd(ptr(z), ptr(inv_norm), float(ebd_weight), int(blended), ptr(tn), ptr(logits),
+                                            ptr(labels), ptr(dlogits), float(temperature), float(grad_scale), ptr(dz),
+                                            B, D, C, stream()), "l2norm_sim_ce_bwd")
+    return dz
+
+
+def adapter_fwd(x, w1, b1, gamma, beta, running_mean, running_var, nbt, w2, b2, train, eps=1e-5, momentum=0.1):
+    require_cuda(x, w1)
+    _f32c(x)
+    B, D = x.shape
+    H = w1.shape[0]
+    dev = x.device
+    h = torch.empty((B, H), device=dev, dtype=torch.float32)
+    r = torch.empty((B, H), device=dev, dtype=torch.float32)
+    z = torch.empty((B, D), device=dev, dtype=torch.float32)
+    mean = torch.empty((H,), device=dev, dtype=torch.float32) if train else None
+    invstd = torch.empty((H,), device=dev, dtype=torch.float32) if train else None
+    check(_lib.lib().dbmm_adapter_fwd(ptr(x), ptr(w1), ptr(b1), ptr(gamma), ptr(beta), ptr(running_mean),
+                                      ptr(running_var), ptr(nbt), ptr(w2), ptr(b2), ptr(h), ptr(mean), ptr(invstd),
+                                      ptr(r), ptr(z), B, D, H, int(train), eps, momentum, stream()), "adapter_fwd")
+    return z, h, mean, invstd, r
+
+
+def adapter_bwd(x, dz, h, mean, invstd, r, gamma, beta, w2):
+    B, D = x.shape
+    H = h.shape[1]
+    dev = x.device
+    f = dict(device=dev, dtype=torch.float32)
+    dw1, db1 = torch.empty((H, D), **f), torch.empty((H,), **f)
+    dgamma, dbeta = torch.empty((H,), **f), torch.empty((H,), **f)
+    dw2, db2 = torch.empty((D, H), **f), torch.empty((D,), **f)
+    nbytes = _lib.lib().dbmm_workspace_bytes_adapter_bwd(B, D, H)
+    ws = torch.empty(nbytes // 4, **f)
+    check(_lib.lib().dbmm_adapter_bwd(ptr(x), ptr(dz), ptr(h), ptr(mean), ptr(invstd), ptr(r), ptr(gamma), ptr(beta),
+                                      ptr(w2), ptr(dw1), ptr(db1), ptr(dgamma), ptr(dbeta), ptr(dw2), ptr(db2), B, D, H,
+                                      ptr(ws), nbytes, stream()), "adapter_bwd")
+    return dw1, db1, dgamma, dbeta, dw2, db2, ws[B * H:].view(B, H)   # last = dh (for an optional dx)
+
+
+def sgd_momentum(params, grads, bufs, lr, momentum, weight_decay, first_step):
+    n = len(params)
+    for i in range(0, n, 16):
+        ps, gs, bs = params[i:i + 16], grads[i:i + 16], bufs[i:i + 16]
+        m = len(ps)
+        P = (ctypes.c_void_p * m)(*[p.data_ptr() for p in ps])
+        G = (ctypes.c_void_p * m)(*[g.data_ptr() for g in gs])
+        Bf = (ctypes.c_void_p * m)(*[b.data_ptr() for b in bs])
+        S = (ctypes.c_int64 * m)(*[p.numel() for p in ps])
+        check(_lib.lib().dbmm_sgd_momentum(m, P, G, Bf, S, float(lr), float(momentum), float(weight_decay),
+                                           int(first_step), stream()), "sgd_momentum")
+
+
+def group_count(logits, y, g, counts):
+    """counts int64 [G,2] accumulated in place: (n, correct) per group."""
+    require_cuda(logits, y, g, counts)
+    B, C = logits.shape
+    check(_lib.lib().dbmm_group_count(ptr(logits), ptr(y), ptr(g), ptr(counts), B, C, counts.shape[0], stream()),
+          "group_count")
+    return counts
+
+
+def group_loss_sum(loss_rows, g, sums):
+    check(_lib.lib().dbmm_group_loss_sum(ptr(loss_rows), ptr(g), ptr(sums), loss_rows.shape[0], sums.shape[0], stream()),
+          "group_loss_sum")
+    return sums

@@ -1,0 +1,209 @@
+/*
+ * dbmm.h -- C ABI of libdbmm_hip.so: the MI355X (gfx950) kernels under the reference's
+ * CLIP-embedding + debiasing-adapter hot path.
+ *
+ * The reference (Lainshower/debiasing-multi-modal) is pure PyTorch: it has no native
+ * boundary of its own.  Each entry point below replaces the ATen operator sequence at the
+ * cited reference site (paths relative to /root/reference); the Python mirror of the
+ * reference classes in debiasing-multi-modal_amd/ binds them through ctypes
+ * (INTEGRATION.md shows the stub a maintainer would add).
+ *
+ * Conventions
+ *   - plain pointers + int64 sizes; no torch / hip types in signatures (`stream` is a
+ *     hipStream_t passed as void*; NULL = the null stream).
+ *   - the caller owns every buffer, including workspaces; the library never allocates,
+ *     frees, retains pointers or synchronises.  All work is enqueued on `stream`.
+ *   - return 0 on success, a negative DBMM_E_* for shape/alignment violations, or the
+ *     positive hipError_t of a failed launch.  Never throws, never aborts.
+ *   - activations are fp32, channels-last (NHWC) inside the library; image input is the
+ *     reference's NCHW and is converted by the first kernel that touches it.
+ *   - all float pointers must be 16-byte aligned; leading dimensions multiples of 4.
+ */
+#ifndef DBMM_H
+#define DBMM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DBMM_OK 0
+#define DBMM_E_SHAPE (-1)     /* unsupported / inconsistent dimensions            */
+#define DBMM_E_ALIGN (-2)     /* pointer or leading dimension not 16-byte aligned */
+#define DBMM_E_WORKSPACE (-3) /* workspace too small                              */
+#define DBMM_E_ARG (-4)       /* null pointer / bad enum                          */
+
+#define DBMM_ACT_NONE 0
+#define DBMM_ACT_RELU 1
+#define DBMM_ACT_QUICKGELU 2 /* x * sigmoid(1.702 x), clip/model.py:166-168 */
+
+int dbmm_version(void);
+const char* dbmm_error_string(int code);
+
+/* ---------------------------------------------------------------------------------------
+ * Dense contractions on fp32 MFMA (v_mfma_f32_32x32x2_f32), LDS-tiled implicit GEMM.
+ * ------------------------------------------------------------------------------------ */
+
+/* y[B,Ho,Wo,Cout] = act( conv(x[B,H,W,Cin], w) + bias + residual ), NHWC, BatchNorm already
+ * folded into (w, bias) by the caller.  w is [Cout][KH][KW][Cin].  Cin % 4 == 0.
+ * Replaces conv->bn->relu(->add) of Bottleneck.forward (clip/model.py:45-54) and the stem
+ * convs 2/3 (clip/model.py:141-142).  residual may be NULL; it has y's shape. */
+int dbmm_conv_bn_act(const float* x, const float* w, const float* bias, const float* residual,
+                     float* y, int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t Cout,
+                     int64_t KH, int64_t KW, int64_t stride, int64_t pad, int act, void* stream);
+/* named specialisations of the above */
+int dbmm_conv1x1_bn_act(const float* x, const float* w, const float* bias, const float* residual,
+                        float* y, int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t Cout,
+                        int act, void* stream);
+int dbmm_conv3x3_bn_act(const float* x, const float* w, const float* bias, const float* residual,
+                        float* y, int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t Cout,
+                        int act, void* stream);
+
+/* c[M,N] = act( alpha * (op(a) @ op(w)^T + bias) + residual )
+ *   trans_a = 0: a is [M][lda] (K contiguous);  1: a is [K][lda] (M contiguous)
+ *   trans_w = 0: w is [N][ldw] (K contiguous, i.e. nn.Linear.weight); 1: w is [K][ldw]
+ * Replaces F.linear / addmm at clip/model.py:72-90 (attention-pool projections), :185-191
+ * (QKV / out_proj / c_fc+QuickGELU / c_proj with residual), :238, :354 (projections) and the
+ * adapter Linear layers and their weight/input gradients (final_main.py:167-172). */
+int dbmm_gemm_bias_act(const float* a, int64_t lda, int trans_a, const float* w, int64_t ldw,
+                       int trans_w, const float* bias, const float* residual, int64_t ldr,
+                       float* c, int64_t ldc, int64_t M, int64_t N, int64_t K, float alpha,
+                       int act, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * ModifiedResNet pieces (clip/model.py:94-154)
+ * ------------------------------------------------------------------------------------ */
+
+/* stem conv1: 3x3 stride 2 pad 1 on the NCHW image, BN folded, ReLU, NHWC out
+ * (clip/model.py:108-110,140).  w is [3][3][3][Cout] = (kh, kw, cin, cout). */
+int dbmm_conv_stem_s2(const float* x_nchw, const float* w, const float* bias, float* y_nhwc,
+                      int64_t B, int64_t H, int64_t W, int64_t Cout, void* stream);
+
+/* AvgPool2d(k) with kernel = stride = k, NHWC (clip/model.py:25,37,117). C % 4 == 0. */
+int dbmm_avgpool2d(const float* x, float* y, int64_t B, int64_t H, int64_t W, int64_t C,
+                   int64_t k, void* stream);
+
+/* AttentionPool2d.forward (clip/model.py:68-91) on x[B,HW,C] (NHWC feature map).
+ *   pos [HW+1][C]; wq [C][C] bq [C]; wkv [2C][C] bkv [2C] (k rows then v rows);
+ *   wc [Dout][C] bc [Dout]; out [B][Dout].
+ * workspace: dbmm_workspace_bytes_attnpool(B, HW, C) bytes. */
+size_t dbmm_workspace_bytes_attnpool(int64_t B, int64_t HW, int64_t C);
+int dbmm_attnpool(const float* x, const float* pos, const float* wq, const float* bq,
+                  const float* wkv, const float* bkv, const float* wc, const float* bc,
+                  float* out, int64_t B, int64_t HW, int64_t C, int64_t heads, int64_t Dout,
+                  void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Transformer pieces (clip/model.py:157-240, 343-356)
+ * ------------------------------------------------------------------------------------ */
+
+/* LayerNorm over the last dim, fp32 statistics (clip/model.py:157-163).
+ * x rows start at x + r*ldx (lets ln_post read only token 0 of every image). */
+int dbmm_layernorm(const float* x, int64_t ldx, const float* gamma, const float* beta, float* y,
+                   int64_t ldy, int64_t rows, int64_t E, float eps, void* stream);
+
+/* softmax(q k^T * hd^-0.5 [+ causal mask]) v for packed qkv[B*L][3E] (batch-first rows),
+ * head h uses columns [h*64, h*64+64) of each third.  head_dim must be 64 (all CLIP models).
+ * Replaces the attention core inside nn.MultiheadAttention (clip/model.py:185-187). */
+int dbmm_mha_core(const float* qkv, float* out, int64_t B, int64_t L, int64_t E, int64_t heads,
+                  int causal, void* stream);
+
+/* x[n][L][W] = table[tokens[n][l]] + pos[l]  (clip/model.py:344-346).  tokens int32. */
+int dbmm_embed_gather(const int32_t* tokens, const float* table, const float* pos, float* out,
+                      int64_t n, int64_t L, int64_t W, int64_t vocab, void* stream);
+
+/* patch im2col for the ViT stem conv (kernel = stride = P, clip/model.py:211,224):
+ * out[B*g*g][3*P*P] in (cin, kh, kw) order = the flattened conv weight's K order. */
+int dbmm_im2col_patch(const float* x_nchw, float* out, int64_t B, int64_t R, int64_t P, void* stream);
+
+/* tokens[B][g*g+1][W] = concat(class_embedding, patches[B][g*g][W]) + pos (clip/model.py:227-228) */
+int dbmm_vit_tokens(const float* patches, const float* cls, const float* pos, float* out,
+                    int64_t B, int64_t L, int64_t W, void* stream);
+
+/* out[n][W] = x[n][eot[n]][W] where eot[n] = argmax_l tokens[n][l] (clip/model.py:354) */
+int dbmm_gather_eot(const int32_t* tokens, const float* x, float* out, int64_t n, int64_t L,
+                    int64_t W, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Adapter step (final_main.py:53-174, 426-496; demo/util.py:118-136)
+ * ------------------------------------------------------------------------------------ */
+
+/* BatchNorm1d batch statistics of h[B][H] (train mode): mean, invstd = rsqrt(biased var+eps);
+ * running stats updated with momentum and the unbiased variance; nbt (int64) += 1.
+ * running_* / nbt may be NULL. */
+int dbmm_bn1d_stats(const float* h, int64_t B, int64_t H, float eps, float momentum, float* mean,
+                    float* invstd, float* running_mean, float* running_var, int64_t* nbt,
+                    void* stream);
+
+/* r = relu(gamma * (h - mean) * invstd + beta).  var_mode = 1: the `invstd` argument holds a
+ * variance (running_var, eval mode) and rsqrt(var + eps) is applied on the fly. */
+int dbmm_bn1d_relu(const float* h, const float* mean, const float* invstd, const float* gamma,
+                   const float* beta, float* r, int64_t B, int64_t H, int var_mode, float eps,
+                   void* stream);
+
+/* Adapter.forward (final_main.py:173): z = Linear2(relu(bn(Linear1(x)))).
+ * train != 0: batch statistics (saved to mean/invstd, running stats updated).
+ * Saves h (pre-BN) and r (post-ReLU) for the backward pass. */
+int dbmm_adapter_fwd(const float* x, const float* w1, const float* b1, const float* gamma,
+                     const float* beta, float* running_mean, float* running_var, int64_t* nbt,
+                     const float* w2, const float* b2, float* h, float* mean, float* invstd,
+                     float* r, float* z, int64_t B, int64_t D, int64_t H, int train, float eps,
+                     float momentum, void* stream);
+
+/* Gradients of the adapter parameters given dz = dLoss/dz[B][D] (no grad w.r.t. x:
+ * embeddings.detach(), final_main.py:455).  workspace: dbmm_workspace_bytes_adapter_bwd. */
+size_t dbmm_workspace_bytes_adapter_bwd(int64_t B, int64_t D, int64_t H);
+int dbmm_adapter_bwd(const float* x, const float* dz, const float* h, const float* mean,
+                     const float* invstd, const float* r, const float* gamma, const float* beta,
+                     const float* w2, float* dw1, float* db1, float* dgamma, float* dbeta,
+                     float* dw2, float* db2, int64_t B, int64_t D, int64_t H, void* workspace,
+                     size_t workspace_bytes, void* stream);
+
+/* tn[C][D] = (text[D][C] / ||text[:,c]||)^T  (final_main.py:77, column normalisation) */
+int dbmm_text_colnorm(const float* text, float* tn, int64_t D, int64_t C, void* stream);
+
+/* Fused row L2-norm + image x text logits + cross-entropy (final_main.py:68,78,302;
+ * MultipleAdapter blend :123-127,138; zero-shot tail clip_inference.py:207-216):
+ *   f = z/||z||;  feat = f                      (z_old == NULL)
+ *                 feat = w*z_old/||z_old|| + (1-w)*f
+ *   logits[b][c] = feat . tn[c] / T;   loss_rows[b] = CE(logits[b], labels[b]);
+ *   pred[b] = argmax_c logits[b][c].
+ * inv_norm[B] (1/||z||) is saved for the backward.  labels/loss_rows/pred/inv_norm may be
+ * NULL.  C <= 8.  loss_mean (1 float, may be NULL) = mean of loss_rows. */
+int dbmm_l2norm_sim_ce_fwd(const float* z, const float* z_old, float ebd_weight, const float* tn,
+                           const int64_t* labels, float temperature, float* logits,
+                           float* loss_rows, float* loss_mean, int64_t* pred, float* inv_norm,
+                           int64_t B, int64_t D, int64_t C, void* stream);
+
+/* dz[B][D] through the blend weight (1-w) and the row normalisation.
+ *   dlogits == NULL: loss = grad_scale * mean_b CE; the softmax is recomputed from `logits`
+ *                    and `labels` (fused training path).
+ *   dlogits != NULL: dLoss/dlogits [B][C] is given by the caller (autograd of an external
+ *                    criterion, e.g. nn.CrossEntropyLoss at final_main.py:456); logits, labels
+ *                    and grad_scale are ignored. */
+int dbmm_l2norm_sim_ce_bwd(const float* z, const float* inv_norm, float ebd_weight, int blended,
+                           const float* tn, const float* logits, const int64_t* labels,
+                           const float* dlogits, float temperature, float grad_scale, float* dz,
+                           int64_t B, int64_t D, int64_t C, void* stream);
+
+/* torch.optim.SGD step (demo/util.py:118-136; dampening 0, no nesterov) on n tensors in one
+ * launch: g' = g + wd*p; buf = first ? g' : mu*buf + g'; p -= lr*buf.   n <= 16. */
+int dbmm_sgd_momentum(int64_t n, float* const* params, const float* const* grads,
+                      float* const* bufs, const int64_t* sizes, float lr, float momentum,
+                      float weight_decay, int first_step, void* stream);
+
+/* update_dict (final_main.py:383-391) on device: counts[g][0] += 1, counts[g][1] += (argmax
+ * logits == y) for every row; counts is int64 [G][2], accumulated (not cleared). */
+int dbmm_group_count(const float* logits, const int64_t* y, const int64_t* g, int64_t* counts,
+                     int64_t B, int64_t C, int64_t G, void* stream);
+
+/* Per-group mean CE (build-side addition): sums[g] += loss_rows over g. */
+int dbmm_group_loss_sum(const float* loss_rows, const int64_t* g, float* sums, int64_t B,
+                        int64_t G, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DBMM_H */

@@ -1,0 +1,174 @@
+"""Adapter step parity on the MI355X: CustomCLIP / MultipleAdapter forward, CE, backward and
+SGD through the HIP path against the reference-generated fixtures (tests/golden/adapter.npz)
+and the oracle.  Index tensors (group counts, predictions) are bit-exact."""
+import copy
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import adapter_oracle as AO
+from conftest import relerr, summary
+from dbmm_amd import adapter, optim, synth
+
+pytestmark = pytest.mark.gpu
+D, H = 1024, 128
+
+
+@pytest.fixture(scope="module")
+def text_paths(tmp_path_factory):
+    d = tmp_path_factory.mktemp("text")
+    mats = dict(clip_class=(synth.text_matrix(1, D, 2, "class"), ["c0", "c1"]),
+                clip_spurious=(synth.text_matrix(1, D, 2, "spurious"), ["s0", "s1"]),
+                clip_group=(synth.text_matrix(1, D, 4, "group"), ["g0", "g1", "g2", "g3"]))
+    paths = []
+    for name, (m, cols) in mats.items():
+        p = os.path.join(d, name + ".json")
+        json.dump({n: m[:, i].numpy().tolist() for i, n in enumerate(cols)}, open(p, "w"))
+        paths.append(p)
+    return paths
+
+
+def _check(g, tag, name, t, tol=1e-4):
+    t = t.detach().float().cpu()
+    if tag.endswith("/grad") and name.endswith("layers.0.bias"):
+        assert t.abs().max() < 1e-5          # analytically zero (bias in front of train-mode BN)
+    elif f"{tag}/{name}" in g.files:
+        assert relerr(t, g[f"{tag}/{name}"]) < tol, (tag, name, relerr(t, g[f"{tag}/{name}"]))
+    else:
+        _, sample = summary(t)
+        ref = g[f"{tag}/{name}_sample"]
+        assert np.abs(sample - ref).max() <= tol * max(np.abs(ref).max(), 1e-6), (tag, name)
+
+
+def _ns(**k):
+    from types import SimpleNamespace
+    return SimpleNamespace(learning_rate=0.1, learning_rate_reg=0.05, momentum=0.9, weight_decay=5e-5, **k)
+
+
+@pytest.mark.parametrize("B", [4, 256, 1024])
+@pytest.mark.parametrize("fused", [False, True])
+def test_custom_clip_and_multiple_adapter(B, fused, golden, text_paths):
+    g = golden("adapter.npz")
+    x = synth.normal(5, f"x{B}", (B, D), 0.5).cuda()
+    y, c, grp = (t.cuda() for t in synth.labels(6, B))
+    crit = torch.nn.CrossEntropyLoss()
+    stage1 = None
+    for use_group in (False, True):
+        tag = f"custom_B{B}_{'group' if use_group else 'class'}"
+        ad = adapter.Adapter(D, H); ad.load_state_dict(synth.adapter_state_dict(3, D, H))
+        clf = adapter.CustomCLIP(ad, *text_paths, temperature=0.01).cuda()
+        opt = optim.set_optimizer(_ns(), clf)
+        labels = grp if use_group else y
+        clf.train()
+        for step in range(3):
+            if fused:
+                loss, logits, _ = clf.loss(x.detach(), labels, use_group)
+            else:
+                logits = clf(x.detach(), use_group)
+                loss = crit(logits, labels)
+            opt.zero_grad(); loss.backward()
+            if step == 0:
+                assert (logits.detach().cpu() - torch.from_numpy(g[tag + "/step0/logits"])).abs().max() < 1e-3
+                assert abs(loss.item() - float(g[tag + "/step0/loss"])) < 1e-4 * max(1.0, abs(loss.item()))
+                for n, p in clf.named_parameters():
+                    _check(g, tag + "/step0/grad", n, p.grad, 2e-4)
+            opt.step()
+        for k, v in clf.state_dict().items():
+            if v.dtype.is_floating_point:
+                _check(g, tag + "/after3", k, v, 2e-4)
+            else:
+                assert int(v) == int(g[f"{tag}/after3/{k}"])
+        clf.eval()
+        with torch.no_grad():
+            ev, evs = clf(x), clf.forward_spurious(x)
+        assert (ev.cpu() - torch.from_numpy(g[tag + "/eval/logits"])).abs().max() < 2e-3
+        assert (evs.cpu() - torch.from_numpy(g[tag + "/eval/logits_spurious"])).abs().max() < 2e-3
+        if not use_group:
+            meters = {i: adapter.AverageMeter() for i in range(4)}
+            adapter.update_dict(meters, y, grp, torch.from_numpy(g[tag + "/eval/logits"]).cuda())
+            cnt = np.array([[m.count, round(m.sum)] for m in meters.values()])
+            assert (cnt == g[tag + "/counts"]).all()                     # int counts bit-exact
+            from functools import partial
+            res = adapter.get_results(meters, partial(adapter.get_y_p, n_places=2))
+            assert np.array_equal(np.array([res[k] for k in sorted(res)]), g[tag + "/results"])
+            stage1 = clf
+    for ni in (True, False):
+        for use_group in (False, True):
+            tag = f"multi_B{B}_{'ni' if ni else 'rn'}_{'group' if use_group else 'class'}"
+            old = copy.deepcopy(stage1)
+            new_ad = adapter.Adapter(D, H); new_ad.load_state_dict(synth.adapter_state_dict(4, D, H))
+            import contextlib, io
+            with contextlib.redirect_stdout(io.StringIO()):
+                ma = adapter.MultipleAdapter(old, new_ad, init_near_identity=ni, ebd_weight=0.5).cuda()
+            opt = optim.set_optimizer_reg(_ns(), ma)
+            assert sum(len(gr["params"]) for gr in opt.param_groups) == 6
+            labels = grp if use_group else y
+            ma.train()
+            for step in range(3):
+                if fused:
+                    loss, logits, _ = ma.loss(x.detach(), labels, use_group)
+                else:
+                    logits = ma(x.detach(), use_group); loss = crit(logits, labels)
+                opt.zero_grad(); loss.backward()
+                if step == 0:
+                    assert (logits.detach().cpu() - torch.from_numpy(g[tag + "/step0/logits"])).abs().max() < 2e-3
+                    for n, p in ma.named_parameters():
+                        if "old_cls" in n:
+                            assert p.grad is None
+                        else:
+                            _check(g, tag + "/step0/grad", n, p.grad, 3e-4)
+                opt.step()
+            for k, v in ma.state_dict().items():
+                if v.dtype.is_floating_point:
+                    _check(g, tag + "/after3", k, v, 3e-4)
+            ma.eval()
+            with torch.no_grad():
+                assert (ma(x).cpu() - torch.from_numpy(g[tag + "/eval/logits"])).abs().max() < 3e-3
+
+
+def test_per_group_loss_and_flags(text_paths):
+    B = 512
+    x = synth.normal(5, "xx", (B, D), 0.5)
+    y, c, grp = synth.labels(6, B)
+    ad = adapter.Adapter(D, H); ad.load_state_dict(synth.adapter_state_dict(3, D, H))
+    clf = adapter.CustomCLIP(ad, *text_paths).cuda().train()
+    loss, logits, rows = clf.loss(x.cuda(), y.cuda())
+    ref = AO.per_group_loss(logits.cpu(), y, grp)
+    out = adapter.per_group_loss(rows, grp.cuda())
+    assert (out.cpu() - ref).abs().max() < 1e-3
+    pred = logits.argmax(1).cpu()
+    import clip_oracle as CO
+    for ds in ("waterbirds", "celeba"):
+        a, b = adapter.minority_flags(ds, y, c, pred)
+        ra, rb = CO.minority_flags(ds, y, c, pred)
+        assert torch.equal(a, ra) and torch.equal(b, rb) and a.dtype == torch.int64
+
+
+def test_training_trajectory_matches_oracle(text_paths):
+    """20 fused steps on synthetic embeddings: loss curve and final worst-group accuracy equal
+    the oracle's (stand-in for the +-0.2 pp accuracy criterion)."""
+    B = 256
+    x = synth.normal(8, "traj", (B, D), 0.5)
+    y, c, grp = synth.labels(9, B)
+    x = x + 0.3 * synth.normal(10, "sig", (1, D)) * (2 * y.float().unsqueeze(1) - 1)
+    tcls = synth.text_matrix(1, D, 2, "class")
+    osd = {"adapter." + k: v.clone() for k, v in synth.adapter_state_dict(3, D, H).items()}
+    obufs = {}
+    ad = adapter.Adapter(D, H); ad.load_state_dict(synth.adapter_state_dict(3, D, H))
+    clf = adapter.CustomCLIP(ad, *text_paths).cuda().train()
+    opt = optim.set_optimizer(_ns(), clf)
+    xd, yd = x.cuda(), y.cuda()
+    for step in range(20):
+        ol, ologits, _ = AO.train_step(osd, obufs, x, y, tcls, 0.1)
+        loss, logits, _ = clf.loss(xd, yd)
+        opt.zero_grad(); loss.backward(); opt.step()
+        assert abs(loss.item() - ol.item()) < 2e-3 * max(1.0, abs(ol.item())), step
+    clf.eval()
+    with torch.no_grad():
+        ev = clf(xd)
+    oev = AO.custom_clip_logits(osd, x, tcls, 0.01, train=False)
+    cnt = adapter.group_counts(ev, yd, grp.cuda(), 4).cpu().numpy()
+    assert (cnt == AO.group_counts(oev, y, grp)).all()

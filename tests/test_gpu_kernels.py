@@ -1,0 +1,287 @@
+"""Kernel-level parity: every C-ABI entry point against a plain torch-CPU fp32 computation of
+the same op (the floating-point oracle for a single kernel), through the ctypes binding."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import clip_oracle as CO
+from conftest import relerr
+from dbmm_amd import ops, synth
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def rnd(seed, name, shape, std=1.0):
+    return synth.normal(seed, name, shape, std)
+
+
+GEMM_SHAPES = [
+    # M, N, K  -> exercises the 128x128, 128x64, 128x32 and 64x64 tiles, ragged edges, K tails
+    (512, 256, 128), (1000, 128, 64), (300, 64, 96), (257, 32, 288), (64, 1024, 2048),
+    (200, 136, 588), (50, 20, 36), (1024, 128, 1024), (4, 1024, 128),
+]
+
+
+@pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
+@pytest.mark.parametrize("ta,tw", [(False, False), (False, True), (True, False), (True, True)])
+def test_gemm_modes(M, N, K, ta, tw):
+    if ta and M % 4:
+        pytest.skip("K-major A needs M % 4 == 0")
+    if tw and N % 4:
+        pytest.skip("K-major W needs N % 4 == 0")
+    a = rnd(1, "a", (M, K)); w = rnd(2, "w", (N, K), K ** -0.5); b = rnd(3, "b", (N,))
+    ref = a @ w.t() + b
+    ad = (a.t().contiguous() if ta else a).to(DEV)
+    wd = (w.t().contiguous() if tw else w).to(DEV)
+    out = ops.gemm(ad, wd, b.to(DEV), trans_a=ta, trans_w=tw)
+    assert out.shape == (M, N)
+    assert relerr(out.cpu(), ref) < 2e-5
+
+
+@pytest.mark.parametrize("act", [ops.ACT_NONE, ops.ACT_RELU, ops.ACT_QUICKGELU])
+def test_gemm_epilogue(act):
+    M, N, K = 333, 192, 256
+    a = rnd(1, "a", (M, K)); w = rnd(2, "w", (N, K), K ** -0.5); b = rnd(3, "b", (N,)); r = rnd(4, "r", (M, N))
+    v = (a @ w.t() + b) * 0.125 + r
+    ref = {0: v, 1: F.relu(v), 2: v * torch.sigmoid(1.702 * v)}[act]
+    out = ops.gemm(a.to(DEV), w.to(DEV), b.to(DEV), residual=r.to(DEV), act=act, alpha=0.125)
+    assert relerr(out.cpu(), ref) < 2e-5
+
+
+def test_gemm_strided_rows():
+    """row stride > K: the q projection of attention-pool reads token 0 of every image."""
+    B, L, C = 37, 5, 64
+    t = rnd(1, "t", (B, L, C)); w = rnd(2, "w", (C, C), C ** -0.5)
+    out = ops.gemm(t.to(DEV), w.to(DEV), M=B, K=C, lda=L * C)
+    assert relerr(out.cpu(), t[:, 0] @ w.t()) < 2e-5
+
+
+def test_gemm_rejects_bad_shapes():
+    from dbmm_amd._lib import DbmmError
+    a = torch.zeros(8, 6, device=DEV); w = torch.zeros(4, 6, device=DEV)
+    with pytest.raises(DbmmError):
+        ops.gemm(a, w)                       # K % 4 != 0
+    with pytest.raises(DbmmError):
+        ops.gemm(torch.zeros(8, 8), torch.zeros(4, 8))   # CPU tensors: no fallback
+
+
+CONV_CASES = [
+    # B, H, W, Cin, Cout, k, stride, pad
+    (2, 16, 16, 32, 32, 3, 1, 1), (2, 16, 16, 32, 64, 3, 1, 1), (3, 14, 14, 64, 128, 3, 1, 1),
+    (2, 7, 7, 16, 48, 3, 1, 1), (1, 9, 11, 8, 40, 3, 1, 1), (2, 12, 12, 64, 256, 1, 1, 0),
+    (2, 13, 13, 32, 64, 3, 2, 1), (5, 7, 7, 512, 512, 3, 1, 1), (2, 56, 56, 64, 64, 3, 1, 1),
+]
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,k,stride,pad", CONV_CASES)
+def test_conv_bn_act(B, H, W, Cin, Cout, k, stride, pad):
+    x = rnd(1, "x", (B, Cin, H, W)); w = rnd(2, "w", (Cout, Cin, k, k), (Cin * k * k) ** -0.5)
+    bias = rnd(3, "b", (Cout,), 0.1)
+    ref = F.conv2d(x, w, bias, stride=stride, padding=pad)
+    res = rnd(4, "r", tuple(ref.shape))
+    ref = F.relu(ref + res).permute(0, 2, 3, 1)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    wd = w.permute(0, 2, 3, 1).contiguous().to(DEV)
+    out = ops.conv_bn_act(xd, wd, bias.to(DEV), res.permute(0, 2, 3, 1).contiguous().to(DEV), k, k, stride, pad,
+                          ops.ACT_RELU)
+    assert relerr(out.cpu(), ref) < 2e-5
+
+
+@pytest.mark.parametrize("B,R,Cout", [(2, 64, 32), (3, 33, 16), (1, 224, 32)])
+def test_conv_stem_s2(B, R, Cout):
+    x = rnd(1, "x", (B, 3, R, R)); w = rnd(2, "w", (Cout, 3, 3, 3), 27 ** -0.5); b = rnd(3, "b", (Cout,), 0.1)
+    ref = F.relu(F.conv2d(x, w, b, stride=2, padding=1)).permute(0, 2, 3, 1)
+    out = ops.conv_stem_s2(x.to(DEV), w.permute(2, 3, 1, 0).contiguous().to(DEV), b.to(DEV))
+    assert relerr(out.cpu(), ref) < 1e-5
+
+
+@pytest.mark.parametrize("k", [2, 7])
+def test_avgpool(k):
+    x = rnd(1, "x", (3, 32, 14, 14))
+    ref = F.avg_pool2d(x, k).permute(0, 2, 3, 1)
+    out = ops.avgpool2d(x.permute(0, 2, 3, 1).contiguous().to(DEV), k)
+    assert relerr(out.cpu(), ref) < 1e-6
+
+
+def test_attnpool():
+    B, C, S, heads, Dout = 5, 256, 3, 4, 96
+    sd = {}
+    p = "a."
+    sd[p + "positional_embedding"] = rnd(1, "pos", (S * S + 1, C), C ** -0.5)
+    for nm, o in (("q_proj", C), ("k_proj", C), ("v_proj", C), ("c_proj", Dout)):
+        sd[p + nm + ".weight"] = rnd(2, nm, (o, C), C ** -0.5)
+        sd[p + nm + ".bias"] = rnd(3, nm + "b", (o,), 0.1)
+    x = rnd(4, "x", (B, C, S, S))
+    ref = CO.attention_pool(x, sd, p, heads)
+    d = {k: v.to(DEV) for k, v in sd.items()}
+    out = ops.attnpool(x.permute(0, 2, 3, 1).contiguous().to(DEV), d[p + "positional_embedding"],
+                       d[p + "q_proj.weight"], d[p + "q_proj.bias"],
+                       torch.cat([d[p + "k_proj.weight"], d[p + "v_proj.weight"]]).contiguous(),
+                       torch.cat([d[p + "k_proj.bias"], d[p + "v_proj.bias"]]).contiguous(),
+                       d[p + "c_proj.weight"], d[p + "c_proj.bias"], heads)
+    assert relerr(out.cpu(), ref) < 1e-5
+
+
+@pytest.mark.parametrize("rows,E", [(7, 64), (100, 768), (33, 1024), (5, 100)])
+def test_layernorm(rows, E):
+    x = rnd(1, "x", (rows, E), 2.0) + 0.5
+    g = synth.uniform(2, "g", (E,), 0.5, 1.5); b = rnd(3, "b", (E,), 0.1)
+    ref = F.layer_norm(x, (E,), g, b, 1e-5)
+    out = ops.layernorm(x.to(DEV), g.to(DEV), b.to(DEV))
+    assert relerr(out.cpu(), ref) < 1e-5
+
+
+def test_layernorm_strided_rows():
+    B, L, E = 6, 5, 128
+    x = rnd(1, "x", (B, L, E))
+    g = synth.uniform(2, "g", (E,), 0.5, 1.5); b = rnd(3, "b", (E,), 0.1)
+    out = ops.layernorm(x.to(DEV), g.to(DEV), b.to(DEV), rows=B, ldx=L * E)
+    assert relerr(out.cpu(), F.layer_norm(x[:, 0], (E,), g, b)) < 1e-5
+
+
+@pytest.mark.parametrize("B,L,heads,causal", [(3, 50, 2, False), (2, 77, 8, True), (2, 130, 1, False),
+                                              (1, 130, 2, True), (2, 5, 1, False), (1, 577, 1, False)])
+def test_mha_core(B, L, heads, causal):
+    E = heads * 64
+    qkv = rnd(1, "qkv", (B, L, 3 * E))
+    q, k, v = qkv.split(E, dim=-1)
+    sh = lambda t: t.reshape(B, L, heads, 64).transpose(1, 2)
+    s = (sh(q) * 0.125) @ sh(k).transpose(-1, -2)
+    if causal:
+        s = s + torch.full((L, L), float("-inf")).triu_(1)
+    ref = (torch.softmax(s, -1) @ sh(v)).transpose(1, 2).reshape(B * L, E)
+    out = ops.mha_core(qkv.to(DEV).view(B * L, 3 * E), B, L, E, heads, causal)
+    assert relerr(out.cpu(), ref) < 1e-5
+
+
+def test_mha_core_spiked_scores():
+    """forces large running-max jumps between key groups (online-softmax rescale path)."""
+    B, L, E = 1, 100, 64
+    qkv = rnd(1, "qkv", (B, L, 3 * E))
+    qkv[0, :, E:2 * E][37] *= 40.0
+    qkv[0, :, E:2 * E][90] *= -60.0
+    q, k, v = qkv.split(E, dim=-1)
+    ref = torch.softmax((q * 0.125) @ k.transpose(-1, -2), -1) @ v
+    out = ops.mha_core(qkv.to(DEV).view(L, 3 * E), B, L, E, 1, False)
+    assert relerr(out.cpu(), ref.reshape(L, E)) < 1e-5
+
+
+def test_embed_gather_and_eot():
+    n, L, W, V = 5, 77, 64, 300
+    table = rnd(1, "t", (V, W)); pos = rnd(2, "p", (L, W))
+    tok = torch.zeros(n, L, dtype=torch.int32)
+    lens = [3, 77, 10, 2, 40]
+    for i, ln in enumerate(lens):
+        tok[i, :ln - 1] = synth.integers(3 + i, "tk", (ln - 1,), V - 1).int()
+        tok[i, ln - 1] = V - 1
+    x, tk = ops.embed_gather(tok.to(DEV), table.to(DEV), pos.to(DEV))
+    ref = table[tok.long()] + pos
+    assert torch.equal(x.cpu(), ref)
+    e = ops.gather_eot(tk, x)
+    assert torch.equal(e.cpu(), ref[torch.arange(n), tok.argmax(-1)])
+
+
+def test_gather_eot_tie_takes_first():
+    tok = torch.tensor([[5, 9, 9, 1], [7, 7, 7, 7]], dtype=torch.int32)
+    x = rnd(1, "x", (2, 4, 8))
+    e = ops.gather_eot(tok.to(DEV), x.to(DEV))
+    assert torch.equal(e.cpu(), torch.stack([x[0, 1], x[1, 0]]))
+
+
+@pytest.mark.parametrize("R,P", [(64, 16), (28, 14), (224, 32)])
+def test_im2col_patch_and_tokens(R, P):
+    B, W = 2, 64
+    x = rnd(1, "x", (B, 3, R, R))
+    g = R // P
+    cols = ops.im2col_patch(x.to(DEV), P)
+    ref = F.unfold(x, P, stride=P).transpose(1, 2).reshape(B * g * g, 3 * P * P)
+    assert torch.equal(cols.cpu(), ref)
+    patches = rnd(2, "pt", (B * g * g, W)); cls = rnd(3, "c", (W,)); pos = rnd(4, "pos", (g * g + 1, W))
+    t = ops.vit_tokens(patches.to(DEV), cls.to(DEV), pos.to(DEV), B)
+    rt = torch.cat([cls.expand(B, 1, W), patches.view(B, g * g, W)], 1) + pos
+    assert torch.equal(t.cpu(), rt)
+
+
+@pytest.mark.parametrize("B,H", [(4, 128), (256, 128), (1000, 136)])
+def test_bn1d_stats_and_relu(B, H):
+    h = rnd(1, "h", (B, H), 2.0) + 0.3
+    bn = torch.nn.BatchNorm1d(H)
+    bn.weight.data = synth.uniform(2, "g", (H,), 0.5, 1.5); bn.bias.data = rnd(3, "b", (H,), 0.1)
+    bn.running_mean.data = rnd(4, "rm", (H,), 0.1); bn.running_var.data = synth.uniform(5, "rv", (H,), 0.5, 1.5)
+    rm, rv = bn.running_mean.clone().to(DEV), bn.running_var.clone().to(DEV)
+    nbt = torch.zeros((), dtype=torch.int64, device=DEV)
+    bn.train()
+    ref = F.relu(bn(h))
+    mean = torch.empty(H, device=DEV); invstd = torch.empty(H, device=DEV)
+    from dbmm_amd import _lib
+    L = _lib.lib()
+    _lib.check(L.dbmm_bn1d_stats(h.to(DEV).data_ptr(), B, H, 1e-5, 0.1, mean.data_ptr(), invstd.data_ptr(),
+                                 rm.data_ptr(), rv.data_ptr(), nbt.data_ptr(), _lib.stream()))
+    r = torch.empty(B, H, device=DEV)
+    hd = h.to(DEV)
+    _lib.check(L.dbmm_bn1d_relu(hd.data_ptr(), mean.data_ptr(), invstd.data_ptr(), bn.weight.data.to(DEV).data_ptr(),
+                                bn.bias.data.to(DEV).data_ptr(), r.data_ptr(), B, H, 0, 1e-5, _lib.stream()))
+    assert relerr(r.cpu(), ref.detach()) < 1e-5
+    assert relerr(rm.cpu(), bn.running_mean) < 1e-5 and relerr(rv.cpu(), bn.running_var) < 1e-5
+    assert int(nbt) == 1
+
+
+@pytest.mark.parametrize("C", [2, 4, 7])
+@pytest.mark.parametrize("blended", [False, True])
+def test_l2norm_sim_ce(C, blended):
+    B, D, T = 77, 256, 0.01
+    z = rnd(1, "z", (B, D)).requires_grad_(True)
+    zo = rnd(2, "zo", (B, D)) if blended else None
+    text = rnd(3, "t", (D, C))
+    y = synth.integers(4, "y", (B,), C)
+    f = z / z.norm(dim=-1, keepdim=True)
+    if blended:
+        f = 0.3 * (zo / zo.norm(dim=-1, keepdim=True)) + 0.7 * f
+    logits = f @ (text / text.norm(dim=0, keepdim=True)) / T
+    loss = F.cross_entropy(logits, y)
+    loss.backward()
+    tn = ops.text_colnorm(text.to(DEV))
+    assert relerr(tn.cpu(), (text / text.norm(dim=0, keepdim=True)).t()) < 1e-6
+    zd = z.detach().to(DEV)
+    lg, lrows, lmean, pred, inv = ops.l2norm_sim_ce_fwd(zd, tn, T, labels=y.to(DEV), z_old=zo.to(DEV) if blended else None,
+                                                        ebd_weight=0.3, want_pred=True)
+    assert (lg.cpu() - logits.detach()).abs().max() < 1e-3          # BASELINE.json: logits within 1e-3
+    assert abs(lmean.item() - loss.item()) < 1e-4 * max(1.0, abs(loss.item()))
+    assert relerr(lrows.cpu(), F.cross_entropy(logits.detach(), y, reduction="none")) < 1e-4
+    assert torch.equal(pred.cpu(), logits.detach().argmax(1))
+    dz = ops.l2norm_sim_ce_bwd(zd, inv, tn, T, logits=lg, labels=y.to(DEV), blended=blended, ebd_weight=0.3)
+    assert relerr(dz.cpu(), z.grad) < 2e-4
+    # external-criterion path: feed d(loss)/d(logits)
+    dl = (torch.softmax(logits.detach(), 1) - F.one_hot(y, C)) / B
+    dz2 = ops.l2norm_sim_ce_bwd(zd, inv, tn, T, dlogits=dl.float().to(DEV), blended=blended, ebd_weight=0.3)
+    assert relerr(dz2.cpu(), z.grad) < 2e-4
+
+
+def test_sgd_matches_torch():
+    shapes = [(128, 1024), (128,), (1024, 128), (1024,), (7,)]
+    ps = [torch.nn.Parameter(rnd(i, "p", s)) for i, s in enumerate(shapes)]
+    opt = torch.optim.SGD(ps, lr=0.1, momentum=0.9, weight_decay=5e-5)
+    dps = [p.detach().clone().to(DEV) for p in ps]
+    bufs = [torch.zeros_like(p) for p in dps]
+    for step in range(3):
+        gs = [rnd(10 * step + i, "g", s) for i, s in enumerate(shapes)]
+        for p, g in zip(ps, gs):
+            p.grad = g.clone()
+        opt.step()
+        ops.sgd_momentum(dps, [g.to(DEV) for g in gs], bufs, 0.1, 0.9, 5e-5, step == 0)
+    for p, d in zip(ps, dps):
+        assert relerr(d.cpu(), p.detach()) < 1e-6
+
+
+def test_group_count_bit_exact():
+    B, C, G = 1000, 2, 4
+    logits = rnd(1, "l", (B, C))
+    logits[5] = 0.25                                           # tie -> first index
+    y, c, g = synth.labels(2, B)
+    counts = torch.zeros(G, 2, dtype=torch.int64, device=DEV)
+    ops.group_count(logits.to(DEV), y.to(DEV), g.to(DEV), counts)
+    ops.group_count(logits.to(DEV), y.to(DEV), g.to(DEV), counts)      # accumulates
+    import adapter_oracle as AO
+    assert (counts.cpu().numpy() == 2 * AO.group_counts(logits, y, g, G)).all()
