@@ -94,7 +94,7 @@ def test_custom_clip_and_multiple_adapter(B, fused, golden, text_paths):
             from functools import partial
             res = adapter.get_results(meters, partial(adapter.get_y_p, n_places=2))
             assert np.array_equal(np.array([res[k] for k in sorted(res)]), g[tag + "/results"])
-            stage1 = clf
+        stage1 = clf        # like the fixture generator: stage 2 starts from the last stage-1 run
     for ni in (True, False):
         for use_group in (False, True):
             tag = f"multi_B{B}_{'ni' if ni else 'rn'}_{'group' if use_group else 'class'}"

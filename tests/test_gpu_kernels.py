@@ -217,12 +217,13 @@ def test_bn1d_stats_and_relu(B, H):
     mean = torch.empty(H, device=DEV); invstd = torch.empty(H, device=DEV)
     from dbmm_amd import _lib
     L = _lib.lib()
-    _lib.check(L.dbmm_bn1d_stats(h.to(DEV).data_ptr(), B, H, 1e-5, 0.1, mean.data_ptr(), invstd.data_ptr(),
+    hd = h.to(DEV)                      # keep alive: raw pointers are passed below
+    _lib.check(L.dbmm_bn1d_stats(hd.data_ptr(), B, H, 1e-5, 0.1, mean.data_ptr(), invstd.data_ptr(),
                                  rm.data_ptr(), rv.data_ptr(), nbt.data_ptr(), _lib.stream()))
     r = torch.empty(B, H, device=DEV)
-    hd = h.to(DEV)
-    _lib.check(L.dbmm_bn1d_relu(hd.data_ptr(), mean.data_ptr(), invstd.data_ptr(), bn.weight.data.to(DEV).data_ptr(),
-                                bn.bias.data.to(DEV).data_ptr(), r.data_ptr(), B, H, 0, 1e-5, _lib.stream()))
+    gam, bet = bn.weight.data.to(DEV), bn.bias.data.to(DEV)
+    _lib.check(L.dbmm_bn1d_relu(hd.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gam.data_ptr(),
+                                bet.data_ptr(), r.data_ptr(), B, H, 0, 1e-5, _lib.stream()))
     assert relerr(r.cpu(), ref.detach()) < 1e-5
     assert relerr(rm.cpu(), bn.running_mean) < 1e-5 and relerr(rv.cpu(), bn.running_var) < 1e-5
     assert int(nbt) == 1
