@@ -42,7 +42,8 @@ def build(force=False, verbose=False):
     for cmd, p in procs:
         out, _ = p.communicate()
         if p.returncode != 0:
-            raise RuntimeError("hipcc failed: %s\n%s" % (" ".join(cmd), out.decode()))
+            errs = [l for l in out.decode().splitlines() if "error" in l][:8]
+            raise RuntimeError("hipcc failed: %s\n%s" % (" ".join(cmd), "\n".join(errs) or out.decode()[-2000:]))
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs
     subprocess.run(cmd, check=True)
     return LIB_PATH

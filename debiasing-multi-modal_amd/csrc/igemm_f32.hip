@@ -19,6 +19,7 @@
 // element j of both halves (k pair {8g+j, 8g+4+j}).  Any fixed K order is a valid fp32 sum.
 //
 // Roofline: MFMA-bound. 32x32x2 = 4096 FLOP / 64 cycles / SIMD -> 157.3 TFLOP/s chip peak.
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -37,20 +38,35 @@ struct IgemmP {
     int tiles_n, n_tiles;
 };
 
-constexpr int BK = 32;
-
+// LDS rows hold BK floats; the 16-B chunk index is XOR-swizzled with row bits so that the 16
+// lanes of a ds_read_b128 group (16 x 16 B = all 64 banks) never collide:
+//   BK = 32 (128-B rows, 2 rows per bank sweep): chunk ^= (row >> 1) & 7
+//   BK = 16 ( 64-B rows, 4 rows per bank sweep): chunk ^= (row >> 2) & 3
+template <int BK>
+__device__ __forceinline__ int lds_swz(int row) {
+    return BK == 32 ? ((row >> 1) & 7) : ((row >> 2) & 3);
+}
+template <int BK>
 __device__ __forceinline__ int lds_off(int row, int kchunk) {  // float index of a 16-B chunk
-    return row * BK + ((kchunk ^ ((row >> 1) & 7)) << 2);
+    return row * BK + ((kchunk ^ lds_swz<BK>(row)) << 2);
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int AMODE, int WMODE>
-__global__ __launch_bounds__(256) void igemm_f32_kernel(const IgemmP p) {
+// MINB = resident workgroups per CU the register allocator must leave room for (hipcc sizes
+// its VGPR budget from a 64-KB LDS model otherwise and drops the 128x128 tile to 1 block/CU).
+template <int BM, int BN, int WAVES_M, int WAVES_N, int AMODE, int WMODE, int BK, int MINB>
+__global__ __launch_bounds__(256, MINB) void igemm_f32_kernel(const IgemmP p) {
     constexpr int TM = BM / WAVES_M / 32, TN = BN / WAVES_N / 32;
-    constexpr int ALD = BM / 32, WLD = BN / 32;  // float4 loads per thread per chunk
+    constexpr int CPR = BK / 4;                  // 16-B chunks per LDS row
+    constexpr int RPP = 256 / CPR;               // rows covered by one pass of the 256 threads
+    constexpr int ALD = (BM + RPP - 1) / RPP, WLD = (BN + RPP - 1) / RPP;  // float4 loads per thread per chunk
+    // (a tile narrower than one pass of the 256 threads leaves the surplus threads idle: the
+    //  `< BM` / `< BN` / `< BK` guards below are compile-time true otherwise)
     static_assert(WAVES_M * WAVES_N == 4, "4 waves");
-    __shared__ __attribute__((aligned(16))) float lds[2 * (BM + BN) * BK];
-    float* As = lds;                 // [2][BM][32]
-    float* Ws = lds + 2 * BM * BK;   // [2][BN][32]
+    constexpr int EPI_FLOATS = 4 * 32 * (TN * 32 + 4);
+    constexpr int LDS_FLOATS = 2 * (BM + BN) * BK > EPI_FLOATS ? 2 * (BM + BN) * BK : EPI_FLOATS;
+    __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
+    float* As = lds;                 // [2][BM][BK]
+    float* Ws = lds + 2 * BM * BK;   // [2][BN][BK]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tile = xcd_remap(blockIdx.x, p.n_tiles);
@@ -58,21 +74,21 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(const IgemmP p) {
     const int wm0 = (wave / WAVES_N) * (TM * 32), wn0 = (wave % WAVES_N) * (TN * 32);
 
     // ---- per-thread global-load bookkeeping -------------------------------------------
-    // row-major / conv: thread covers 16-B chunk (tid&7) of rows (tid>>3) + 32*i
-    const int lc = tid & 7, lr = tid >> 3;
+    // row-major / conv: thread covers 16-B chunk (tid % CPR) of rows tid / CPR + RPP*i
+    const int lc = tid % CPR, lr = tid / CPR;
     long long a_base[ALD];
     int a_hi0[ALD], a_wi0[ALD];
     if constexpr (AMODE == 0) {
 #pragma unroll
         for (int i = 0; i < ALD; ++i) {
-            const int m = m0 + lr + 32 * i;
-            a_base[i] = (m < p.M) ? (long long)m * p.lda : -1;
+            const int m = m0 + lr + RPP * i;
+            a_base[i] = (m < p.M && lr + RPP * i < BM) ? (long long)m * p.lda : -1;
         }
     } else if constexpr (AMODE == 1) {
 #pragma unroll
         for (int i = 0; i < ALD; ++i) {
-            const int m = m0 + lr + 32 * i;
-            if (m < p.M) {
+            const int m = m0 + lr + RPP * i;
+            if (m < p.M && lr + RPP * i < BM) {
                 const int hw = p.Ho * p.Wo;
                 const int n = m / hw, rem = m - n * hw;
                 const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
@@ -116,7 +132,7 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(const IgemmP p) {
                 const int kk = tid / AQ + (256 / AQ) * i;
                 const int k = k0 + kk, m = m0 + mq * 4;
                 a_reg[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if (k < p.K && m < p.M) a_reg[i] = *(const f32x4*)(p.a + (long long)k * p.lda + m);
+                if (kk < BK && k < p.K && m < p.M) a_reg[i] = *(const f32x4*)(p.a + (long long)k * p.lda + m);
             }
         }
     };
@@ -125,9 +141,9 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(const IgemmP p) {
             const int k = k0 + lc * 4;
 #pragma unroll
             for (int i = 0; i < WLD; ++i) {
-                const int n = n0 + lr + 32 * i;
+                const int n = n0 + lr + RPP * i;
                 w_reg[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if (n < p.N && k < p.K) w_reg[i] = *(const f32x4*)(p.w + (long long)n * p.ldw + k);
+                if (lr + RPP * i < BN && n < p.N && k < p.K) w_reg[i] = *(const f32x4*)(p.w + (long long)n * p.ldw + k);
             }
         } else {
             const int nq = tid % WQ;
@@ -136,7 +152,7 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(const IgemmP p) {
                 const int kk = tid / WQ + (256 / WQ) * i;
                 const int k = k0 + kk, n = n0 + nq * 4;
                 w_reg[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if (k < p.K && n < p.N) w_reg[i] = *(const f32x4*)(p.w + (long long)k * p.ldw + n);
+                if (kk < BK && k < p.K && n < p.N) w_reg[i] = *(const f32x4*)(p.w + (long long)k * p.ldw + n);
             }
         }
     };
@@ -145,26 +161,30 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(const IgemmP p) {
         float* Wb = Ws + buf * BN * BK;
         if constexpr (AMODE != 2) {
 #pragma unroll
-            for (int i = 0; i < ALD; ++i) *(f32x4*)(Ab + lds_off(lr + 32 * i, lc)) = a_reg[i];
+            for (int i = 0; i < ALD; ++i)
+                if (lr + RPP * i < BM) *(f32x4*)(Ab + lds_off<BK>(lr + RPP * i, lc)) = a_reg[i];
         } else {
             const int mq = tid % AQ;
 #pragma unroll
             for (int i = 0; i < ALD; ++i) {
                 const int kk = tid / AQ + (256 / AQ) * i;
+                if (kk < BK)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) Ab[lds_off(mq * 4 + j, kk >> 2) + (kk & 3)] = a_reg[i][j];
+                for (int j = 0; j < 4; ++j) Ab[lds_off<BK>(mq * 4 + j, kk >> 2) + (kk & 3)] = a_reg[i][j];
             }
         }
         if constexpr (WMODE == 0) {
 #pragma unroll
-            for (int i = 0; i < WLD; ++i) *(f32x4*)(Wb + lds_off(lr + 32 * i, lc)) = w_reg[i];
+            for (int i = 0; i < WLD; ++i)
+                if (lr + RPP * i < BN) *(f32x4*)(Wb + lds_off<BK>(lr + RPP * i, lc)) = w_reg[i];
         } else {
             const int nq = tid % WQ;
 #pragma unroll
             for (int i = 0; i < WLD; ++i) {
                 const int kk = tid / WQ + (256 / WQ) * i;
+                if (kk < BK)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) Wb[lds_off(nq * 4 + j, kk >> 2) + (kk & 3)] = w_reg[i][j];
+                for (int j = 0; j < 4; ++j) Wb[lds_off<BK>(nq * 4 + j, kk >> 2) + (kk & 3)] = w_reg[i][j];
             }
         }
     };
@@ -177,7 +197,7 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(const IgemmP p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int fr = lane & 31, fh = lane >> 5, fsw = (fr >> 1) & 7;
+    const int fr = lane & 31, fh = lane >> 5, fsw = lds_swz<BK>(fr);
     const int nk = (p.K + BK - 1) / BK;
 
     load_a(0); load_w(0);
@@ -190,7 +210,7 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(const IgemmP p) {
         const float* Ab = As + buf * BM * BK;
         const float* Wb = Ws + buf * BN * BK;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
+        for (int g = 0; g < BK / 8; ++g) {
             const int ch = ((2 * g + fh) ^ fsw) << 2;
             f32x4 af[TM], wf[TN];
 #pragma unroll
@@ -209,7 +229,61 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(const IgemmP p) {
         __syncthreads();
     }
 
-    // ---- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ---------
+    // ---- epilogue -----------------------------------------------------------------------
+    // C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+    // Fast path (N, ldc, ldr multiples of 4): each wave transposes 32 output rows at a time
+    // through its own slice of the (now idle) staging LDS so that every lane owns 4
+    // consecutive columns: residual loads and stores become 16 B per lane, a whole
+    // 128/256-B row segment per 8/16 lanes, and all residual loads of a half-tile are in
+    // flight together.  (The per-element path below it was latency-bound at ~1 TB/s.)
+    constexpr int WTN = TN * 32;              // wave tile width
+    constexpr int LROW = WTN + 4;             // padded LDS row (keeps 16-B alignment)
+    constexpr int LPR = WTN / 4;              // lanes per output row
+    constexpr int RPI = 64 / LPR;             // rows per wave instruction
+    constexpr int NIT = 32 / RPI;             // instructions per 32-row half tile
+    static_assert(4 * 32 * LROW <= LDS_FLOATS, "epilogue staging fits in the tile LDS");
+    const bool vec_ok = ((p.N & 3) == 0) && ((p.ldc & 3) == 0) && (!p.res || (p.ldr & 3) == 0);
+    if (vec_ok) {
+        float* Ls = lds + wave * (32 * LROW);
+        const int ec = (lane % LPR) * 4, er = lane / LPR;
+        const int n = n0 + wn0 + ec;
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias && n < p.N) bv = *(const f32x4*)(p.bias + n);
+        const float* __restrict__ resp = p.res;
+        float* __restrict__ cp = p.c;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            __syncthreads();                  // K loop (or previous half) done with this LDS
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    Ls[((r & 3) + 8 * (r >> 2) + 4 * fh) * LROW + j * 32 + fr] = acc[i][j][r];
+            __syncthreads();
+            const int mb = m0 + wm0 + i * 32 + er;
+            f32x4 rv[NIT];
+#pragma unroll
+            for (int t = 0; t < NIT; ++t) {
+                const int m = mb + t * RPI;
+                rv[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (resp && m < p.M && n < p.N) rv[t] = *(const f32x4*)(resp + (long long)m * p.ldr + n);
+            }
+#pragma unroll
+            for (int t = 0; t < NIT; ++t) {
+                const int m = mb + t * RPI;
+                f32x4 v = (*(const f32x4*)(Ls + (er + t * RPI) * LROW + ec) + bv) * p.alpha + rv[t];
+                if (p.act == DBMM_ACT_RELU) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
+                } else if (p.act == DBMM_ACT_QUICKGELU) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] = v[q] / (1.f + expf(-1.702f * v[q]));
+                }
+                if (m < p.M && n < p.N) *(f32x4*)(cp + (long long)m * p.ldc + n) = v;
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + wn0 + j * 32 + fr;
@@ -231,14 +305,20 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(const IgemmP p) {
     }
 }
 
-template <int BM, int BN, int WM, int WN, int AMODE, int WMODE>
+template <int BM, int BN, int WM, int WN, int AMODE, int WMODE, int BK, int MINB>
 int launch_cfg(IgemmP& p, hipStream_t s) {
     const int tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = (p.N + BN - 1) / BN;
     p.n_tiles = tiles_m * p.tiles_n;
-    hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN, AMODE, WMODE>), dim3(p.n_tiles), dim3(256), 0, s, p);
+    hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN, AMODE, WMODE, BK, MINB>), dim3(p.n_tiles), dim3(256), 0, s, p);
     DBMM_CHECK_LAUNCH();
     return DBMM_OK;
+}
+
+// developer knob: DBMM_IGEMM_BK=16|32 forces the K-chunk depth of the 128-wide tiles
+inline int forced_bk() {
+    static const int v = [] { const char* e = getenv("DBMM_IGEMM_BK"); return e ? atoi(e) : 0; }();
+    return v;
 }
 
 template <int AMODE, int WMODE>
@@ -246,10 +326,21 @@ int launch_modes(IgemmP& p, hipStream_t s) {
     // tile choice: widest N tile that N fills; drop to 64x64 when the 128-wide grid would
     // leave most of the 256 CUs idle (small-M projections).
     const long long t128 = (long long)((p.M + 127) / 128) * ((p.N + 127) / 128);
-    if (p.N <= 32) return launch_cfg<128, 32, 4, 1, AMODE, WMODE>(p, s);
-    if (p.N <= 64) return launch_cfg<128, 64, 2, 2, AMODE, WMODE>(p, s);
-    if (t128 < 192) return launch_cfg<64, 64, 2, 2, AMODE, WMODE>(p, s);
-    return launch_cfg<128, 128, 2, 2, AMODE, WMODE>(p, s);
+    const int bk = forced_bk() ? forced_bk() : 16;
+    if (bk == 32) {
+        if (p.N <= 32) return launch_cfg<128, 32, 4, 1, AMODE, WMODE, 32, 3>(p, s);
+        if (p.N <= 64) return launch_cfg<128, 64, 2, 2, AMODE, WMODE, 32, 3>(p, s);
+        if (t128 < 192) return launch_cfg<64, 64, 2, 2, AMODE, WMODE, 32, 4>(p, s);
+        return launch_cfg<128, 128, 2, 2, AMODE, WMODE, 32, 2>(p, s);
+    }
+    // default: 16-deep K chunks -> 18-35 KB of LDS per workgroup, 4-8 resident workgroups
+    // per CU (one wave of each on every SIMD) so a wave parked at a barrier, a global load or
+    // in its epilogue always leaves others feeding the matrix pipe.
+    // (the narrow-N tiles measured 2-5 % faster with 32-deep chunks at 3 workgroups per CU)
+    if (p.N <= 32) return launch_cfg<128, 32, 4, 1, AMODE, WMODE, 32, 3>(p, s);
+    if (p.N <= 64) return launch_cfg<128, 64, 2, 2, AMODE, WMODE, 32, 3>(p, s);
+    if (t128 < 192) return launch_cfg<64, 64, 2, 2, AMODE, WMODE, 16, 6>(p, s);
+    return launch_cfg<128, 128, 2, 2, AMODE, WMODE, 16, 4>(p, s);
 }
 
 }  // namespace
@@ -312,4 +403,14 @@ extern "C" int dbmm_conv3x3_bn_act(const float* x, const float* w, const float* 
                                    float* y, int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t Cout,
                                    int act, void* stream) {
     return dbmm_conv_bn_act(x, w, bias, residual, y, B, H, W, Cin, Cout, 3, 3, 1, 1, act, stream);
+}
+
+// developer aid (not part of include/dbmm.h): resident blocks per CU of the main tiles
+extern "C" int dbmm_debug_occupancy(int* out4) {
+    int n = 0;
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, igemm_f32_kernel<128, 128, 2, 2, 1, 0, 32, 2>, 256, 0); out4[0] = n;
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, igemm_f32_kernel<128, 128, 2, 2, 1, 0, 16, 4>, 256, 0); out4[1] = n;
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, igemm_f32_kernel<128, 64, 2, 2, 1, 0, 32, 3>, 256, 0); out4[2] = n;
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, igemm_f32_kernel<64, 64, 2, 2, 0, 0, 16, 6>, 256, 0); out4[3] = n;
+    return 0;
 }

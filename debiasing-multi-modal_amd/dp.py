@@ -1,0 +1,74 @@
+"""Data-parallel "embed + adapter step" (SURVEY.md section 8e).
+
+The image batch shards across ranks (encode_image is per-image independent: frozen weights,
+eval-mode BN).  The adapter step is NOT row-separable (BatchNorm1d batch statistics, the
+batch-mean CE and the SGD update are defined over the global batch in the single-process
+reference), so each rank all-gathers the per-rank embeddings [B_l, D] and labels over
+RCCL/xGMI and then runs the identical full-batch adapter step redundantly: parameters stay
+bit-identical on every rank by construction -- no gradient all-reduce, no SyncBN, and the
+N-GPU result equals the 1-GPU result.  Rank-major gather order = the original row order.
+"""
+import torch
+import torch.distributed as dist
+
+from . import adapter
+
+
+def _world(group=None):
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_world_size(group), dist.get_rank(group)
+    return 1, 0
+
+
+def shard_rows(n_rows, world, rank):
+    """[start, stop) of this rank's contiguous row block (equal blocks; n_rows % world == 0)."""
+    if n_rows % world:
+        raise ValueError(f"global batch {n_rows} is not divisible by world size {world}")
+    per = n_rows // world
+    return rank * per, (rank + 1) * per
+
+
+def all_gather_rows(t, group=None):
+    """concatenate equal-sized per-rank row blocks in rank order (one all-gather)."""
+    world, _ = _world(group)
+    if world == 1:
+        return t
+    t = t.contiguous()
+    out = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    dist.all_gather_into_tensor(out, t, group=group)
+    return out
+
+
+class EmbedAdapterStep:
+    """encode local images -> all-gather embeddings + (y, g) -> replicated adapter step.
+
+    encode_fn:   images[B_l,3,R,R] -> embeddings[B_l,D]   (model.encode_image)
+    classifier:  CustomCLIP / MultipleAdapter (must offer .loss(features, labels, use_group))
+    optimizer:   dbmm_amd.optim.SGD over the classifier's trainable parameters
+    """
+
+    def __init__(self, encode_fn, classifier, optimizer, n_groups=4, group=None):
+        self.encode_fn, self.classifier, self.optimizer = encode_fn, classifier, optimizer
+        self.n_groups, self.group = n_groups, group
+        self.counts = None
+
+    def gather(self, emb_local, y_local, g_local):
+        labels = torch.stack([y_local, g_local], dim=1)             # int64 [B_l, 2]: one message
+        emb = all_gather_rows(emb_local, self.group)
+        labels = all_gather_rows(labels, self.group)
+        return emb, labels[:, 0].contiguous(), labels[:, 1].contiguous()
+
+    def step(self, images_local, y_local, g_local, use_group=False):
+        emb_local = self.encode_fn(images_local)
+        emb, y, g = self.gather(emb_local, y_local, g_local)
+        labels = g if use_group else y
+        loss, logits, loss_rows = self.classifier.loss(emb.detach(), labels, use_group)
+        self.optimizer.zero_grad()
+        loss.backward()
+        self.optimizer.step()
+        # update_dict (final_main.py:473) without a host sync: counters stay on the device
+        if not use_group:
+            if self.counts is None:
+                self.counts = torch.zeros((self.n_groups, 2), dtype=torch.int64, device=logits.device)
+            adapter.group_counts(logits, y, g, self.n_groups, self.counts)
+        return loss, logits, emb

@@ -11,6 +11,59 @@ from ._lib import check, ptr, require_cuda, stream
 
 ACT_NONE, ACT_RELU, ACT_QUICKGELU = 0, 1, 2
 
+# ---- optional per-launch timing of the MFMA kernel family (bench.py roofline leg) ----------
+_prof = None
+
+
+def profile_begin():
+    """start collecting (kernel tag, flops, start event, end event) for every igemm launch."""
+    global _prof
+    _prof = []
+
+
+def profile_end():
+    """stop collecting; returns {tag: (launches, total_flops, total_ms)} (synchronises)."""
+    global _prof
+    rec, _prof = _prof or [], None
+    torch.cuda.synchronize()
+    out = {}
+    for tag, flops, e0, e1 in rec:
+        n, f, ms = out.get(tag, (0, 0.0, 0.0))
+        out[tag] = (n + 1, f + flops, ms + e0.elapsed_time(e1))
+    return out
+
+
+def _igemm_tag(M, N, amode, wmode):
+    """name of the template instantiation dbmm_gemm_bias_act / dbmm_conv_bn_act will pick
+    (mirrors launch_modes() in csrc/igemm_f32.hip)."""
+    t128 = ((M + 127) // 128) * ((N + 127) // 128)
+    if N <= 32:
+        tile, bk = "128,32,4,1", 32
+    elif N <= 64:
+        tile, bk = "128,64,2,2", 32
+    elif t128 < 192:
+        tile, bk = "64,64,2,2", 16
+    else:
+        tile, bk = "128,128,2,2", 16
+    return f"igemm_f32_kernel<{tile},{amode},{wmode},{bk}>"
+
+
+class _Timed:
+    def __init__(self, M, N, K, amode, wmode):
+        self.args = (M, N, K, amode, wmode)
+
+    def __enter__(self):
+        if _prof is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+
+    def __exit__(self, *exc):
+        if _prof is not None and exc[0] is None:
+            M, N, K, amode, wmode = self.args
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            _prof.append((_igemm_tag(M, N, amode, wmode), 2.0 * M * N * K, self.e0, e1))
+
 
 def _f32c(t):
     if t.dtype != torch.float32 or not t.is_contiguous():
@@ -37,9 +90,10 @@ def gemm(a, w, bias=None, residual=None, act=ACT_NONE, alpha=1.0, trans_a=False,
     if out is None:
         out = torch.empty((M, N), device=a.device, dtype=torch.float32)
     ldr = residual.shape[-1] if residual is not None else 0
-    check(_lib.lib().dbmm_gemm_bias_act(ptr(a), lda, int(trans_a), ptr(w), w.shape[-1], int(trans_w), ptr(bias),
-                                        ptr(residual), ldr, ptr(out), out.shape[-1], M, N, K, float(alpha), act,
-                                        stream()), "gemm_bias_act")
+    with _Timed(M, N, K, 2 if trans_a else 0, int(trans_w)):
+        check(_lib.lib().dbmm_gemm_bias_act(ptr(a), lda, int(trans_a), ptr(w), w.shape[-1], int(trans_w), ptr(bias),
+                                            ptr(residual), ldr, ptr(out), out.shape[-1], M, N, K, float(alpha), act,
+                                            stream()), "gemm_bias_act")
     return out
 
 
@@ -52,8 +106,10 @@ def conv_bn_act(x, w, bias, residual, kh, kw, stride, pad, act):
     Ho = (H + 2 * pad - kh) // stride + 1
     Wo = (W + 2 * pad - kw) // stride + 1
     y = torch.empty((B, Ho, Wo, Cout), device=x.device, dtype=torch.float32)
-    check(_lib.lib().dbmm_conv_bn_act(ptr(x), ptr(w), ptr(bias), ptr(residual), ptr(y), B, H, W, Cin, Cout, kh, kw,
-                                      stride, pad, act, stream()), "conv_bn_act")
+    plain = kh == 1 and kw == 1 and stride == 1 and pad == 0
+    with _Timed(B * Ho * Wo, Cout, kh * kw * Cin, 0 if plain else 1, 0):
+        check(_lib.lib().dbmm_conv_bn_act(ptr(x), ptr(w), ptr(bias), ptr(residual), ptr(y), B, H, W, Cin, Cout, kh, kw,
+                                          stride, pad, act, stream()), "conv_bn_act")
     return y
 
 
