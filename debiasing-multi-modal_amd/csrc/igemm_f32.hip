@@ -36,6 +36,7 @@ struct IgemmP {
     int act;
     float alpha;
     int tiles_n, n_tiles;
+    long long sa, sw, sbias, sres, sc;  // per-batch element strides (grid.y = batch index)
 };
 
 // LDS rows hold BK floats; the 16-B chunk index is XOR-swizzled with row bits so that the 16
@@ -54,7 +55,7 @@ __device__ __forceinline__ int lds_off(int row, int kchunk) {  // float index of
 // MINB = resident workgroups per CU the register allocator must leave room for (hipcc sizes
 // its VGPR budget from a 64-KB LDS model otherwise and drops the 128x128 tile to 1 block/CU).
 template <int BM, int BN, int WAVES_M, int WAVES_N, int AMODE, int WMODE, int BK, int MINB>
-__global__ __launch_bounds__(256, MINB) void igemm_f32_kernel(const IgemmP p) {
+__global__ __launch_bounds__(256, MINB) void igemm_f32_kernel(const IgemmP p_in) {
     constexpr int TM = BM / WAVES_M / 32, TN = BN / WAVES_N / 32;
     constexpr int CPR = BK / 4;                  // 16-B chunks per LDS row
     constexpr int RPP = 256 / CPR;               // rows covered by one pass of the 256 threads
@@ -68,6 +69,13 @@ __global__ __launch_bounds__(256, MINB) void igemm_f32_kernel(const IgemmP p) {
     float* As = lds;                 // [2][BM][BK]
     float* Ws = lds + 2 * BM * BK;   // [2][BN][BK]
 
+    IgemmP p = p_in;
+    if (blockIdx.y) {   // batched GEMM: independent problems along grid.y
+        const long long b = blockIdx.y;
+        p.a += b * p.sa; p.w += b * p.sw; p.c += b * p.sc;
+        if (p.bias) p.bias += b * p.sbias;
+        if (p.res) p.res += b * p.sres;
+    }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tile = xcd_remap(blockIdx.x, p.n_tiles);
     const int m0 = (tile / p.tiles_n) * BM, n0 = (tile % p.tiles_n) * BN;
@@ -306,11 +314,12 @@ __global__ __launch_bounds__(256, MINB) void igemm_f32_kernel(const IgemmP p) {
 }
 
 template <int BM, int BN, int WM, int WN, int AMODE, int WMODE, int BK, int MINB>
-int launch_cfg(IgemmP& p, hipStream_t s) {
+int launch_cfg(IgemmP& p, hipStream_t s, int nbatch) {
     const int tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = (p.N + BN - 1) / BN;
     p.n_tiles = tiles_m * p.tiles_n;
-    hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN, AMODE, WMODE, BK, MINB>), dim3(p.n_tiles), dim3(256), 0, s, p);
+    hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN, AMODE, WMODE, BK, MINB>), dim3(p.n_tiles, nbatch), dim3(256), 0,
+                       s, p);
     DBMM_CHECK_LAUNCH();
     return DBMM_OK;
 }
@@ -322,25 +331,25 @@ inline int forced_bk() {
 }
 
 template <int AMODE, int WMODE>
-int launch_modes(IgemmP& p, hipStream_t s) {
+int launch_modes(IgemmP& p, hipStream_t s, int nbatch = 1) {
     // tile choice: widest N tile that N fills; drop to 64x64 when the 128-wide grid would
     // leave most of the 256 CUs idle (small-M projections).
-    const long long t128 = (long long)((p.M + 127) / 128) * ((p.N + 127) / 128);
+    const long long t128 = (long long)((p.M + 127) / 128) * ((p.N + 127) / 128) * nbatch;
     const int bk = forced_bk() ? forced_bk() : 16;
     if (bk == 32) {
-        if (p.N <= 32) return launch_cfg<128, 32, 4, 1, AMODE, WMODE, 32, 3>(p, s);
-        if (p.N <= 64) return launch_cfg<128, 64, 2, 2, AMODE, WMODE, 32, 3>(p, s);
-        if (t128 < 192) return launch_cfg<64, 64, 2, 2, AMODE, WMODE, 32, 4>(p, s);
-        return launch_cfg<128, 128, 2, 2, AMODE, WMODE, 32, 2>(p, s);
+        if (p.N <= 32) return launch_cfg<128, 32, 4, 1, AMODE, WMODE, 32, 3>(p, s, nbatch);
+        if (p.N <= 64) return launch_cfg<128, 64, 2, 2, AMODE, WMODE, 32, 3>(p, s, nbatch);
+        if (t128 < 192) return launch_cfg<64, 64, 2, 2, AMODE, WMODE, 32, 4>(p, s, nbatch);
+        return launch_cfg<128, 128, 2, 2, AMODE, WMODE, 32, 2>(p, s, nbatch);
     }
     // default: 16-deep K chunks -> 18-35 KB of LDS per workgroup, 4-8 resident workgroups
     // per CU (one wave of each on every SIMD) so a wave parked at a barrier, a global load or
     // in its epilogue always leaves others feeding the matrix pipe.
     // (the narrow-N tiles measured 2-5 % faster with 32-deep chunks at 3 workgroups per CU)
-    if (p.N <= 32) return launch_cfg<128, 32, 4, 1, AMODE, WMODE, 32, 3>(p, s);
-    if (p.N <= 64) return launch_cfg<128, 64, 2, 2, AMODE, WMODE, 32, 3>(p, s);
-    if (t128 < 192) return launch_cfg<64, 64, 2, 2, AMODE, WMODE, 16, 6>(p, s);
-    return launch_cfg<128, 128, 2, 2, AMODE, WMODE, 16, 4>(p, s);
+    if (p.N <= 32) return launch_cfg<128, 32, 4, 1, AMODE, WMODE, 32, 3>(p, s, nbatch);
+    if (p.N <= 64) return launch_cfg<128, 64, 2, 2, AMODE, WMODE, 32, 3>(p, s, nbatch);
+    if (t128 < 192) return launch_cfg<64, 64, 2, 2, AMODE, WMODE, 16, 6>(p, s, nbatch);
+    return launch_cfg<128, 128, 2, 2, AMODE, WMODE, 16, 4>(p, s, nbatch);
 }
 
 }  // namespace
@@ -367,6 +376,31 @@ extern "C" int dbmm_gemm_bias_act(const float* a, int64_t lda, int trans_a, cons
     if (!trans_a && trans_w) return launch_modes<0, 1>(p, s);
     if (trans_a && !trans_w) return launch_modes<2, 0>(p, s);
     return launch_modes<2, 1>(p, s);
+}
+
+extern "C" int dbmm_gemm_batched(const float* a, int64_t lda, int64_t stride_a, int trans_a, const float* w,
+                                 int64_t ldw, int64_t stride_w, int trans_w, const float* bias, int64_t stride_bias,
+                                 float* c, int64_t ldc, int64_t stride_c, int64_t M, int64_t N, int64_t K,
+                                 int64_t batch, float alpha, int act, void* stream) {
+    if (!a || !w || !c) return DBMM_E_ARG;
+    if (M <= 0 || N <= 0 || K <= 0 || batch <= 0 || batch > 65535 || M > INT32_MAX || N > INT32_MAX || K > INT32_MAX)
+        return DBMM_E_SHAPE;
+    if (act < 0 || act > 2) return DBMM_E_ARG;
+    if ((lda & 3) || (ldw & 3) || (stride_a & 3) || (stride_w & 3)) return DBMM_E_ALIGN;
+    if (!dbmm_aligned16(a) || !dbmm_aligned16(w)) return DBMM_E_ALIGN;
+    if ((!trans_a && (K & 3)) || (trans_a && (M & 3)) || (!trans_w && (K & 3)) || (trans_w && (N & 3)))
+        return DBMM_E_SHAPE;
+    IgemmP p{};
+    p.a = a; p.w = w; p.bias = bias; p.res = nullptr; p.c = c;
+    p.lda = lda; p.ldw = ldw; p.ldr = 0; p.ldc = ldc;
+    p.sa = stride_a; p.sw = stride_w; p.sbias = stride_bias; p.sc = stride_c;
+    p.M = (int)M; p.N = (int)N; p.K = (int)K; p.act = act; p.alpha = alpha;
+    hipStream_t s = (hipStream_t)stream;
+    const int nb = (int)batch;
+    if (!trans_a && !trans_w) return launch_modes<0, 0>(p, s, nb);
+    if (!trans_a && trans_w) return launch_modes<0, 1>(p, s, nb);
+    if (trans_a && !trans_w) return launch_modes<2, 0>(p, s, nb);
+    return launch_modes<2, 1>(p, s, nb);
 }
 
 extern "C" int dbmm_conv_bn_act(const float* x, const float* w, const float* bias, const float* residual,

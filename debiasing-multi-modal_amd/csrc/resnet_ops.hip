@@ -84,15 +84,17 @@ __global__ __launch_bounds__(256) void avgpool_kernel(const float* __restrict__ 
 // ---------------------------------------------------------------------------------------
 // attention-pool tokens: t[b][0] = mean_j x[b][j] + pos[0]; t[b][1+j] = x[b][j] + pos[1+j]
 // ---------------------------------------------------------------------------------------
+// (token rows are padded with zero rows up to Lp = a multiple of 4 so that the token matrix can
+//  be used as a K-major GEMM operand)
 __global__ __launch_bounds__(256) void attnpool_tokens_kernel(const float* __restrict__ x,
                                                               const float* __restrict__ pos,
-                                                              float* __restrict__ t, int HW, int C4) {
+                                                              float* __restrict__ t, int HW, int C4, int Lp) {
     const int b = blockIdx.y;
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C4) return;
     const f32x4* xb = (const f32x4*)x + (long long)b * HW * C4 + c;
     const f32x4* pp = (const f32x4*)pos + c;
-    f32x4* tb = (f32x4*)t + (long long)b * (HW + 1) * C4 + c;
+    f32x4* tb = (f32x4*)t + (long long)b * Lp * C4 + c;
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
     for (int j = 0; j < HW; ++j) {
         const f32x4 v = xb[(long long)j * C4];
@@ -100,29 +102,23 @@ __global__ __launch_bounds__(256) void attnpool_tokens_kernel(const float* __res
         tb[(long long)(j + 1) * C4] = v + pp[(long long)(j + 1) * C4];
     }
     tb[0] = s * (1.f / (float)HW) + pp[0];
+    for (int j = HW + 1; j < Lp; ++j) tb[(long long)j * C4] = (f32x4){0.f, 0.f, 0.f, 0.f};
 }
 
-// ---------------------------------------------------------------------------------------
-// one-query attention: per (image, head) one wave; q already scaled by hd^-0.5.
-// kv[b*L + j][0..C) = k, [C..2C) = v.  Lane d of the wave owns head dim d (hd = 64).
-// ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void attnpool_core_kernel(const float* __restrict__ q,
-                                                           const float* __restrict__ kv,
-                                                           float* __restrict__ out, int L, int C) {
-    const int h = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
-    const float qd = q[(long long)b * C + h * 64 + lane];
-    const float* kb = kv + (long long)b * L * 2 * C + h * 64 + lane;
-    float m = -INFINITY, l = 0.f, o = 0.f;
-    for (int j = 0; j < L; ++j) {
-        const float s = wave_sum(qd * kb[(long long)j * 2 * C]);
-        const float vj = kb[(long long)j * 2 * C + C];
-        const float mn = fmaxf(m, s);
-        const float sc = expf(m - mn), pj = expf(s - mn);
-        l = l * sc + pj;
-        o = o * sc + pj * vj;
-        m = mn;
-    }
-    out[(long long)b * C + h * 64 + lane] = o / l;
+// in-place softmax over the first L entries of rows of length Lp (padding entries -> 0);
+// one wave per row
+__global__ __launch_bounds__(256) void softmax_rows_kernel(float* __restrict__ s, int rows, int L, int Lp) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    float* r = s + (long long)row * Lp;
+    float m = -INFINITY;
+    for (int j = lane; j < L; j += 64) m = fmaxf(m, r[j]);
+    m = wave_max(m);
+    float sum = 0.f;
+    for (int j = lane; j < L; j += 64) sum += expf(r[j] - m);
+    sum = wave_sum(sum);
+    const float inv = 1.f / sum;
+    for (int j = lane; j < Lp; j += 64) r[j] = (j < L) ? expf(r[j] - m) * inv : 0.f;
 }
 
 }  // namespace
@@ -158,36 +154,60 @@ extern "C" int dbmm_avgpool2d(const float* x, float* y, int64_t B, int64_t H, in
 }
 
 extern "C" size_t dbmm_workspace_bytes_attnpool(int64_t B, int64_t HW, int64_t C) {
-    // tokens [B][HW+1][C] + kv [B][HW+1][2C] + q [B][C] + o [B][C]
-    return (size_t)(B * (HW + 1) * C * 3 + 2 * B * C) * sizeof(float);
+    // tokens [B][Lp][C] + q [B][C] + U/Sx [B][heads][C] + scores [B][heads][Lp] + o [B][C]
+    const int64_t Lp = (HW + 1 + 3) / 4 * 4, heads = C / 64;
+    return (size_t)(B * Lp * C + 2 * B * C + B * heads * C + B * heads * Lp) * sizeof(float);
 }
 
+// AttentionPool2d with the single query exploited algebraically (clip/model.py:68-91 computes
+// k and v projections of all HW+1 tokens although only token 0 queries):
+//   score_h[j] = q_h . (Wk_h t_j + bk_h) = (Wk_h^T q_h) . t_j + const   -> softmax drops the const
+//   out_h      = sum_j p_h[j] (Wv_h t_j + bv_h) = Wv_h (sum_j p_h[j] t_j) + bv_h   (sum_j p = 1)
+// i.e. 2*(HW+1)*C*C MACs per image become ~4*C*C.  All products are (batched) MFMA GEMMs.
 extern "C" int dbmm_attnpool(const float* x, const float* pos, const float* wq, const float* bq,
                              const float* wkv, const float* bkv, const float* wc, const float* bc, float* out,
                              int64_t B, int64_t HW, int64_t C, int64_t heads, int64_t Dout, void* workspace,
                              size_t workspace_bytes, void* stream) {
-    if (!x || !pos || !wq || !wkv || !wc || !out || !workspace) return DBMM_E_ARG;
-    if (B <= 0 || HW <= 0 || C <= 0 || heads <= 0 || C != heads * 64 || (C & 3) || Dout <= 0) return DBMM_E_SHAPE;
+    if (!x || !pos || !wq || !wkv || !bkv || !wc || !out || !workspace) return DBMM_E_ARG;
+    if (B <= 0 || HW <= 0 || C <= 0 || heads <= 0 || C != heads * 64 || (C & 3) || Dout <= 0 || B > 65535)
+        return DBMM_E_SHAPE;
     if (workspace_bytes < dbmm_workspace_bytes_attnpool(B, HW, C)) return DBMM_E_WORKSPACE;
     if (!dbmm_aligned16(x) || !dbmm_aligned16(pos) || !dbmm_aligned16(workspace)) return DBMM_E_ALIGN;
-    const int64_t L = HW + 1;
-    float* tok = (float*)workspace;
-    float* kv = tok + B * L * C;
-    float* q = kv + B * L * 2 * C;
-    float* o = q + B * C;
+    const int64_t L = HW + 1, Lp = (L + 3) / 4 * 4;
+    float* tok = (float*)workspace;          // [B][Lp][C]
+    float* q = tok + B * Lp * C;             // [B][C]
+    float* U = q + B * C;                    // [B][heads][C]   (re-used for Sx)
+    float* S = U + B * heads * C;            // [B][heads][Lp]
+    float* o = S + B * heads * Lp;           // [B][C]
     hipStream_t s = (hipStream_t)stream;
     const int C4 = (int)(C / 4);
     hipLaunchKernelGGL(attnpool_tokens_kernel, dim3((C4 + 255) / 256, (unsigned)B), dim3(256), 0, s, x, pos, tok,
-                       (int)HW, C4);
+                       (int)HW, C4, (int)Lp);
     DBMM_CHECK_LAUNCH();
     int rc;
-    // k and v projections of every token in one GEMM: [B*L, C] x [2C, C]^T
-    rc = dbmm_gemm_bias_act(tok, C, 0, wkv, C, 0, bkv, nullptr, 0, kv, 2 * C, B * L, 2 * C, C, 1.f, DBMM_ACT_NONE, stream);
+    // q = (t_0 Wq^T + bq) * head_dim^-0.5          (token 0 of every image: row stride Lp*C)
+    rc = dbmm_gemm_bias_act(tok, Lp * C, 0, wq, C, 0, bq, nullptr, 0, q, C, B, C, C, 0.125f, DBMM_ACT_NONE, stream);
     if (rc) return rc;
-    // q projection of token 0 only (row stride L*C), scaled by head_dim^-0.5 after the bias
-    rc = dbmm_gemm_bias_act(tok, L * C, 0, wq, C, 0, bq, nullptr, 0, q, C, B, C, C, 0.125f, DBMM_ACT_NONE, stream);
+    // U[b][h][:] = Wk_h^T q_h : per head, A = q[:, 64h:64h+64], W = Wk rows 64h.. as [K=64][N=C]
+    rc = dbmm_gemm_batched(q, C, 64, 0, wkv, C, 64 * C, 1, nullptr, 0, U, heads * C, C, B, C, 64, heads, 1.f,
+                           DBMM_ACT_NONE, stream);
     if (rc) return rc;
-    hipLaunchKernelGGL(attnpool_core_kernel, dim3((unsigned)heads, (unsigned)B), dim3(64), 0, s, q, kv, o, (int)L, (int)C);
+    // S[b][h][j] = U[b][h] . t[b][j] : per image, A = U[b] [heads][C], W = t[b] [Lp][C]
+    rc = dbmm_gemm_batched(U, C, heads * C, 0, tok, C, Lp * C, 0, nullptr, 0, S, Lp, heads * Lp, heads, Lp, C, B, 1.f,
+                           DBMM_ACT_NONE, stream);
+    if (rc) return rc;
+    const int64_t rows = B * heads;
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, S, (int)rows, (int)L,
+                       (int)Lp);
     DBMM_CHECK_LAUNCH();
+    // Sx[b][h][:] = sum_j p[b][h][j] t[b][j][:] : per image, A = P[b] [heads][Lp], W = t[b] K-major [Lp][C]
+    float* Sx = U;
+    rc = dbmm_gemm_batched(S, Lp, heads * Lp, 0, tok, C, Lp * C, 1, nullptr, 0, Sx, C, heads * C, heads, C, Lp, B, 1.f,
+                           DBMM_ACT_NONE, stream);
+    if (rc) return rc;
+    // o[:, 64h:64h+64] = Sx[:, h, :] Wv_h^T + bv_h : per head
+    rc = dbmm_gemm_batched(Sx, heads * C, C, 0, wkv + C * C, C, 64 * C, 0, bkv + C, 64, o, C, 64, B, 64, C, heads, 1.f,
+                           DBMM_ACT_NONE, stream);
+    if (rc) return rc;
     return dbmm_gemm_bias_act(o, C, 0, wc, C, 0, bc, nullptr, 0, out, Dout, B, Dout, C, 1.f, DBMM_ACT_NONE, stream);
 }

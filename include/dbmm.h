@@ -72,6 +72,14 @@ int dbmm_gemm_bias_act(const float* a, int64_t lda, int trans_a, const float* w,
                        float* c, int64_t ldc, int64_t M, int64_t N, int64_t K, float alpha,
                        int act, void* stream);
 
+/* `batch` independent GEMMs of identical shape in one launch (grid.y): problem b uses
+ * a + b*stride_a, w + b*stride_w, bias + b*stride_bias, c + b*stride_c (element strides,
+ * multiples of 4).  Used for the per-head products of the collapsed attention pool. */
+int dbmm_gemm_batched(const float* a, int64_t lda, int64_t stride_a, int trans_a, const float* w,
+                      int64_t ldw, int64_t stride_w, int trans_w, const float* bias,
+                      int64_t stride_bias, float* c, int64_t ldc, int64_t stride_c, int64_t M,
+                      int64_t N, int64_t K, int64_t batch, float alpha, int act, void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * ModifiedResNet pieces (clip/model.py:94-154)
  * ------------------------------------------------------------------------------------ */
