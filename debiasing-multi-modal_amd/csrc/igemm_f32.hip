@@ -18,6 +18,17 @@
 // lane half h = lane>>5 reads k = 8g+4h .. 8g+4h+3 as one 16-B LDS read and MFMA step j uses
 // element j of both halves (k pair {8g+j, 8g+4+j}).  Any fixed K order is a valid fp32 sum.
 //
+// Operand fetch (FAST = 1, the production path): `buffer_load_dwordx4` through a buffer
+// descriptor.  Out-of-tile rows, out-of-image halo taps and rows past M use an out-of-range
+// offset, for which the hardware returns zeros -- no branches, no selects.  Row-major
+// operands keep a per-thread row offset in a VGPR for the whole K loop and advance along K
+// through the scalar offset operand (zero VALU instructions per load); the conv gather adds
+// one wave-uniform tap offset per load and tests one bit of a per-row tap-validity mask.
+// (An ablation with the loads removed ran at 149 TFLOP/s against 119 for the first,
+// branchy flat-load loader: address arithmetic + exec-mask branches, not latency, were the
+// loss.)  FAST = 0 is the general fallback (K tails, K-major operands, Cin % BK != 0,
+// operands >= 2 GiB).
+//
 // Roofline: MFMA-bound. 32x32x2 = 4096 FLOP / 64 cycles / SIMD -> 157.3 TFLOP/s chip peak.
 #include <stdlib.h>
 #include "common.h"
@@ -37,7 +48,15 @@ struct IgemmP {
     float alpha;
     int tiles_n, n_tiles;
     long long sa, sw, sbias, sres, sc;  // per-batch element strides (grid.y = batch index)
+    unsigned a_bytes, w_bytes;          // FAST loader: buffer extents (< 2 GiB)
 };
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned OOR = 0x80000000u;   // >= any accepted extent, and OOR + (K offset) cannot wrap
+
+__device__ __forceinline__ f32x4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
 
 // LDS rows hold BK floats; the 16-B chunk index is XOR-swizzled with row bits so that the 16
 // lanes of a ds_read_b128 group (16 x 16 B = all 64 banks) never collide:
@@ -54,7 +73,7 @@ __device__ __forceinline__ int lds_off(int row, int kchunk) {  // float index of
 
 // MINB = resident workgroups per CU the register allocator must leave room for (hipcc sizes
 // its VGPR budget from a 64-KB LDS model otherwise and drops the 128x128 tile to 1 block/CU).
-template <int BM, int BN, int WAVES_M, int WAVES_N, int AMODE, int WMODE, int BK, int MINB>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int AMODE, int WMODE, int BK, int MINB, int FAST>
 __global__ __launch_bounds__(256, MINB) void igemm_f32_kernel(const IgemmP p_in) {
     constexpr int TM = BM / WAVES_M / 32, TN = BN / WAVES_N / 32;
     constexpr int CPR = BK / 4;                  // 16-B chunks per LDS row
@@ -111,10 +130,63 @@ __global__ __launch_bounds__(256, MINB) void igemm_f32_kernel(const IgemmP p_in)
     // K-major operands: thread covers m-quad (tid % (BX/4)) of k rows tid/(BX/4) + step*i
     constexpr int AQ = BM / 4, WQ = BN / 4;
 
+    // ---- FAST loader state ---------------------------------------------------------------------
+    unsigned fa_off[ALD], fa_mask[ALD], fw_off[WLD];
+    __amdgpu_buffer_rsrc_t rsA, rsW;
+    int f_ci0 = 0, f_kh = 0, f_kw = 0, f_tap = 0;     // conv: wave-uniform position along K
+    if constexpr (FAST) {
+        static_assert(AMODE != 2 && WMODE == 0, "FAST loader: K-contiguous operands only");
+        rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.a, 0, (int)p.a_bytes, 0x00020000);
+        rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)p.w_bytes, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < WLD; ++i) {
+            const int n = n0 + lr + RPP * i;
+            fw_off[i] = (lr + RPP * i < BN && n < p.N) ? (unsigned)n * (unsigned)p.ldw * 4u + lc * 16u : OOR;
+        }
+#pragma unroll
+        for (int i = 0; i < ALD; ++i) {
+            const int m = m0 + lr + RPP * i;
+            const bool rv = (lr + RPP * i < BM) && (m < p.M);
+            if constexpr (AMODE == 0) {
+                fa_off[i] = rv ? (unsigned)m * (unsigned)p.lda * 4u + lc * 16u : OOR;
+                fa_mask[i] = 0;
+            } else {
+                const int hw = p.Ho * p.Wo;
+                const int n = m / hw, rem = m - n * hw;
+                const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+                const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
+                // modular 32-bit arithmetic: the halo start may lie "before" the tensor, the tap
+                // offset added per load brings every valid tap back into range
+                fa_off[i] = ((unsigned)(n * p.H + hi0) * (unsigned)p.W + (unsigned)wi0) * (unsigned)p.Cin * 4u + lc * 16u;
+                unsigned msk = 0;
+                for (int kh = 0; kh < p.KH; ++kh)
+                    for (int kw = 0; kw < p.KW; ++kw)
+                        if (hi0 + kh >= 0 && hi0 + kh < p.H && wi0 + kw >= 0 && wi0 + kw < p.W)
+                            msk |= 1u << (kh * p.KW + kw);
+                fa_mask[i] = rv ? msk : 0u;
+            }
+        }
+    }
+
     f32x4 a_reg[ALD], w_reg[WLD];
 
     auto load_a = [&](int k0) {
-        if constexpr (AMODE == 0) {
+        if constexpr (FAST && AMODE == 0) {
+#pragma unroll
+            for (int i = 0; i < ALD; ++i) a_reg[i] = buf_load16(rsA, fa_off[i], (unsigned)k0 * 4u);
+        } else if constexpr (FAST && AMODE == 1) {
+            // chunk k0 lies inside tap (f_kh, f_kw) at channel f_ci0 (Cin % BK == 0)
+            const unsigned delta = ((unsigned)(f_kh * p.W + f_kw) * (unsigned)p.Cin + (unsigned)f_ci0) * 4u;
+            const unsigned bit = 1u << f_tap;
+#pragma unroll
+            for (int i = 0; i < ALD; ++i)
+                a_reg[i] = buf_load16(rsA, (fa_mask[i] & bit) ? fa_off[i] + delta : OOR, 0u);
+            f_ci0 += BK;
+            if (f_ci0 == p.Cin) {
+                f_ci0 = 0; ++f_tap;
+                if (++f_kw == p.KW) { f_kw = 0; ++f_kh; }
+            }
+        } else if constexpr (AMODE == 0) {
             const int k = k0 + lc * 4;
 #pragma unroll
             for (int i = 0; i < ALD; ++i) {
@@ -145,7 +217,10 @@ __global__ __launch_bounds__(256, MINB) void igemm_f32_kernel(const IgemmP p_in)
         }
     };
     auto load_w = [&](int k0) {
-        if constexpr (WMODE == 0) {
+        if constexpr (FAST) {
+#pragma unroll
+            for (int i = 0; i < WLD; ++i) w_reg[i] = buf_load16(rsW, fw_off[i], (unsigned)k0 * 4u);
+        } else if constexpr (WMODE == 0) {
             const int k = k0 + lc * 4;
 #pragma unroll
             for (int i = 0; i < WLD; ++i) {
@@ -313,13 +388,31 @@ __global__ __launch_bounds__(256, MINB) void igemm_f32_kernel(const IgemmP p_in)
     }
 }
 
+// FAST loader eligibility (see the header comment); `DBMM_IGEMM_FAST=0` forces the fallback.
+template <int AMODE, int WMODE, int BK>
+bool fast_ok(const IgemmP& p, int nbatch) {
+    static const int allow = [] { const char* e = getenv("DBMM_IGEMM_FAST"); return e ? atoi(e) : 1; }();
+    if (!allow || AMODE == 2 || WMODE != 0 || (p.K % BK) != 0) return false;
+    if (AMODE == 1 && ((p.Cin % BK) != 0 || p.KH * p.KW > 32)) return false;
+    (void)nbatch;
+    return p.a_bytes != 0 && p.w_bytes != 0;
+}
+
 template <int BM, int BN, int WM, int WN, int AMODE, int WMODE, int BK, int MINB>
 int launch_cfg(IgemmP& p, hipStream_t s, int nbatch) {
     const int tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = (p.N + BN - 1) / BN;
     p.n_tiles = tiles_m * p.tiles_n;
-    hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN, AMODE, WMODE, BK, MINB>), dim3(p.n_tiles, nbatch), dim3(256), 0,
-                       s, p);
+    if constexpr (AMODE != 2 && WMODE == 0) {
+        if (fast_ok<AMODE, WMODE, BK>(p, nbatch)) {
+            hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN, AMODE, WMODE, BK, MINB, 1>), dim3(p.n_tiles, nbatch),
+                               dim3(256), 0, s, p);
+            DBMM_CHECK_LAUNCH();
+            return DBMM_OK;
+        }
+    }
+    hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN, AMODE, WMODE, BK, MINB, 0>), dim3(p.n_tiles, nbatch), dim3(256),
+                       0, s, p);
     DBMM_CHECK_LAUNCH();
     return DBMM_OK;
 }
@@ -345,11 +438,23 @@ int launch_modes(IgemmP& p, hipStream_t s, int nbatch = 1) {
     // default: 16-deep K chunks -> 18-35 KB of LDS per workgroup, 4-8 resident workgroups
     // per CU (one wave of each on every SIMD) so a wave parked at a barrier, a global load or
     // in its epilogue always leaves others feeding the matrix pipe.
+    {
+        static const int ft = [] { const char* e = getenv("DBMM_IGEMM_TILE"); return e ? atoi(e) : 0; }();
+        if (ft == 64 && p.N > 64) return launch_cfg<64, 64, 2, 2, AMODE, WMODE, 16, 6>(p, s, nbatch);
+        if (ft == 12864 && p.N > 64) return launch_cfg<128, 64, 2, 2, AMODE, WMODE, 16, 5>(p, s, nbatch);
+    }
     // (the narrow-N tiles measured 2-5 % faster with 32-deep chunks at 3 workgroups per CU)
     if (p.N <= 32) return launch_cfg<128, 32, 4, 1, AMODE, WMODE, 32, 3>(p, s, nbatch);
     if (p.N <= 64) return launch_cfg<128, 64, 2, 2, AMODE, WMODE, 32, 3>(p, s, nbatch);
     if (t128 < 192) return launch_cfg<64, 64, 2, 2, AMODE, WMODE, 16, 6>(p, s, nbatch);
     return launch_cfg<128, 128, 2, 2, AMODE, WMODE, 16, 4>(p, s, nbatch);
+}
+
+// buffer extents for the FAST loader; 0 (= not eligible) when an operand reaches 2 GiB
+inline void set_extents(IgemmP& p, long long a_bytes, long long w_bytes) {
+    const long long lim = 0x7FFFFFF0LL;
+    p.a_bytes = (a_bytes > 0 && a_bytes < lim) ? (unsigned)a_bytes : 0u;
+    p.w_bytes = (w_bytes > 0 && w_bytes < lim) ? (unsigned)w_bytes : 0u;
 }
 
 }  // namespace
@@ -371,6 +476,7 @@ extern "C" int dbmm_gemm_bias_act(const float* a, int64_t lda, int trans_a, cons
     p.a = a; p.w = w; p.bias = bias; p.res = residual; p.c = c;
     p.lda = lda; p.ldw = ldw; p.ldr = ldr; p.ldc = ldc;
     p.M = (int)M; p.N = (int)N; p.K = (int)K; p.act = act; p.alpha = alpha;
+    set_extents(p, trans_a ? 0 : ((M - 1) * lda + K) * 4, trans_w ? 0 : ((N - 1) * ldw + K) * 4);
     hipStream_t s = (hipStream_t)stream;
     if (!trans_a && !trans_w) return launch_modes<0, 0>(p, s);
     if (!trans_a && trans_w) return launch_modes<0, 1>(p, s);
@@ -395,6 +501,7 @@ extern "C" int dbmm_gemm_batched(const float* a, int64_t lda, int64_t stride_a, 
     p.lda = lda; p.ldw = ldw; p.ldr = 0; p.ldc = ldc;
     p.sa = stride_a; p.sw = stride_w; p.sbias = stride_bias; p.sc = stride_c;
     p.M = (int)M; p.N = (int)N; p.K = (int)K; p.act = act; p.alpha = alpha;
+    set_extents(p, trans_a ? 0 : ((M - 1) * lda + K) * 4, trans_w ? 0 : ((N - 1) * ldw + K) * 4);
     hipStream_t s = (hipStream_t)stream;
     const int nb = (int)batch;
     if (!trans_a && !trans_w) return launch_modes<0, 0>(p, s, nb);
@@ -422,6 +529,7 @@ extern "C" int dbmm_conv_bn_act(const float* x, const float* w, const float* bia
     p.M = (int)M; p.N = (int)Cout; p.K = (int)K; p.act = act; p.alpha = 1.f;
     p.H = (int)H; p.W = (int)W; p.Cin = (int)Cin; p.Ho = (int)Ho; p.Wo = (int)Wo;
     p.KH = (int)KH; p.KW = (int)KW; p.stride = (int)stride; p.pad = (int)pad;
+    set_extents(p, B * H * W * Cin * 4, Cout * K * 4);
     hipStream_t s = (hipStream_t)stream;
     if (KH == 1 && KW == 1 && stride == 1 && pad == 0) return launch_modes<0, 0>(p, s);  // plain GEMM
     return launch_modes<1, 0>(p, s);
@@ -442,9 +550,9 @@ extern "C" int dbmm_conv3x3_bn_act(const float* x, const float* w, const float* 
 // developer aid (not part of include/dbmm.h): resident blocks per CU of the main tiles
 extern "C" int dbmm_debug_occupancy(int* out4) {
     int n = 0;
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, igemm_f32_kernel<128, 128, 2, 2, 1, 0, 32, 2>, 256, 0); out4[0] = n;
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, igemm_f32_kernel<128, 128, 2, 2, 1, 0, 16, 4>, 256, 0); out4[1] = n;
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, igemm_f32_kernel<128, 64, 2, 2, 1, 0, 32, 3>, 256, 0); out4[2] = n;
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, igemm_f32_kernel<64, 64, 2, 2, 0, 0, 16, 6>, 256, 0); out4[3] = n;
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, igemm_f32_kernel<128, 128, 2, 2, 1, 0, 32, 2, 1>, 256, 0); out4[0] = n;
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, igemm_f32_kernel<128, 128, 2, 2, 1, 0, 16, 4, 1>, 256, 0); out4[1] = n;
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, igemm_f32_kernel<128, 64, 2, 2, 1, 0, 32, 3, 1>, 256, 0); out4[2] = n;
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, igemm_f32_kernel<64, 64, 2, 2, 0, 0, 16, 6, 1>, 256, 0); out4[3] = n;
     return 0;
 }
