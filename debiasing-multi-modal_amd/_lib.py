@@ -59,6 +59,9 @@ _SIGS = {
     "dbmm_conv1x1_bn_act": [_P, _P, _P, _P, _P, _L, _L, _L, _L, _L, _I, _P],
     "dbmm_conv3x3_bn_act": [_P, _P, _P, _P, _P, _L, _L, _L, _L, _L, _I, _P],
     "dbmm_gemm_bias_act": [_P, _L, _I, _P, _L, _I, _P, _P, _L, _P, _L, _L, _L, _L, _F, _I, _P],
+    "dbmm_workspace_bytes_igemm": [],
+    "dbmm_conv_bn_act_ws": [_P, _P, _P, _P, _P, _L, _L, _L, _L, _L, _L, _L, _L, _L, _I, _P, _Z, _P],
+    "dbmm_gemm_bias_act_ws": [_P, _L, _I, _P, _L, _I, _P, _P, _L, _P, _L, _L, _L, _L, _F, _I, _P, _Z, _P],
     "dbmm_gemm_batched": [_P, _L, _L, _I, _P, _L, _L, _I, _P, _L, _P, _L, _L, _L, _L, _L, _L, _F, _I, _P],
     "dbmm_conv_stem_s2": [_P, _P, _P, _P, _L, _L, _L, _L, _P],
     "dbmm_avgpool2d": [_P, _P, _L, _L, _L, _L, _L, _P],
@@ -85,6 +88,7 @@ _SIGS = {
 _RESTYPES = {
     "dbmm_error_string": ctypes.c_char_p,
     "dbmm_workspace_bytes_attnpool": c_size_t,
+    "dbmm_workspace_bytes_igemm": c_size_t,
     "dbmm_workspace_bytes_adapter_bwd": c_size_t,
 }
 

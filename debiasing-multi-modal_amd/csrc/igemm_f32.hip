@@ -8,11 +8,11 @@
 //   AMODE 2  A K-major [K][lda]                (weight gradients: reduction over the batch)
 //   WMODE 0  W [N][ldw] (nn.Linear / packed conv weight)      WMODE 1  W [K][ldw]
 //
-// Tiling: 256 threads = 4 wave64; block tile BM x BN x 32; each wave owns TM x TN MFMA tiles
+// Tiling: 256 threads = 4 wave64; block tile BM x BN x BK; each wave owns TM x TN MFMA tiles
 // of 32x32.  Global -> registers -> LDS (double buffered, one barrier per K chunk, next
-// chunk's global loads issued before the current chunk's MFMAs).  LDS rows hold 32 floats
-// (128 B) with the 16-B chunk index XOR-swizzled by (row>>1)&7, which makes the ds_read_b128
-// operand fetches bank-conflict free (16 lanes x 16 B cover all 64 banks).
+// chunk's global loads issued before the current chunk's MFMAs).  LDS rows hold BK floats
+// with the 16-B chunk index XOR-swizzled by row bits, which makes the ds_read_b128 operand
+// fetches bank-conflict free (16 lanes x 16 B cover all 64 banks).
 //
 // K is consumed in a permuted order that is identical for A and W: per 8-wide group g the
 // lane half h = lane>>5 reads k = 8g+4h .. 8g+4h+3 as one 16-B LDS read and MFMA step j uses
@@ -28,6 +28,13 @@
 // branchy flat-load loader: address arithmetic + exec-mask branches, not latency, were the
 // loss.)  FAST = 0 is the general fallback (K tails, K-major operands, Cin % BK != 0,
 // operands >= 2 GiB).
+//
+// Work distribution: one tile per workgroup, or -- when the tile count does not divide over
+// the 256 CUs (e.g. 784 tiles: every CU waits for the 16 that got a 4th tile) -- stream-K:
+// a resident grid of 256 x MINB workgroups each takes an equal contiguous share of all
+// (tile, K-chunk) units; tiles cut by a share boundary leave raw partial accumulators in a
+// caller-provided workspace and a small second kernel sums them and runs the epilogue.
+// No inter-workgroup synchronisation inside a launch; results do not depend on scheduling.
 //
 // Roofline: MFMA-bound. 32x32x2 = 4096 FLOP / 64 cycles / SIMD -> 157.3 TFLOP/s chip peak.
 #include <stdlib.h>
@@ -49,6 +56,8 @@ struct IgemmP {
     int tiles_n, n_tiles;
     long long sa, sw, sbias, sres, sc;  // per-batch element strides (grid.y = batch index)
     unsigned a_bytes, w_bytes;          // FAST loader: buffer extents (< 2 GiB)
+    int sk_blocks;                      // stream-K: resident grid size (0 = one tile per block)
+    float* sk_ws;                       // stream-K: [sk_blocks][2][BM*BN] partial accumulators
 };
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -71,47 +80,59 @@ __device__ __forceinline__ int lds_off(int row, int kchunk) {  // float index of
     return row * BK + ((kchunk ^ lds_swz<BK>(row)) << 2);
 }
 
-// MINB = resident workgroups per CU the register allocator must leave room for (hipcc sizes
-// its VGPR budget from a 64-KB LDS model otherwise and drops the 128x128 tile to 1 block/CU).
-template <int BM, int BN, int WAVES_M, int WAVES_N, int AMODE, int WMODE, int BK, int MINB, int FAST>
-__global__ __launch_bounds__(256, MINB) void igemm_f32_kernel(const IgemmP p_in) {
-    constexpr int TM = BM / WAVES_M / 32, TN = BN / WAVES_N / 32;
+template <int BM, int BN, int WAVES_M, int WAVES_N, int BK>
+struct Geo {
+    static constexpr int TM = BM / WAVES_M / 32, TN = BN / WAVES_N / 32;
+    static constexpr int WTN = TN * 32;          // wave tile width
+    static constexpr int LROW = WTN + 4;         // padded epilogue-staging row (16-B aligned)
+    static constexpr int EPI_FLOATS = 4 * 32 * LROW;
+    static constexpr int LDS_FLOATS = 2 * (BM + BN) * BK > EPI_FLOATS ? 2 * (BM + BN) * BK : EPI_FLOATS;
+};
+
+// ---------------------------------------------------------------------------------------------
+// One output tile over K chunks [kb, ke).  partial == nullptr: full epilogue; otherwise the raw
+// accumulators are written to `partial` ([TM*TN*16][256] floats, thread-contiguous).
+// FIXUP = 1 (second stream-K kernel): no K loop; the accumulators are the sum of the partials of
+// workgroups fix_c0, fix_c0+1, ... whose shares intersect the tile, then the epilogue runs.
+// (The epilogue is deliberately part of this function body: hipcc allocated ~250 VGPRs and
+// spilled ~950 at the 128-register budget when it was a separate inlined function.)
+//
+// Epilogue.  C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+// Fast path (N, ldc, ldr multiples of 4): each wave transposes 32 output rows at a time through
+// its own slice of the (now idle) staging LDS so that every lane owns 4 consecutive columns:
+// bias/residual loads and stores are 16 B per lane, a whole 128/256-B row segment per 8/16
+// lanes, and all residual loads of a half tile are in flight together.  (The per-element path
+// below it was latency-bound at ~1 TB/s on the conv3 + residual layers.)
+// ---------------------------------------------------------------------------------------------
+template <int BM, int BN, int WAVES_M, int WAVES_N, int AMODE, int WMODE, int BK, int FAST, int FIXUP>
+__device__ __forceinline__ void igemm_tile(const IgemmP& p, float* lds, int tile, int kb, int ke, float* partial,
+                                           int fix_c0) {
+    using G = Geo<BM, BN, WAVES_M, WAVES_N, BK>;
+    constexpr int TM = G::TM, TN = G::TN, WTN = G::WTN, LROW = G::LROW;
     constexpr int CPR = BK / 4;                  // 16-B chunks per LDS row
     constexpr int RPP = 256 / CPR;               // rows covered by one pass of the 256 threads
     constexpr int ALD = (BM + RPP - 1) / RPP, WLD = (BN + RPP - 1) / RPP;  // float4 loads per thread per chunk
     // (a tile narrower than one pass of the 256 threads leaves the surplus threads idle: the
     //  `< BM` / `< BN` / `< BK` guards below are compile-time true otherwise)
-    static_assert(WAVES_M * WAVES_N == 4, "4 waves");
-    constexpr int EPI_FLOATS = 4 * 32 * (TN * 32 + 4);
-    constexpr int LDS_FLOATS = 2 * (BM + BN) * BK > EPI_FLOATS ? 2 * (BM + BN) * BK : EPI_FLOATS;
-    __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
     float* As = lds;                 // [2][BM][BK]
     float* Ws = lds + 2 * BM * BK;   // [2][BN][BK]
 
-    IgemmP p = p_in;
-    if (blockIdx.y) {   // batched GEMM: independent problems along grid.y
-        const long long b = blockIdx.y;
-        p.a += b * p.sa; p.w += b * p.sw; p.c += b * p.sc;
-        if (p.bias) p.bias += b * p.sbias;
-        if (p.res) p.res += b * p.sres;
-    }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int tile = xcd_remap(blockIdx.x, p.n_tiles);
     const int m0 = (tile / p.tiles_n) * BM, n0 = (tile % p.tiles_n) * BN;
     const int wm0 = (wave / WAVES_N) * (TM * 32), wn0 = (wave % WAVES_N) * (TN * 32);
 
-    // ---- per-thread global-load bookkeeping -------------------------------------------
+    // ---- per-thread global-load bookkeeping (fallback loader) -----------------------------------
     // row-major / conv: thread covers 16-B chunk (tid % CPR) of rows tid / CPR + RPP*i
     const int lc = tid % CPR, lr = tid / CPR;
     long long a_base[ALD];
     int a_hi0[ALD], a_wi0[ALD];
-    if constexpr (AMODE == 0) {
+    if constexpr (!FAST && AMODE == 0) {
 #pragma unroll
         for (int i = 0; i < ALD; ++i) {
             const int m = m0 + lr + RPP * i;
             a_base[i] = (m < p.M && lr + RPP * i < BM) ? (long long)m * p.lda : -1;
         }
-    } else if constexpr (AMODE == 1) {
+    } else if constexpr (!FAST && AMODE == 1) {
 #pragma unroll
         for (int i = 0; i < ALD; ++i) {
             const int m = m0 + lr + RPP * i;
@@ -135,7 +156,7 @@ __global__ __launch_bounds__(256, MINB) void igemm_f32_kernel(const IgemmP p_in)
     __amdgpu_buffer_rsrc_t rsA, rsW;
     int f_ci0 = 0, f_kh = 0, f_kw = 0, f_tap = 0;     // conv: wave-uniform position along K
     if constexpr (FAST) {
-        static_assert(AMODE != 2 && WMODE == 0, "FAST loader: K-contiguous operands only");
+        static_assert(!FAST || (AMODE != 2 && WMODE == 0), "FAST loader: K-contiguous operands only");
         rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.a, 0, (int)p.a_bytes, 0x00020000);
         rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)p.w_bytes, 0x00020000);
 #pragma unroll
@@ -165,6 +186,11 @@ __global__ __launch_bounds__(256, MINB) void igemm_f32_kernel(const IgemmP p_in)
                             msk |= 1u << (kh * p.KW + kw);
                 fa_mask[i] = rv ? msk : 0u;
             }
+        }
+        if constexpr (AMODE == 1) {   // position of chunk kb along (kh, kw, cin)
+            const int k = kb * BK;
+            f_tap = k / p.Cin; f_ci0 = k - f_tap * p.Cin;
+            f_kh = f_tap / p.KW; f_kw = f_tap - f_kh * p.KW;
         }
     }
 
@@ -281,15 +307,33 @@ __global__ __launch_bounds__(256, MINB) void igemm_f32_kernel(const IgemmP p_in)
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int fr = lane & 31, fh = lane >> 5, fsw = lds_swz<BK>(fr);
-    const int nk = (p.K + BK - 1) / BK;
 
-    load_a(0); load_w(0);
+    if constexpr (FIXUP) {
+        const int nk = (p.K + BK - 1) / BK;
+        const long long U = (long long)p.n_tiles * nk, t = tile;
+        for (int c = fix_c0; c < p.sk_blocks; ++c) {
+            const long long bc = U * c / p.sk_blocks;
+            if (bc >= (t + 1) * nk) break;
+            if (U * (c + 1) / p.sk_blocks == bc) continue;   // empty share: wrote nothing
+            // slot 0 = a share that starts inside the tile, slot 1 = one that started earlier
+            const float* part = p.sk_ws + ((size_t)c * 2 + (bc >= t * nk ? 0 : 1)) * (size_t)(BM * BN);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] += part[((i * TN + j) * 16 + r) * 256 + tid];
+        }
+    } else {
+    __syncthreads();                      // a previous tile of this workgroup may still use the LDS
+    load_a(kb * BK); load_w(kb * BK);
     store_lds(0);
     __syncthreads();
+    }
 
-    for (int kc = 0; kc < nk; ++kc) {
-        const int buf = kc & 1;
-        if (kc + 1 < nk) { load_a((kc + 1) * BK); load_w((kc + 1) * BK); }
+    for (int kc = kb; !FIXUP && kc < ke; ++kc) {
+        const int buf = (kc - kb) & 1;
+        if (kc + 1 < ke) { load_a((kc + 1) * BK); load_w((kc + 1) * BK); }
         const float* Ab = As + buf * BM * BK;
         const float* Wb = Ws + buf * BN * BK;
 #pragma unroll
@@ -308,23 +352,23 @@ __global__ __launch_bounds__(256, MINB) void igemm_f32_kernel(const IgemmP p_in)
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], wf[j][s], acc[i][j], 0, 0, 0);
         }
-        if (kc + 1 < nk) store_lds(buf ^ 1);
+        if (kc + 1 < ke) store_lds(buf ^ 1);
         __syncthreads();
     }
 
-    // ---- epilogue -----------------------------------------------------------------------
-    // C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
-    // Fast path (N, ldc, ldr multiples of 4): each wave transposes 32 output rows at a time
-    // through its own slice of the (now idle) staging LDS so that every lane owns 4
-    // consecutive columns: residual loads and stores become 16 B per lane, a whole
-    // 128/256-B row segment per 8/16 lanes, and all residual loads of a half-tile are in
-    // flight together.  (The per-element path below it was latency-bound at ~1 TB/s.)
-    constexpr int WTN = TN * 32;              // wave tile width
-    constexpr int LROW = WTN + 4;             // padded LDS row (keeps 16-B alignment)
+    if (partial) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) partial[((i * TN + j) * 16 + r) * 256 + tid] = acc[i][j][r];
+        return;
+    }
+    {
     constexpr int LPR = WTN / 4;              // lanes per output row
     constexpr int RPI = 64 / LPR;             // rows per wave instruction
     constexpr int NIT = 32 / RPI;             // instructions per 32-row half tile
-    static_assert(4 * 32 * LROW <= LDS_FLOATS, "epilogue staging fits in the tile LDS");
     const bool vec_ok = ((p.N & 3) == 0) && ((p.ldc & 3) == 0) && (!p.res || (p.ldr & 3) == 0);
     if (vec_ok) {
         float* Ls = lds + wave * (32 * LROW);
@@ -386,68 +430,143 @@ __global__ __launch_bounds__(256, MINB) void igemm_f32_kernel(const IgemmP p_in)
             }
         }
     }
+    }
+}
+
+// MINB = resident workgroups per CU the register allocator must leave room for (hipcc sizes
+// its VGPR budget from a 64-KB LDS model otherwise and drops the 128x128 tile to 1 block/CU).
+template <int BM, int BN, int WAVES_M, int WAVES_N, int AMODE, int WMODE, int BK, int MINB, int FAST, int SK>
+__global__ __launch_bounds__(256, MINB) void igemm_f32_kernel(const IgemmP p_in) {
+    static_assert(WAVES_M * WAVES_N == 4, "4 waves");
+    using G = Geo<BM, BN, WAVES_M, WAVES_N, BK>;
+    __shared__ __attribute__((aligned(16))) float lds[G::LDS_FLOATS];
+    IgemmP p = p_in;
+    if (blockIdx.y) {   // batched GEMM: independent problems along grid.y
+        const long long b = blockIdx.y;
+        p.a += b * p.sa; p.w += b * p.sw; p.c += b * p.sc;
+        if (p.bias) p.bias += b * p.sbias;
+        if (p.res) p.res += b * p.sres;
+    }
+    const int nk = (p.K + BK - 1) / BK;
+    if constexpr (!SK) {
+        igemm_tile<BM, BN, WAVES_M, WAVES_N, AMODE, WMODE, BK, FAST, 0>(p, lds, xcd_remap(blockIdx.x, p.n_tiles), 0,
+                                                                        nk, nullptr, 0);
+    } else {
+        // stream-K: this workgroup's contiguous share [u, u1) of the n_tiles * nk (tile, chunk) units
+        const long long U = (long long)p.n_tiles * nk;
+        long long u = U * blockIdx.x / p.sk_blocks;
+        const long long u1 = U * (blockIdx.x + 1) / p.sk_blocks;
+        for (int seg = 0; u < u1; ++seg) {
+            const int tile = (int)(u / nk), kb = (int)(u - (long long)tile * nk);
+            const int ke = (int)((u1 - u < nk - kb) ? kb + (u1 - u) : nk);
+            float* partial = (kb == 0 && ke == nk)
+                                 ? nullptr
+                                 : p.sk_ws + ((size_t)blockIdx.x * 2 + (seg ? 1 : 0)) * (size_t)(BM * BN);
+            igemm_tile<BM, BN, WAVES_M, WAVES_N, AMODE, WMODE, BK, FAST, 0>(p, lds, tile, kb, ke, partial, 0);
+            u += ke - kb;
+        }
+    }
+}
+
+// Second stream-K kernel: workgroup g (1 <= g < sk_blocks) owns share boundary g.  If that
+// boundary cuts tile t and is the first boundary inside t, it sums every partial of t (the
+// workgroups whose shares intersect t, recomputed from the same arithmetic) and runs the
+// epilogue.  Slot 0 = a share that starts inside t, slot 1 = a share that started earlier.
+template <int BM, int BN, int WAVES_M, int WAVES_N, int BK>
+__global__ __launch_bounds__(256) void igemm_fixup_kernel(const IgemmP p) {
+    using G = Geo<BM, BN, WAVES_M, WAVES_N, BK>;
+    __shared__ __attribute__((aligned(16))) float lds[G::EPI_FLOATS];
+    const int nk = (p.K + BK - 1) / BK;
+    const long long U = (long long)p.n_tiles * nk;
+    const int g = blockIdx.x + 1, nb = p.sk_blocks;
+    const long long b = U * g / nb;
+    if (b % nk == 0) return;                                  // boundary on a tile edge: nothing split
+    const long long t = b / nk;
+    const long long bp = U * (g - 1) / nb;
+    if (bp % nk != 0 && bp / nk == t) return;                 // an earlier boundary owns this tile
+    igemm_tile<BM, BN, WAVES_M, WAVES_N, 0, 0, BK, 0, 1>(p, lds, (int)t, 0, 0, nullptr, g - 1);
 }
 
 // FAST loader eligibility (see the header comment); `DBMM_IGEMM_FAST=0` forces the fallback.
 template <int AMODE, int WMODE, int BK>
-bool fast_ok(const IgemmP& p, int nbatch) {
+bool fast_ok(const IgemmP& p) {
     static const int allow = [] { const char* e = getenv("DBMM_IGEMM_FAST"); return e ? atoi(e) : 1; }();
     if (!allow || AMODE == 2 || WMODE != 0 || (p.K % BK) != 0) return false;
     if (AMODE == 1 && ((p.Cin % BK) != 0 || p.KH * p.KW > 32)) return false;
-    (void)nbatch;
     return p.a_bytes != 0 && p.w_bytes != 0;
 }
 
+constexpr int NUM_CUS = 256;
+
 template <int BM, int BN, int WM, int WN, int AMODE, int WMODE, int BK, int MINB>
-int launch_cfg(IgemmP& p, hipStream_t s, int nbatch) {
+int launch_cfg(IgemmP& p, hipStream_t s, int nbatch, void* ws, size_t ws_bytes) {
     const int tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = (p.N + BN - 1) / BN;
     p.n_tiles = tiles_m * p.tiles_n;
-    if constexpr (AMODE != 2 && WMODE == 0) {
-        if (fast_ok<AMODE, WMODE, BK>(p, nbatch)) {
-            hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN, AMODE, WMODE, BK, MINB, 1>), dim3(p.n_tiles, nbatch),
-                               dim3(256), 0, s, p);
-            DBMM_CHECK_LAUNCH();
-            return DBMM_OK;
+    p.sk_blocks = 0; p.sk_ws = nullptr;
+    // stream-K when whole tiles leave >7 % of the chip idle in the last round and the tile's K
+    // loop is long enough to be worth cutting (DBMM_IGEMM_STREAMK=0 disables, =2 forces)
+    static const int sk_mode = [] { const char* e = getenv("DBMM_IGEMM_STREAMK"); return e ? atoi(e) : 1; }();
+    const int nk = (p.K + BK - 1) / BK;
+    const int grid_sk = NUM_CUS * MINB;
+    const size_t need = (size_t)grid_sk * 2 * BM * BN * sizeof(float);
+    if (sk_mode && nbatch == 1 && ws && ws_bytes >= need && dbmm_aligned16(ws) && nk >= 8) {
+        const double per_cu = (double)p.n_tiles / NUM_CUS;
+        const double eff = per_cu / (double)((p.n_tiles + NUM_CUS - 1) / NUM_CUS);
+        if (sk_mode == 2 || (eff < 0.93 && (long long)p.n_tiles * nk >= 4LL * grid_sk)) {
+            p.sk_blocks = grid_sk; p.sk_ws = (float*)ws;
         }
     }
-    hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN, AMODE, WMODE, BK, MINB, 0>), dim3(p.n_tiles, nbatch), dim3(256),
-                       0, s, p);
+    const dim3 grid(p.sk_blocks ? p.sk_blocks : p.n_tiles, nbatch);
+    bool launched = false;
+    if constexpr (AMODE != 2 && WMODE == 0) {
+        if (fast_ok<AMODE, WMODE, BK>(p)) {
+            if (p.sk_blocks)
+                hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN, AMODE, WMODE, BK, MINB, 1, 1>), grid, dim3(256), 0, s, p);
+            else
+                hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN, AMODE, WMODE, BK, MINB, 1, 0>), grid, dim3(256), 0, s, p);
+            launched = true;
+        }
+    }
+    if (!launched) {
+        if (p.sk_blocks)
+            hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN, AMODE, WMODE, BK, MINB, 0, 1>), grid, dim3(256), 0, s, p);
+        else
+            hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN, AMODE, WMODE, BK, MINB, 0, 0>), grid, dim3(256), 0, s, p);
+    }
     DBMM_CHECK_LAUNCH();
+    if (p.sk_blocks) {
+        hipLaunchKernelGGL((igemm_fixup_kernel<BM, BN, WM, WN, BK>), dim3(p.sk_blocks - 1), dim3(256), 0, s, p);
+        DBMM_CHECK_LAUNCH();
+    }
     return DBMM_OK;
 }
 
-// developer knob: DBMM_IGEMM_BK=16|32 forces the K-chunk depth of the 128-wide tiles
+// developer knob: DBMM_IGEMM_BK=32 forces the 64-KB / 2-workgroups-per-CU variants
 inline int forced_bk() {
     static const int v = [] { const char* e = getenv("DBMM_IGEMM_BK"); return e ? atoi(e) : 0; }();
     return v;
 }
 
 template <int AMODE, int WMODE>
-int launch_modes(IgemmP& p, hipStream_t s, int nbatch = 1) {
+int launch_modes(IgemmP& p, hipStream_t s, int nbatch = 1, void* ws = nullptr, size_t wsb = 0) {
     // tile choice: widest N tile that N fills; drop to 64x64 when the 128-wide grid would
     // leave most of the 256 CUs idle (small-M projections).
     const long long t128 = (long long)((p.M + 127) / 128) * ((p.N + 127) / 128) * nbatch;
-    const int bk = forced_bk() ? forced_bk() : 16;
-    if (bk == 32) {
-        if (p.N <= 32) return launch_cfg<128, 32, 4, 1, AMODE, WMODE, 32, 3>(p, s, nbatch);
-        if (p.N <= 64) return launch_cfg<128, 64, 2, 2, AMODE, WMODE, 32, 3>(p, s, nbatch);
-        if (t128 < 192) return launch_cfg<64, 64, 2, 2, AMODE, WMODE, 32, 4>(p, s, nbatch);
-        return launch_cfg<128, 128, 2, 2, AMODE, WMODE, 32, 2>(p, s, nbatch);
+    if (forced_bk() == 32) {
+        if (p.N <= 32) return launch_cfg<128, 32, 4, 1, AMODE, WMODE, 32, 3>(p, s, nbatch, ws, wsb);
+        if (p.N <= 64) return launch_cfg<128, 64, 2, 2, AMODE, WMODE, 32, 3>(p, s, nbatch, ws, wsb);
+        if (t128 < 192) return launch_cfg<64, 64, 2, 2, AMODE, WMODE, 32, 4>(p, s, nbatch, ws, wsb);
+        return launch_cfg<128, 128, 2, 2, AMODE, WMODE, 32, 2>(p, s, nbatch, ws, wsb);
     }
-    // default: 16-deep K chunks -> 18-35 KB of LDS per workgroup, 4-8 resident workgroups
-    // per CU (one wave of each on every SIMD) so a wave parked at a barrier, a global load or
-    // in its epilogue always leaves others feeding the matrix pipe.
-    {
-        static const int ft = [] { const char* e = getenv("DBMM_IGEMM_TILE"); return e ? atoi(e) : 0; }();
-        if (ft == 64 && p.N > 64) return launch_cfg<64, 64, 2, 2, AMODE, WMODE, 16, 6>(p, s, nbatch);
-        if (ft == 12864 && p.N > 64) return launch_cfg<128, 64, 2, 2, AMODE, WMODE, 16, 5>(p, s, nbatch);
-    }
-    // (the narrow-N tiles measured 2-5 % faster with 32-deep chunks at 3 workgroups per CU)
-    if (p.N <= 32) return launch_cfg<128, 32, 4, 1, AMODE, WMODE, 32, 3>(p, s, nbatch);
-    if (p.N <= 64) return launch_cfg<128, 64, 2, 2, AMODE, WMODE, 32, 3>(p, s, nbatch);
-    if (t128 < 192) return launch_cfg<64, 64, 2, 2, AMODE, WMODE, 16, 6>(p, s, nbatch);
-    return launch_cfg<128, 128, 2, 2, AMODE, WMODE, 16, 4>(p, s, nbatch);
+    // default: 16-deep K chunks on the 128x128 tile -> 35 KB of LDS per workgroup, 4 resident
+    // workgroups per CU (one wave of each on every SIMD) so a wave parked at a barrier, a global
+    // load or in its epilogue always leaves others feeding the matrix pipe.  (The narrow-N
+    // tiles measured 2-5 % faster with 32-deep chunks at 3 workgroups per CU.)
+    if (p.N <= 32) return launch_cfg<128, 32, 4, 1, AMODE, WMODE, 32, 3>(p, s, nbatch, ws, wsb);
+    if (p.N <= 64) return launch_cfg<128, 64, 2, 2, AMODE, WMODE, 32, 3>(p, s, nbatch, ws, wsb);
+    if (t128 < 192) return launch_cfg<64, 64, 2, 2, AMODE, WMODE, 16, 6>(p, s, nbatch, ws, wsb);
+    return launch_cfg<128, 128, 2, 2, AMODE, WMODE, 16, 4>(p, s, nbatch, ws, wsb);
 }
 
 // buffer extents for the FAST loader; 0 (= not eligible) when an operand reaches 2 GiB
@@ -457,12 +576,9 @@ inline void set_extents(IgemmP& p, long long a_bytes, long long w_bytes) {
     p.w_bytes = (w_bytes > 0 && w_bytes < lim) ? (unsigned)w_bytes : 0u;
 }
 
-}  // namespace
-
-extern "C" int dbmm_gemm_bias_act(const float* a, int64_t lda, int trans_a, const float* w, int64_t ldw,
-                                  int trans_w, const float* bias, const float* residual, int64_t ldr,
-                                  float* c, int64_t ldc, int64_t M, int64_t N, int64_t K, float alpha,
-                                  int act, void* stream) {
+int gemm_impl(const float* a, int64_t lda, int trans_a, const float* w, int64_t ldw, int trans_w, const float* bias,
+              const float* residual, int64_t ldr, float* c, int64_t ldc, int64_t M, int64_t N, int64_t K, float alpha,
+              int act, void* ws, size_t wsb, void* stream) {
     if (!a || !w || !c) return DBMM_E_ARG;
     if (M <= 0 || N <= 0 || K <= 0 || M > INT32_MAX || N > INT32_MAX || K > INT32_MAX) return DBMM_E_SHAPE;
     if (act < 0 || act > 2) return DBMM_E_ARG;
@@ -478,10 +594,58 @@ extern "C" int dbmm_gemm_bias_act(const float* a, int64_t lda, int trans_a, cons
     p.M = (int)M; p.N = (int)N; p.K = (int)K; p.act = act; p.alpha = alpha;
     set_extents(p, trans_a ? 0 : ((M - 1) * lda + K) * 4, trans_w ? 0 : ((N - 1) * ldw + K) * 4);
     hipStream_t s = (hipStream_t)stream;
-    if (!trans_a && !trans_w) return launch_modes<0, 0>(p, s);
-    if (!trans_a && trans_w) return launch_modes<0, 1>(p, s);
-    if (trans_a && !trans_w) return launch_modes<2, 0>(p, s);
-    return launch_modes<2, 1>(p, s);
+    if (!trans_a && !trans_w) return launch_modes<0, 0>(p, s, 1, ws, wsb);
+    if (!trans_a && trans_w) return launch_modes<0, 1>(p, s, 1, ws, wsb);
+    if (trans_a && !trans_w) return launch_modes<2, 0>(p, s, 1, ws, wsb);
+    return launch_modes<2, 1>(p, s, 1, ws, wsb);
+}
+
+int conv_impl(const float* x, const float* w, const float* bias, const float* residual, float* y, int64_t B, int64_t H,
+              int64_t W, int64_t Cin, int64_t Cout, int64_t KH, int64_t KW, int64_t stride, int64_t pad, int act,
+              void* ws, size_t wsb, void* stream) {
+    if (!x || !w || !y) return DBMM_E_ARG;
+    if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || KH <= 0 || KW <= 0 || stride <= 0 || pad < 0)
+        return DBMM_E_SHAPE;
+    if (Cin & 3) return DBMM_E_SHAPE;
+    if (act < 0 || act > 2) return DBMM_E_ARG;
+    if (!dbmm_aligned16(x) || !dbmm_aligned16(w)) return DBMM_E_ALIGN;
+    const int64_t Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
+    if (Ho <= 0 || Wo <= 0) return DBMM_E_SHAPE;
+    const int64_t M = B * Ho * Wo, K = KH * KW * Cin;
+    if (M > INT32_MAX || K > INT32_MAX) return DBMM_E_SHAPE;
+    IgemmP p{};
+    p.a = x; p.w = w; p.bias = bias; p.res = residual; p.c = y;
+    p.lda = Cin; p.ldw = K; p.ldr = Cout; p.ldc = Cout;
+    p.M = (int)M; p.N = (int)Cout; p.K = (int)K; p.act = act; p.alpha = 1.f;
+    p.H = (int)H; p.W = (int)W; p.Cin = (int)Cin; p.Ho = (int)Ho; p.Wo = (int)Wo;
+    p.KH = (int)KH; p.KW = (int)KW; p.stride = (int)stride; p.pad = (int)pad;
+    set_extents(p, B * H * W * Cin * 4, Cout * K * 4);
+    hipStream_t s = (hipStream_t)stream;
+    if (KH == 1 && KW == 1 && stride == 1 && pad == 0) return launch_modes<0, 0>(p, s, 1, ws, wsb);  // plain GEMM
+    return launch_modes<1, 0>(p, s, 1, ws, wsb);
+}
+
+}  // namespace
+
+extern "C" size_t dbmm_workspace_bytes_igemm(void) {
+    // stream-K partial accumulators: (256 CUs x 6 resident workgroups) x 2 slots x 128x128 fp32
+    return (size_t)NUM_CUS * 6 * 2 * 128 * 128 * sizeof(float);
+}
+
+extern "C" int dbmm_gemm_bias_act(const float* a, int64_t lda, int trans_a, const float* w, int64_t ldw,
+                                  int trans_w, const float* bias, const float* residual, int64_t ldr,
+                                  float* c, int64_t ldc, int64_t M, int64_t N, int64_t K, float alpha,
+                                  int act, void* stream) {
+    return gemm_impl(a, lda, trans_a, w, ldw, trans_w, bias, residual, ldr, c, ldc, M, N, K, alpha, act, nullptr, 0,
+                     stream);
+}
+
+extern "C" int dbmm_gemm_bias_act_ws(const float* a, int64_t lda, int trans_a, const float* w, int64_t ldw,
+                                     int trans_w, const float* bias, const float* residual, int64_t ldr, float* c,
+                                     int64_t ldc, int64_t M, int64_t N, int64_t K, float alpha, int act,
+                                     void* workspace, size_t workspace_bytes, void* stream) {
+    return gemm_impl(a, lda, trans_a, w, ldw, trans_w, bias, residual, ldr, c, ldc, M, N, K, alpha, act, workspace,
+                     workspace_bytes, stream);
 }
 
 extern "C" int dbmm_gemm_batched(const float* a, int64_t lda, int64_t stride_a, int trans_a, const float* w,
@@ -513,26 +677,15 @@ extern "C" int dbmm_gemm_batched(const float* a, int64_t lda, int64_t stride_a, 
 extern "C" int dbmm_conv_bn_act(const float* x, const float* w, const float* bias, const float* residual,
                                 float* y, int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t Cout,
                                 int64_t KH, int64_t KW, int64_t stride, int64_t pad, int act, void* stream) {
-    if (!x || !w || !y) return DBMM_E_ARG;
-    if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || KH <= 0 || KW <= 0 || stride <= 0 || pad < 0)
-        return DBMM_E_SHAPE;
-    if (Cin & 3) return DBMM_E_SHAPE;
-    if (act < 0 || act > 2) return DBMM_E_ARG;
-    if (!dbmm_aligned16(x) || !dbmm_aligned16(w)) return DBMM_E_ALIGN;
-    const int64_t Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
-    if (Ho <= 0 || Wo <= 0) return DBMM_E_SHAPE;
-    const int64_t M = B * Ho * Wo, K = KH * KW * Cin;
-    if (M > INT32_MAX || K > INT32_MAX) return DBMM_E_SHAPE;
-    IgemmP p{};
-    p.a = x; p.w = w; p.bias = bias; p.res = residual; p.c = y;
-    p.lda = Cin; p.ldw = K; p.ldr = Cout; p.ldc = Cout;
-    p.M = (int)M; p.N = (int)Cout; p.K = (int)K; p.act = act; p.alpha = 1.f;
-    p.H = (int)H; p.W = (int)W; p.Cin = (int)Cin; p.Ho = (int)Ho; p.Wo = (int)Wo;
-    p.KH = (int)KH; p.KW = (int)KW; p.stride = (int)stride; p.pad = (int)pad;
-    set_extents(p, B * H * W * Cin * 4, Cout * K * 4);
-    hipStream_t s = (hipStream_t)stream;
-    if (KH == 1 && KW == 1 && stride == 1 && pad == 0) return launch_modes<0, 0>(p, s);  // plain GEMM
-    return launch_modes<1, 0>(p, s);
+    return conv_impl(x, w, bias, residual, y, B, H, W, Cin, Cout, KH, KW, stride, pad, act, nullptr, 0, stream);
+}
+
+extern "C" int dbmm_conv_bn_act_ws(const float* x, const float* w, const float* bias, const float* residual,
+                                   float* y, int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int64_t KH,
+                                   int64_t KW, int64_t stride, int64_t pad, int act, void* workspace,
+                                   size_t workspace_bytes, void* stream) {
+    return conv_impl(x, w, bias, residual, y, B, H, W, Cin, Cout, KH, KW, stride, pad, act, workspace, workspace_bytes,
+                     stream);
 }
 
 extern "C" int dbmm_conv1x1_bn_act(const float* x, const float* w, const float* bias, const float* residual,
@@ -545,14 +698,4 @@ extern "C" int dbmm_conv3x3_bn_act(const float* x, const float* w, const float* 
                                    float* y, int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t Cout,
                                    int act, void* stream) {
     return dbmm_conv_bn_act(x, w, bias, residual, y, B, H, W, Cin, Cout, 3, 3, 1, 1, act, stream);
-}
-
-// developer aid (not part of include/dbmm.h): resident blocks per CU of the main tiles
-extern "C" int dbmm_debug_occupancy(int* out4) {
-    int n = 0;
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, igemm_f32_kernel<128, 128, 2, 2, 1, 0, 32, 2, 1>, 256, 0); out4[0] = n;
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, igemm_f32_kernel<128, 128, 2, 2, 1, 0, 16, 4, 1>, 256, 0); out4[1] = n;
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, igemm_f32_kernel<128, 64, 2, 2, 1, 0, 32, 3, 1>, 256, 0); out4[2] = n;
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, igemm_f32_kernel<64, 64, 2, 2, 0, 0, 16, 6, 1>, 256, 0); out4[3] = n;
-    return 0;
 }

@@ -65,6 +65,20 @@ class _Timed:
             _prof.append((_igemm_tag(M, N, amode, wmode), 2.0 * M * N * K, self.e0, e1))
 
 
+_ws_cache = {}
+
+
+def igemm_workspace(device):
+    """per-device scratch for the stream-K work split (allocated once, reused by every launch on
+    the stream; launches on one stream are ordered, so sharing it is safe)."""
+    key = (device.type, device.index)
+    ws = _ws_cache.get(key)
+    if ws is None:
+        ws = torch.empty(_lib.lib().dbmm_workspace_bytes_igemm() // 4, device=device, dtype=torch.float32)
+        _ws_cache[key] = ws
+    return ws
+
+
 def _f32c(t):
     if t.dtype != torch.float32 or not t.is_contiguous():
         raise _lib.DbmmError(f"expected a contiguous float32 tensor, got {t.dtype} contiguous={t.is_contiguous()}")
@@ -90,10 +104,11 @@ def gemm(a, w, bias=None, residual=None, act=ACT_NONE, alpha=1.0, trans_a=False,
     if out is None:
         out = torch.empty((M, N), device=a.device, dtype=torch.float32)
     ldr = residual.shape[-1] if residual is not None else 0
+    ws = igemm_workspace(a.device)
     with _Timed(M, N, K, 2 if trans_a else 0, int(trans_w)):
-        check(_lib.lib().dbmm_gemm_bias_act(ptr(a), lda, int(trans_a), ptr(w), w.shape[-1], int(trans_w), ptr(bias),
-                                            ptr(residual), ldr, ptr(out), out.shape[-1], M, N, K, float(alpha), act,
-                                            stream()), "gemm_bias_act")
+        check(_lib.lib().dbmm_gemm_bias_act_ws(ptr(a), lda, int(trans_a), ptr(w), w.shape[-1], int(trans_w), ptr(bias),
+                                               ptr(residual), ldr, ptr(out), out.shape[-1], M, N, K, float(alpha), act,
+                                               ptr(ws), ws.numel() * 4, stream()), "gemm_bias_act")
     return out
 
 
@@ -108,8 +123,9 @@ def conv_bn_act(x, w, bias, residual, kh, kw, stride, pad, act):
     y = torch.empty((B, Ho, Wo, Cout), device=x.device, dtype=torch.float32)
     plain = kh == 1 and kw == 1 and stride == 1 and pad == 0
     with _Timed(B * Ho * Wo, Cout, kh * kw * Cin, 0 if plain else 1, 0):
-        check(_lib.lib().dbmm_conv_bn_act(ptr(x), ptr(w), ptr(bias), ptr(residual), ptr(y), B, H, W, Cin, Cout, kh, kw,
-                                          stride, pad, act, stream()), "conv_bn_act")
+        ws = igemm_workspace(x.device)
+        check(_lib.lib().dbmm_conv_bn_act_ws(ptr(x), ptr(w), ptr(bias), ptr(residual), ptr(y), B, H, W, Cin, Cout, kh,
+                                             kw, stride, pad, act, ptr(ws), ws.numel() * 4, stream()), "conv_bn_act")
     return y
 
 

@@ -72,6 +72,19 @@ int dbmm_gemm_bias_act(const float* a, int64_t lda, int trans_a, const float* w,
                        float* c, int64_t ldc, int64_t M, int64_t N, int64_t K, float alpha,
                        int act, void* stream);
 
+/* Variants with a caller-provided scratch buffer (dbmm_workspace_bytes_igemm() bytes, 16-B
+ * aligned).  With it the library may pick the stream-K work split when whole tiles would
+ * leave part of the 256 CUs idle (e.g. 784 tiles); results are deterministic either way. */
+size_t dbmm_workspace_bytes_igemm(void);
+int dbmm_conv_bn_act_ws(const float* x, const float* w, const float* bias, const float* residual,
+                        float* y, int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t Cout,
+                        int64_t KH, int64_t KW, int64_t stride, int64_t pad, int act,
+                        void* workspace, size_t workspace_bytes, void* stream);
+int dbmm_gemm_bias_act_ws(const float* a, int64_t lda, int trans_a, const float* w, int64_t ldw,
+                          int trans_w, const float* bias, const float* residual, int64_t ldr,
+                          float* c, int64_t ldc, int64_t M, int64_t N, int64_t K, float alpha,
+                          int act, void* workspace, size_t workspace_bytes, void* stream);
+
 /* `batch` independent GEMMs of identical shape in one launch (grid.y): problem b uses
  * a + b*stride_a, w + b*stride_w, bias + b*stride_bias, c + b*stride_c (element strides,
  * multiples of 4).  Used for the per-head products of the collapsed attention pool. */

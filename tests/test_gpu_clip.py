@@ -98,10 +98,13 @@ def test_clip_forward_and_surface(models):
 
 def test_large_batch_property_rn50(models):
     """at a batch the oracle would take minutes for: rows are independent, so any row of a big
-    batch must equal the same image encoded alone (bit-exact: same kernels, same K order)."""
+    batch must equal the same image encoded alone.  Not bit-exact: tile shapes and the stream-K
+    split points depend on the batch, which changes the (deterministic) fp32 summation order."""
     model = models("RN50", 2)
     img = synth.images(9, 48, 224).cuda()
     big = model.encode_image(img)
     small = model.encode_image(img[17:19].contiguous())
     assert torch.isfinite(big).all()
-    assert torch.equal(big[17:19], small)
+    assert relerr(big[17:19].cpu(), small.cpu()) < 1e-5
+    again = model.encode_image(img)
+    assert torch.equal(big, again)               # same shape -> same schedule -> bit-identical

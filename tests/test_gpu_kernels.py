@@ -286,3 +286,19 @@ def test_group_count_bit_exact():
     ops.group_count(logits.to(DEV), y.to(DEV), g.to(DEV), counts)      # accumulates
     import adapter_oracle as AO
     assert (counts.cpu().numpy() == 2 * AO.group_counts(logits, y, g, G)).all()
+
+
+def test_gemm_streamk_split_shapes():
+    """784 tiles over 256 CUs triggers the stream-K work split (partials + fix-up kernel);
+    3-image conv below cuts tiles in the middle of a tap as well."""
+    M, N, K = 25088, 512, 1152
+    a = rnd(1, "a", (M, K)); w = rnd(2, "w", (N, K), K ** -0.5); b = rnd(3, "b", (N,)); r = rnd(4, "r", (M, N))
+    ref = F.relu(a @ w.t() + b + r)
+    out = ops.gemm(a.to(DEV), w.to(DEV), b.to(DEV), residual=r.to(DEV), act=ops.ACT_RELU)
+    assert relerr(out.cpu(), ref) < 2e-5
+    B, H, Cin, Cout = 128, 14, 256, 256            # M = 25088 -> 392 tiles of 128x128
+    x = rnd(5, "x", (B, Cin, H, H)); wc = rnd(6, "wc", (Cout, Cin, 3, 3), (Cin * 9) ** -0.5)
+    refc = F.relu(F.conv2d(x, wc, None, padding=1)).permute(0, 2, 3, 1)
+    outc = ops.conv_bn_act(x.permute(0, 2, 3, 1).contiguous().to(DEV), wc.permute(0, 2, 3, 1).contiguous().to(DEV),
+                           None, None, 3, 3, 1, 1, ops.ACT_RELU)
+    assert relerr(outc.cpu(), refc) < 2e-5
