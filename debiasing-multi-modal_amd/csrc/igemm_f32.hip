@@ -559,12 +559,11 @@ int launch_modes(IgemmP& p, hipStream_t s, int nbatch = 1, void* ws = nullptr, s
         if (t128 < 192) return launch_cfg<64, 64, 2, 2, AMODE, WMODE, 32, 4>(p, s, nbatch, ws, wsb);
         return launch_cfg<128, 128, 2, 2, AMODE, WMODE, 32, 2>(p, s, nbatch, ws, wsb);
     }
-    // default: 16-deep K chunks on the 128x128 tile -> 35 KB of LDS per workgroup, 4 resident
-    // workgroups per CU (one wave of each on every SIMD) so a wave parked at a barrier, a global
-    // load or in its epilogue always leaves others feeding the matrix pipe.  (The narrow-N
-    // tiles measured 2-5 % faster with 32-deep chunks at 3 workgroups per CU.)
-    if (p.N <= 32) return launch_cfg<128, 32, 4, 1, AMODE, WMODE, 32, 3>(p, s, nbatch, ws, wsb);
-    if (p.N <= 64) return launch_cfg<128, 64, 2, 2, AMODE, WMODE, 32, 3>(p, s, nbatch, ws, wsb);
+    // default: 16-deep K chunks -> 18-35 KB of LDS per workgroup, 4-6 resident workgroups per CU
+    // (one wave of each on every SIMD) so a wave parked at a barrier, a global load or in its
+    // epilogue always leaves others feeding the matrix pipe.
+    if (p.N <= 32) return launch_cfg<128, 32, 4, 1, AMODE, WMODE, 16, 6>(p, s, nbatch, ws, wsb);
+    if (p.N <= 64) return launch_cfg<128, 64, 2, 2, AMODE, WMODE, 16, 5>(p, s, nbatch, ws, wsb);
     if (t128 < 192) return launch_cfg<64, 64, 2, 2, AMODE, WMODE, 16, 6>(p, s, nbatch, ws, wsb);
     return launch_cfg<128, 128, 2, 2, AMODE, WMODE, 16, 4>(p, s, nbatch, ws, wsb);
 }

@@ -34,6 +34,11 @@ def all_gather_rows(t, group=None):
     if world == 1:
         return t
     t = t.contiguous()
+    if t.is_cuda and dist.get_backend(group) == "gloo":
+        # rehearsal path only (several ranks sharing one GPU cannot use RCCL): stage through the host
+        host = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype)
+        dist.all_gather_into_tensor(host, t.cpu(), group=group)
+        return host.to(t.device)
     out = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
     dist.all_gather_into_tensor(out, t, group=group)
     return out

@@ -38,9 +38,9 @@ def _igemm_tag(M, N, amode, wmode):
     (mirrors launch_modes() in csrc/igemm_f32.hip)."""
     t128 = ((M + 127) // 128) * ((N + 127) // 128)
     if N <= 32:
-        tile, bk = "128,32,4,1", 32
+        tile, bk = "128,32,4,1", 16
     elif N <= 64:
-        tile, bk = "128,64,2,2", 32
+        tile, bk = "128,64,2,2", 16
     elif t128 < 192:
         tile, bk = "64,64,2,2", 16
     else:
