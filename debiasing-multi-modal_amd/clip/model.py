@@ -108,8 +108,8 @@ def _fold_bn(conv_w, bn):
 
 
 def _pack_conv(w64):
-    """[Cout][Cin][kh][kw] -> [Cout][kh][kw][Cin] fp32 contiguous (K order of the igemm kernel)."""
-    return w64.permute(0, 2, 3, 1).contiguous().float()
+    """[Cout][Cin][kh][kw] fp64 (BN folded) -> (packed fp32 weight, layout id) for ops.conv_bn_act."""
+    return ops.pack_conv_weight(w64)
 
 
 class ModifiedResNet(nn.Module):
@@ -146,17 +146,17 @@ class ModifiedResNet(nn.Module):
         P["stem1"] = (w.permute(2, 3, 1, 0).contiguous().float(), b.float().contiguous())   # [kh][kw][cin][cout]
         for i in (2, 3):
             w, b = _fold_bn(getattr(self, f"conv{i}").weight, getattr(self, f"bn{i}"))
-            P[f"stem{i}"] = (_pack_conv(w), b.float().contiguous())
+            P[f"stem{i}"] = _pack_conv(w) + (b.float().contiguous(),)
         blocks = []
         for li in (1, 2, 3, 4):
             for blk in getattr(self, f"layer{li}"):
                 e = {"stride": blk.stride}
                 for i in (1, 2, 3):
                     w, b = _fold_bn(getattr(blk, f"conv{i}").weight, getattr(blk, f"bn{i}"))
-                    e[f"c{i}"] = (_pack_conv(w), b.float().contiguous())
+                    e[f"c{i}"] = _pack_conv(w) + (b.float().contiguous(),)
                 if blk.downsample is not None:
                     w, b = _fold_bn(getattr(blk.downsample, "0").weight, getattr(blk.downsample, "1"))
-                    e["ds"] = (_pack_conv(w), b.float().contiguous())
+                    e["ds"] = _pack_conv(w) + (b.float().contiguous(),)
                 blocks.append(e)
         P["blocks"] = blocks
         ap = self.attnpool
@@ -174,25 +174,25 @@ class ModifiedResNet(nn.Module):
         P = self._plan or self._compile()
         x = x.float().contiguous()                      # NCHW image at the boundary
         x = ops.conv_stem_s2(x, *P["stem1"])            # -> NHWC from here on
-        x = ops.conv_bn_act(x, P["stem2"][0], P["stem2"][1], None, 3, 3, 1, 1, ops.ACT_RELU)
-        x = ops.conv_bn_act(x, P["stem3"][0], P["stem3"][1], None, 3, 3, 1, 1, ops.ACT_RELU)
+        x = ops.conv_bn_act(x, P["stem2"][0], P["stem2"][2], None, 3, 3, 1, 1, ops.ACT_RELU, P["stem2"][1])
+        x = ops.conv_bn_act(x, P["stem3"][0], P["stem3"][2], None, 3, 3, 1, 1, ops.ACT_RELU, P["stem3"][1])
         x = ops.avgpool2d(x, 2)
         stages = {"stem": x}
         bi = 0
         for li in (1, 2, 3, 4):
             for _ in getattr(self, f"layer{li}"):
                 e = P["blocks"][bi]; bi += 1
-                out = ops.conv_bn_act(x, e["c1"][0], e["c1"][1], None, 1, 1, 1, 0, ops.ACT_RELU)
-                out = ops.conv_bn_act(out, e["c2"][0], e["c2"][1], None, 3, 3, 1, 1, ops.ACT_RELU)
+                out = ops.conv_bn_act(x, e["c1"][0], e["c1"][2], None, 1, 1, 1, 0, ops.ACT_RELU, e["c1"][1])
+                out = ops.conv_bn_act(out, e["c2"][0], e["c2"][2], None, 3, 3, 1, 1, ops.ACT_RELU, e["c2"][1])
                 if e["stride"] > 1:
                     out = ops.avgpool2d(out, e["stride"])
                 identity = x
                 if "ds" in e:
                     if e["stride"] > 1:
                         identity = ops.avgpool2d(x, e["stride"])
-                    identity = ops.conv_bn_act(identity, e["ds"][0], e["ds"][1], None, 1, 1, 1, 0, ops.ACT_NONE)
+                    identity = ops.conv_bn_act(identity, e["ds"][0], e["ds"][2], None, 1, 1, 1, 0, ops.ACT_NONE, e["ds"][1])
                 # conv3 + bn3, residual add and the final ReLU fused into one epilogue
-                x = ops.conv_bn_act(out, e["c3"][0], e["c3"][1], identity, 1, 1, 1, 0, ops.ACT_RELU)
+                x = ops.conv_bn_act(out, e["c3"][0], e["c3"][2], identity, 1, 1, 1, 0, ops.ACT_RELU, e["c3"][1])
             stages[f"layer{li}"] = x
         a = P["attn"]
         out = ops.attnpool(x, a["pos"], a["wq"], a["bq"], a["wkv"], a["bkv"], a["wc"], a["bc"], self.attnpool.num_heads)

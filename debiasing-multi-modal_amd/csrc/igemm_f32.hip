@@ -51,6 +51,7 @@ struct IgemmP {
     long long lda, ldw, ldr, ldc;
     int M, N, K;
     int H, W, Cin, Ho, Wo, KH, KW, stride, pad;  // AMODE 1 only
+    int wl;                             // AMODE 1: K order of the packed weights (DBMM_WL_*)
     int act;
     float alpha;
     int tiles_n, n_tiles;
@@ -187,9 +188,15 @@ __device__ __forceinline__ void igemm_tile(const IgemmP& p, float* lds, int tile
                 fa_mask[i] = rv ? msk : 0u;
             }
         }
-        if constexpr (AMODE == 1) {   // position of chunk kb along (kh, kw, cin)
-            const int k = kb * BK;
-            f_tap = k / p.Cin; f_ci0 = k - f_tap * p.Cin;
+        if constexpr (AMODE == 1) {   // position of chunk kb along K
+            if (p.wl == DBMM_WL_CHUNK_MAJOR) {       // K = (cin/16, kh, kw, 16): taps cycle fastest
+                const int taps = p.KH * p.KW, cpc = 16 / BK > 0 ? 16 / BK : 1;   // chunks per (16-ch, tap) cell
+                const int cell = kb / cpc;
+                f_tap = cell % taps; f_ci0 = (cell / taps) * 16 + (kb % cpc) * BK;
+            } else {                                  // K = (kh, kw, cin)
+                const int k = kb * BK;
+                f_tap = k / p.Cin; f_ci0 = k - f_tap * p.Cin;
+            }
             f_kh = f_tap / p.KW; f_kw = f_tap - f_kh * p.KW;
         }
     }
@@ -207,10 +214,21 @@ __device__ __forceinline__ void igemm_tile(const IgemmP& p, float* lds, int tile
 #pragma unroll
             for (int i = 0; i < ALD; ++i)
                 a_reg[i] = buf_load16(rsA, (fa_mask[i] & bit) ? fa_off[i] + delta : OOR, 0u);
-            f_ci0 += BK;
-            if (f_ci0 == p.Cin) {
-                f_ci0 = 0; ++f_tap;
-                if (++f_kw == p.KW) { f_kw = 0; ++f_kh; }
+            if (p.wl == DBMM_WL_CHUNK_MAJOR) {
+                // the KH*KW taps of one 16-channel slab are consecutive K chunks: the 9 re-reads of
+                // an input pixel happen back to back and are served by L1/L2 instead of the fabric
+                f_ci0 += BK;
+                if ((f_ci0 & 15) == 0) {
+                    f_ci0 -= 16; ++f_tap;
+                    if (++f_kw == p.KW) { f_kw = 0; ++f_kh; }
+                    if (f_tap == p.KH * p.KW) { f_tap = 0; f_kh = 0; f_kw = 0; f_ci0 += 16; }
+                }
+            } else {
+                f_ci0 += BK;
+                if (f_ci0 == p.Cin) {
+                    f_ci0 = 0; ++f_tap;
+                    if (++f_kw == p.KW) { f_kw = 0; ++f_kh; }
+                }
             }
         } else if constexpr (AMODE == 0) {
             const int k = k0 + lc * 4;
@@ -221,7 +239,13 @@ __device__ __forceinline__ void igemm_tile(const IgemmP& p, float* lds, int tile
             }
         } else if constexpr (AMODE == 1) {
             const int k = k0 + lc * 4;
-            const int tap = k / p.Cin, ci = k - tap * p.Cin;
+            int tap, ci;
+            if (p.wl == DBMM_WL_CHUNK_MAJOR) {
+                const int cell = k >> 4, taps = p.KH * p.KW;
+                tap = cell % taps; ci = (cell / taps) * 16 + (k & 15);
+            } else {
+                tap = k / p.Cin; ci = k - tap * p.Cin;
+            }
             const int kh = tap / p.KW, kw = tap - kh * p.KW;
             const bool kin = k < p.K;
 #pragma unroll
@@ -493,6 +517,7 @@ bool fast_ok(const IgemmP& p) {
     static const int allow = [] { const char* e = getenv("DBMM_IGEMM_FAST"); return e ? atoi(e) : 1; }();
     if (!allow || AMODE == 2 || WMODE != 0 || (p.K % BK) != 0) return false;
     if (AMODE == 1 && ((p.Cin % BK) != 0 || p.KH * p.KW > 32)) return false;
+    if (AMODE == 1 && p.wl == DBMM_WL_CHUNK_MAJOR && BK > 16) return false;   // one tap per chunk needed
     return p.a_bytes != 0 && p.w_bytes != 0;
 }
 
@@ -601,7 +626,9 @@ int gemm_impl(const float* a, int64_t lda, int trans_a, const float* w, int64_t 
 
 int conv_impl(const float* x, const float* w, const float* bias, const float* residual, float* y, int64_t B, int64_t H,
               int64_t W, int64_t Cin, int64_t Cout, int64_t KH, int64_t KW, int64_t stride, int64_t pad, int act,
-              void* ws, size_t wsb, void* stream) {
+              int w_layout, void* ws, size_t wsb, void* stream) {
+    if (w_layout != DBMM_WL_TAP_MAJOR && w_layout != DBMM_WL_CHUNK_MAJOR) return DBMM_E_ARG;
+    if (w_layout == DBMM_WL_CHUNK_MAJOR && (Cin & 15)) return DBMM_E_SHAPE;
     if (!x || !w || !y) return DBMM_E_ARG;
     if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || KH <= 0 || KW <= 0 || stride <= 0 || pad < 0)
         return DBMM_E_SHAPE;
@@ -617,7 +644,7 @@ int conv_impl(const float* x, const float* w, const float* bias, const float* re
     p.lda = Cin; p.ldw = K; p.ldr = Cout; p.ldc = Cout;
     p.M = (int)M; p.N = (int)Cout; p.K = (int)K; p.act = act; p.alpha = 1.f;
     p.H = (int)H; p.W = (int)W; p.Cin = (int)Cin; p.Ho = (int)Ho; p.Wo = (int)Wo;
-    p.KH = (int)KH; p.KW = (int)KW; p.stride = (int)stride; p.pad = (int)pad;
+    p.KH = (int)KH; p.KW = (int)KW; p.stride = (int)stride; p.pad = (int)pad; p.wl = w_layout;
     set_extents(p, B * H * W * Cin * 4, Cout * K * 4);
     hipStream_t s = (hipStream_t)stream;
     if (KH == 1 && KW == 1 && stride == 1 && pad == 0) return launch_modes<0, 0>(p, s, 1, ws, wsb);  // plain GEMM
@@ -676,15 +703,16 @@ extern "C" int dbmm_gemm_batched(const float* a, int64_t lda, int64_t stride_a, 
 extern "C" int dbmm_conv_bn_act(const float* x, const float* w, const float* bias, const float* residual,
                                 float* y, int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t Cout,
                                 int64_t KH, int64_t KW, int64_t stride, int64_t pad, int act, void* stream) {
-    return conv_impl(x, w, bias, residual, y, B, H, W, Cin, Cout, KH, KW, stride, pad, act, nullptr, 0, stream);
+    return conv_impl(x, w, bias, residual, y, B, H, W, Cin, Cout, KH, KW, stride, pad, act, DBMM_WL_TAP_MAJOR, nullptr, 0,
+                     stream);
 }
 
 extern "C" int dbmm_conv_bn_act_ws(const float* x, const float* w, const float* bias, const float* residual,
                                    float* y, int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int64_t KH,
-                                   int64_t KW, int64_t stride, int64_t pad, int act, void* workspace,
+                                   int64_t KW, int64_t stride, int64_t pad, int act, int w_layout, void* workspace,
                                    size_t workspace_bytes, void* stream) {
-    return conv_impl(x, w, bias, residual, y, B, H, W, Cin, Cout, KH, KW, stride, pad, act, workspace, workspace_bytes,
-                     stream);
+    return conv_impl(x, w, bias, residual, y, B, H, W, Cin, Cout, KH, KW, stride, pad, act, w_layout, workspace,
+                     workspace_bytes, stream);
 }
 
 extern "C" int dbmm_conv1x1_bn_act(const float* x, const float* w, const float* bias, const float* residual,

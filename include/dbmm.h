@@ -35,6 +35,12 @@ extern "C" {
 #define DBMM_E_WORKSPACE (-3) /* workspace too small                              */
 #define DBMM_E_ARG (-4)       /* null pointer / bad enum                          */
 
+/* K order of a packed conv weight [Cout][K], K = KH*KW*Cin */
+#define DBMM_WL_TAP_MAJOR 0   /* (kh, kw, cin)                                              */
+#define DBMM_WL_CHUNK_MAJOR 1 /* (cin/16, kh, kw, 16): needs Cin % 16 == 0; the taps of one
+                                 16-channel slab are adjacent along K, so the KH*KW re-reads
+                                 of an input pixel hit L1/L2 instead of HBM                  */
+
 #define DBMM_ACT_NONE 0
 #define DBMM_ACT_RELU 1
 #define DBMM_ACT_QUICKGELU 2 /* x * sigmoid(1.702 x), clip/model.py:166-168 */
@@ -78,7 +84,7 @@ int dbmm_gemm_bias_act(const float* a, int64_t lda, int trans_a, const float* w,
 size_t dbmm_workspace_bytes_igemm(void);
 int dbmm_conv_bn_act_ws(const float* x, const float* w, const float* bias, const float* residual,
                         float* y, int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t Cout,
-                        int64_t KH, int64_t KW, int64_t stride, int64_t pad, int act,
+                        int64_t KH, int64_t KW, int64_t stride, int64_t pad, int act, int w_layout,
                         void* workspace, size_t workspace_bytes, void* stream);
 int dbmm_gemm_bias_act_ws(const float* a, int64_t lda, int trans_a, const float* w, int64_t ldw,
                           int trans_w, const float* bias, const float* residual, int64_t ldr,

@@ -89,6 +89,19 @@ def test_conv_bn_act(B, H, W, Cin, Cout, k, stride, pad):
     assert relerr(out.cpu(), ref) < 2e-5
 
 
+@pytest.mark.parametrize("B,H,Cin,Cout", [(2, 16, 32, 32), (3, 14, 64, 128), (2, 9, 16, 48), (5, 7, 512, 256)])
+def test_conv_chunk_major_weights(B, H, Cin, Cout):
+    """packed K order (cin/16, kh, kw, 16): same convolution, taps adjacent along K."""
+    x = rnd(1, "x", (B, Cin, H, H)); w = rnd(2, "w", (Cout, Cin, 3, 3), (Cin * 9) ** -0.5); b = rnd(3, "b", (Cout,), 0.1)
+    ref = F.relu(F.conv2d(x, w, b, padding=1)).permute(0, 2, 3, 1)
+    wp, wl = ops.pack_conv_weight(w.to(DEV), chunk_major=True)
+    assert wl == ops.WL_CHUNK_MAJOR
+    out = ops.conv_bn_act(x.permute(0, 2, 3, 1).contiguous().to(DEV), wp, b.to(DEV), None, 3, 3, 1, 1, ops.ACT_RELU, wl)
+    assert relerr(out.cpu(), ref) < 2e-5
+    wp0, wl0 = ops.pack_conv_weight(rnd(4, "w8", (Cout, 8, 3, 3)).to(DEV), chunk_major=True)   # Cin % 16 != 0 -> tap-major
+    assert wl0 == ops.WL_TAP_MAJOR and wp0.shape == (Cout, 72)
+
+
 @pytest.mark.parametrize("B,R,Cout", [(2, 64, 32), (3, 33, 16), (1, 224, 32)])
 def test_conv_stem_s2(B, R, Cout):
     x = rnd(1, "x", (B, 3, R, R)); w = rnd(2, "w", (Cout, 3, 3, 3), 27 ** -0.5); b = rnd(3, "b", (Cout,), 0.1)
