@@ -166,6 +166,13 @@ def main():
         raise SystemExit("non-finite loss in the timed region")
 
     if rank == 0:
+        traffic = None          # HBM-side bytes per launch of the dominant kernel from the committed PMC passes
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+            if Bl == 512 and args.arch == "RN50":
+                traffic = round(tj["kernels"][DOMINANT]["hbm_bytes_per_launch"])
+        except (OSError, KeyError, ValueError):
+            pass
         value = B * args.steps / dt
         n, fl, ms = prof.get(DOMINANT, (0, 0.0, 0.0))
         ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
@@ -181,7 +188,7 @@ def main():
                        "collective": "all_gather(embeddings+labels) per step" if world > 1 else "none"},
             "roofline": {"bound": "mfma", "kernel": DOMINANT, "achieved": round(ach, 2),
                          "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                         "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                          "launches": n, "avg_launch_ms": round(ms / n, 4) if n else None,
                          "flops_per_launch_avg": fl / n if n else None,
                          "all_mfma_kernels": {"achieved": round(all_fl / (all_ms * 1e-3) / 1e12, 2) if all_ms else 0.0,

@@ -29,6 +29,11 @@
 // loss.)  FAST = 0 is the general fallback (K tails, K-major operands, Cin % BK != 0,
 // operands >= 2 GiB).
 //
+// DMA = 1 (default with FAST): the same buffer loads write LDS directly (`buffer_load ... lds`):
+// no staging VGPRs, no ds_write pass.  The LDS-DMA destination is wave-uniform base + lane*16 B,
+// so the swizzle moves to the per-lane SOURCE chunk (lane l of a row loads chunk lc ^ swz(row)
+// and lands on physical chunk lc), the rule-21 "linear dest + swizzled source + swizzled read".
+//
 // Work distribution: one tile per workgroup, or -- when the tile count does not divide over
 // the 256 CUs (e.g. 784 tiles: every CU waits for the 16 that got a 4th tile) -- stream-K:
 // a resident grid of 256 x MINB workgroups each takes an equal contiguous share of all
@@ -68,6 +73,16 @@ __device__ __forceinline__ f32x4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned v
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
 }
 
+// LDS-DMA: 16 B per lane from a buffer straight into LDS at (wave-uniform dst) + 16 * lane.
+// (The builtin only exists in the device pass, hence the guard; the host pass never calls it.)
+__device__ __forceinline__ void buf_load16_lds(__amdgpu_buffer_rsrc_t r, float* lds_dst, unsigned voff, unsigned soff) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_dst, 16, voff, soff, 0, 0);
+#else
+    (void)r; (void)lds_dst; (void)voff; (void)soff;
+#endif
+}
+
 // LDS rows hold BK floats; the 16-B chunk index is XOR-swizzled with row bits so that the 16
 // lanes of a ds_read_b128 group (16 x 16 B = all 64 banks) never collide:
 //   BK = 32 (128-B rows, 2 rows per bank sweep): chunk ^= (row >> 1) & 7
@@ -105,7 +120,7 @@ struct Geo {
 // lanes, and all residual loads of a half tile are in flight together.  (The per-element path
 // below it was latency-bound at ~1 TB/s on the conv3 + residual layers.)
 // ---------------------------------------------------------------------------------------------
-template <int BM, int BN, int WAVES_M, int WAVES_N, int AMODE, int WMODE, int BK, int FAST, int FIXUP>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int AMODE, int WMODE, int BK, int FAST, int FIXUP, int DMA>
 __device__ __forceinline__ void igemm_tile(const IgemmP& p, float* lds, int tile, int kb, int ke, float* partial,
                                            int fix_c0) {
     using G = Geo<BM, BN, WAVES_M, WAVES_N, BK>;
@@ -163,14 +178,16 @@ __device__ __forceinline__ void igemm_tile(const IgemmP& p, float* lds, int tile
 #pragma unroll
         for (int i = 0; i < WLD; ++i) {
             const int n = n0 + lr + RPP * i;
-            fw_off[i] = (lr + RPP * i < BN && n < p.N) ? (unsigned)n * (unsigned)p.ldw * 4u + lc * 16u : OOR;
+            const unsigned cw = DMA ? (unsigned)(lc ^ lds_swz<BK>(lr + RPP * i)) : (unsigned)lc;   // source chunk
+            fw_off[i] = (lr + RPP * i < BN && n < p.N) ? (unsigned)n * (unsigned)p.ldw * 4u + cw * 16u : OOR;
         }
 #pragma unroll
         for (int i = 0; i < ALD; ++i) {
             const int m = m0 + lr + RPP * i;
             const bool rv = (lr + RPP * i < BM) && (m < p.M);
+            const unsigned ca = DMA ? (unsigned)(lc ^ lds_swz<BK>(lr + RPP * i)) : (unsigned)lc;   // source chunk
             if constexpr (AMODE == 0) {
-                fa_off[i] = rv ? (unsigned)m * (unsigned)p.lda * 4u + lc * 16u : OOR;
+                fa_off[i] = rv ? (unsigned)m * (unsigned)p.lda * 4u + ca * 16u : OOR;
                 fa_mask[i] = 0;
             } else {
                 const int hw = p.Ho * p.Wo;
@@ -179,7 +196,7 @@ __device__ __forceinline__ void igemm_tile(const IgemmP& p, float* lds, int tile
                 const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
                 // modular 32-bit arithmetic: the halo start may lie "before" the tensor, the tap
                 // offset added per load brings every valid tap back into range
-                fa_off[i] = ((unsigned)(n * p.H + hi0) * (unsigned)p.W + (unsigned)wi0) * (unsigned)p.Cin * 4u + lc * 16u;
+                fa_off[i] = ((unsigned)(n * p.H + hi0) * (unsigned)p.W + (unsigned)wi0) * (unsigned)p.Cin * 4u + ca * 16u;
                 unsigned msk = 0;
                 for (int kh = 0; kh < p.KH; ++kh)
                     for (int kw = 0; kw < p.KW; ++kw)
@@ -202,6 +219,50 @@ __device__ __forceinline__ void igemm_tile(const IgemmP& p, float* lds, int tile
     }
 
     f32x4 a_reg[ALD], w_reg[WLD];
+
+    // LDS-DMA: chunk k0 -> staging buffer `buf`; lane l of a wave lands on base + 16*l, i.e. on
+    // row (wave's first row) + l / CPR, physical chunk l % CPR
+    const int wrow0 = (tid & ~63) / CPR;          // wave-uniform first row of this wave's pass
+    auto dma_chunk = [&](int k0, int buf) {
+        if constexpr (FAST && DMA) {
+            float* Ab = As + buf * BM * BK;
+            float* Wb = Ws + buf * BN * BK;
+            unsigned delta = 0, bit = 0;
+            if constexpr (AMODE == 1) {
+                delta = ((unsigned)(f_kh * p.W + f_kw) * (unsigned)p.Cin + (unsigned)f_ci0) * 4u;
+                bit = 1u << f_tap;
+            }
+#pragma unroll
+            for (int i = 0; i < ALD; ++i) {
+                if (wrow0 + RPP * i < BM) {           // wave-uniform
+                    unsigned voff, soff;
+                    if constexpr (AMODE == 0) { voff = fa_off[i]; soff = (unsigned)k0 * 4u; }
+                    else { voff = (fa_mask[i] & bit) ? fa_off[i] + delta : OOR; soff = 0u; }
+                    buf_load16_lds(rsA, Ab + (wrow0 + RPP * i) * BK, voff, soff);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < WLD; ++i)
+                if (wrow0 + RPP * i < BN)
+                    buf_load16_lds(rsW, Wb + (wrow0 + RPP * i) * BK, fw_off[i], (unsigned)k0 * 4u);
+            if constexpr (AMODE == 1) {
+                if (p.wl == DBMM_WL_CHUNK_MAJOR) {
+                    f_ci0 += BK;
+                    if ((f_ci0 & 15) == 0) {
+                        f_ci0 -= 16; ++f_tap;
+                        if (++f_kw == p.KW) { f_kw = 0; ++f_kh; }
+                        if (f_tap == p.KH * p.KW) { f_tap = 0; f_kh = 0; f_kw = 0; f_ci0 += 16; }
+                    }
+                } else {
+                    f_ci0 += BK;
+                    if (f_ci0 == p.Cin) {
+                        f_ci0 = 0; ++f_tap;
+                        if (++f_kw == p.KW) { f_kw = 0; ++f_kh; }
+                    }
+                }
+            }
+        }
+    };
 
     auto load_a = [&](int k0) {
         if constexpr (FAST && AMODE == 0) {
@@ -350,14 +411,21 @@ __device__ __forceinline__ void igemm_tile(const IgemmP& p, float* lds, int tile
         }
     } else {
     __syncthreads();                      // a previous tile of this workgroup may still use the LDS
-    load_a(kb * BK); load_w(kb * BK);
-    store_lds(0);
+    if constexpr (FAST && DMA) {
+        dma_chunk(kb * BK, 0);
+    } else {
+        load_a(kb * BK); load_w(kb * BK);
+        store_lds(0);
+    }
     __syncthreads();
     }
 
     for (int kc = kb; !FIXUP && kc < ke; ++kc) {
         const int buf = (kc - kb) & 1;
-        if (kc + 1 < ke) { load_a((kc + 1) * BK); load_w((kc + 1) * BK); }
+        if (kc + 1 < ke) {
+            if constexpr (FAST && DMA) dma_chunk((kc + 1) * BK, buf ^ 1);
+            else { load_a((kc + 1) * BK); load_w((kc + 1) * BK); }
+        }
         const float* Ab = As + buf * BM * BK;
         const float* Wb = Ws + buf * BN * BK;
 #pragma unroll
@@ -376,7 +444,9 @@ __device__ __forceinline__ void igemm_tile(const IgemmP& p, float* lds, int tile
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], wf[j][s], acc[i][j], 0, 0, 0);
         }
-        if (kc + 1 < ke) store_lds(buf ^ 1);
+        if constexpr (!(FAST && DMA)) {
+            if (kc + 1 < ke) store_lds(buf ^ 1);
+        }
         __syncthreads();
     }
 
@@ -459,7 +529,7 @@ __device__ __forceinline__ void igemm_tile(const IgemmP& p, float* lds, int tile
 
 // MINB = resident workgroups per CU the register allocator must leave room for (hipcc sizes
 // its VGPR budget from a 64-KB LDS model otherwise and drops the 128x128 tile to 1 block/CU).
-template <int BM, int BN, int WAVES_M, int WAVES_N, int AMODE, int WMODE, int BK, int MINB, int FAST, int SK>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int AMODE, int WMODE, int BK, int MINB, int FAST, int SK, int DMA>
 __global__ __launch_bounds__(256, MINB) void igemm_f32_kernel(const IgemmP p_in) {
     static_assert(WAVES_M * WAVES_N == 4, "4 waves");
     using G = Geo<BM, BN, WAVES_M, WAVES_N, BK>;
@@ -473,7 +543,7 @@ __global__ __launch_bounds__(256, MINB) void igemm_f32_kernel(const IgemmP p_in)
     }
     const int nk = (p.K + BK - 1) / BK;
     if constexpr (!SK) {
-        igemm_tile<BM, BN, WAVES_M, WAVES_N, AMODE, WMODE, BK, FAST, 0>(p, lds, xcd_remap(blockIdx.x, p.n_tiles), 0,
+        igemm_tile<BM, BN, WAVES_M, WAVES_N, AMODE, WMODE, BK, FAST, 0, DMA>(p, lds, xcd_remap(blockIdx.x, p.n_tiles), 0,
                                                                         nk, nullptr, 0);
     } else {
         // stream-K: this workgroup's contiguous share [u, u1) of the n_tiles * nk (tile, chunk) units
@@ -486,7 +556,7 @@ __global__ __launch_bounds__(256, MINB) void igemm_f32_kernel(const IgemmP p_in)
             float* partial = (kb == 0 && ke == nk)
                                  ? nullptr
                                  : p.sk_ws + ((size_t)blockIdx.x * 2 + (seg ? 1 : 0)) * (size_t)(BM * BN);
-            igemm_tile<BM, BN, WAVES_M, WAVES_N, AMODE, WMODE, BK, FAST, 0>(p, lds, tile, kb, ke, partial, 0);
+            igemm_tile<BM, BN, WAVES_M, WAVES_N, AMODE, WMODE, BK, FAST, 0, DMA>(p, lds, tile, kb, ke, partial, 0);
             u += ke - kb;
         }
     }
@@ -508,7 +578,7 @@ __global__ __launch_bounds__(256) void igemm_fixup_kernel(const IgemmP p) {
     const long long t = b / nk;
     const long long bp = U * (g - 1) / nb;
     if (bp % nk != 0 && bp / nk == t) return;                 // an earlier boundary owns this tile
-    igemm_tile<BM, BN, WAVES_M, WAVES_N, 0, 0, BK, 0, 1>(p, lds, (int)t, 0, 0, nullptr, g - 1);
+    igemm_tile<BM, BN, WAVES_M, WAVES_N, 0, 0, BK, 0, 1, 0>(p, lds, (int)t, 0, 0, nullptr, g - 1);
 }
 
 // FAST loader eligibility (see the header comment); `DBMM_IGEMM_FAST=0` forces the fallback.
@@ -546,18 +616,26 @@ int launch_cfg(IgemmP& p, hipStream_t s, int nbatch, void* ws, size_t ws_bytes) 
     bool launched = false;
     if constexpr (AMODE != 2 && WMODE == 0) {
         if (fast_ok<AMODE, WMODE, BK>(p)) {
-            if (p.sk_blocks)
-                hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN, AMODE, WMODE, BK, MINB, 1, 1>), grid, dim3(256), 0, s, p);
-            else
-                hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN, AMODE, WMODE, BK, MINB, 1, 0>), grid, dim3(256), 0, s, p);
+            static const int dma = [] { const char* e = getenv("DBMM_IGEMM_DMA"); return e ? atoi(e) : 1; }();
+            if (dma) {
+                if (p.sk_blocks)
+                    hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN, AMODE, WMODE, BK, MINB, 1, 1, 1>), grid, dim3(256), 0, s, p);
+                else
+                    hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN, AMODE, WMODE, BK, MINB, 1, 0, 1>), grid, dim3(256), 0, s, p);
+            } else {
+                if (p.sk_blocks)
+                    hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN, AMODE, WMODE, BK, MINB, 1, 1, 0>), grid, dim3(256), 0, s, p);
+                else
+                    hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN, AMODE, WMODE, BK, MINB, 1, 0, 0>), grid, dim3(256), 0, s, p);
+            }
             launched = true;
         }
     }
     if (!launched) {
         if (p.sk_blocks)
-            hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN, AMODE, WMODE, BK, MINB, 0, 1>), grid, dim3(256), 0, s, p);
+            hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN, AMODE, WMODE, BK, MINB, 0, 1, 0>), grid, dim3(256), 0, s, p);
         else
-            hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN, AMODE, WMODE, BK, MINB, 0, 0>), grid, dim3(256), 0, s, p);
+            hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN, AMODE, WMODE, BK, MINB, 0, 0, 0>), grid, dim3(256), 0, s, p);
     }
     DBMM_CHECK_LAUNCH();
     if (p.sk_blocks) {
