@@ -37,7 +37,7 @@ from dbmm_amd.clip.model import build_model  # noqa: E402
 
 FP32_MFMA_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md, chip table
 RN50_GFLOP_PER_IMG = 11.59             # SURVEY.md section 8d (conv 5.367 + attn-pool 0.426 GMAC)
-DOMINANT = "igemm_f32_kernel<128,128,2,2,1,0,16>"
+DOMINANT = "igemm_f32_kernel<128, 128, 2, 2, 1, 0, 16, 4, 1, 0, 1>"   # 3x3 implicit-GEMM conv, one tile per workgroup
 
 
 def write_text_jsons(D):

@@ -60,6 +60,7 @@ _SIGS = {
     "dbmm_conv3x3_bn_act": [_P, _P, _P, _P, _P, _L, _L, _L, _L, _L, _I, _P],
     "dbmm_gemm_bias_act": [_P, _L, _I, _P, _L, _I, _P, _P, _L, _P, _L, _L, _L, _L, _F, _I, _P],
     "dbmm_workspace_bytes_igemm": [],
+    "dbmm_debug_last_igemm": [_P],
     "dbmm_conv_bn_act_ws": [_P, _P, _P, _P, _P, _L, _L, _L, _L, _L, _L, _L, _L, _L, _I, _I, _P, _Z, _P],
     "dbmm_gemm_bias_act_ws": [_P, _L, _I, _P, _L, _I, _P, _P, _L, _P, _L, _L, _L, _L, _F, _I, _P, _Z, _P],
     "dbmm_gemm_batched": [_P, _L, _L, _I, _P, _L, _L, _I, _P, _L, _P, _L, _L, _L, _L, _L, _L, _F, _I, _P],
@@ -89,6 +90,7 @@ _RESTYPES = {
     "dbmm_error_string": ctypes.c_char_p,
     "dbmm_workspace_bytes_attnpool": c_size_t,
     "dbmm_workspace_bytes_igemm": c_size_t,
+    "dbmm_debug_last_igemm": None,
     "dbmm_workspace_bytes_adapter_bwd": c_size_t,
 }
 

@@ -593,6 +593,10 @@ bool fast_ok(const IgemmP& p) {
 
 constexpr int NUM_CUS = 256;
 
+// template arguments of this thread's most recent igemm launch (profiling aid: lets bench.py
+// name the exact instantiation rocprofv3 reports); not used by any compute path
+thread_local int g_last_cfg[11] = {0};
+
 template <int BM, int BN, int WM, int WN, int AMODE, int WMODE, int BK, int MINB>
 int launch_cfg(IgemmP& p, hipStream_t s, int nbatch, void* ws, size_t ws_bytes) {
     const int tiles_m = (p.M + BM - 1) / BM;
@@ -614,9 +618,14 @@ int launch_cfg(IgemmP& p, hipStream_t s, int nbatch, void* ws, size_t ws_bytes) 
     }
     const dim3 grid(p.sk_blocks ? p.sk_blocks : p.n_tiles, nbatch);
     bool launched = false;
+    {
+        const int c[11] = {BM, BN, WM, WN, AMODE, WMODE, BK, MINB, 0, p.sk_blocks ? 1 : 0, 0};
+        for (int i = 0; i < 11; ++i) g_last_cfg[i] = c[i];
+    }
     if constexpr (AMODE != 2 && WMODE == 0) {
         if (fast_ok<AMODE, WMODE, BK>(p)) {
             static const int dma = [] { const char* e = getenv("DBMM_IGEMM_DMA"); return e ? atoi(e) : 1; }();
+            g_last_cfg[8] = 1; g_last_cfg[10] = dma ? 1 : 0;
             if (dma) {
                 if (p.sk_blocks)
                     hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN, AMODE, WMODE, BK, MINB, 1, 1, 1>), grid, dim3(256), 0, s, p);
@@ -730,6 +739,10 @@ int conv_impl(const float* x, const float* w, const float* bias, const float* re
 }
 
 }  // namespace
+
+extern "C" void dbmm_debug_last_igemm(int* out11) {
+    for (int i = 0; i < 11; ++i) out11[i] = g_last_cfg[i];
+}
 
 extern "C" size_t dbmm_workspace_bytes_igemm(void) {
     // stream-K partial accumulators: (256 CUs x 6 resident workgroups) x 2 slots x 128x128 fp32

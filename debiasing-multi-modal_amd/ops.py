@@ -33,19 +33,11 @@ def profile_end():
     return out
 
 
-def _igemm_tag(M, N, amode, wmode):
-    """name of the template instantiation dbmm_gemm_bias_act / dbmm_conv_bn_act will pick
-    (mirrors launch_modes() in csrc/igemm_f32.hip)."""
-    t128 = ((M + 127) // 128) * ((N + 127) // 128)
-    if N <= 32:
-        tile, bk = "128,32,4,1", 16
-    elif N <= 64:
-        tile, bk = "128,64,2,2", 16
-    elif t128 < 192:
-        tile, bk = "64,64,2,2", 16
-    else:
-        tile, bk = "128,128,2,2", 16
-    return f"igemm_f32_kernel<{tile},{amode},{wmode},{bk}>"
+def _last_igemm_tag():
+    """exact instantiation of the igemm launch just issued, spelled like rocprofv3's kernel name"""
+    cfg = (ctypes.c_int * 11)()
+    _lib.lib().dbmm_debug_last_igemm(cfg)
+    return "igemm_f32_kernel<" + ", ".join(str(v) for v in cfg) + ">"
 
 
 class _Timed:
@@ -62,7 +54,7 @@ class _Timed:
             M, N, K, amode, wmode = self.args
             e1 = torch.cuda.Event(enable_timing=True)
             e1.record()
-            _prof.append((_igemm_tag(M, N, amode, wmode), 2.0 * M * N * K, self.e0, e1))
+            _prof.append((_last_igemm_tag(), 2.0 * M * N * K, self.e0, e1))
 
 
 _ws_cache = {}

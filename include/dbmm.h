@@ -91,6 +91,10 @@ int dbmm_gemm_bias_act_ws(const float* a, int64_t lda, int trans_a, const float*
                           float* c, int64_t ldc, int64_t M, int64_t N, int64_t K, float alpha,
                           int act, void* workspace, size_t workspace_bytes, void* stream);
 
+/* profiling aid: the 11 template arguments <BM,BN,WAVES_M,WAVES_N,AMODE,WMODE,BK,MINB,FAST,SK,DMA>
+ * of the calling thread's most recent igemm launch (= the kernel name rocprofv3 reports). */
+void dbmm_debug_last_igemm(int* out11);
+
 /* `batch` independent GEMMs of identical shape in one launch (grid.y): problem b uses
  * a + b*stride_a, w + b*stride_w, bias + b*stride_bias, c + b*stride_c (element strides,
  * multiples of 4).  Used for the per-head products of the collapsed attention pool. */
