@@ -83,6 +83,9 @@ _SIGS = {
     "dbmm_l2norm_sim_ce_fwd": [_P, _P, _F, _P, _P, _F, _P, _P, _P, _P, _P, _L, _L, _L, _P],
     "dbmm_l2norm_sim_ce_bwd": [_P, _P, _F, _I, _P, _P, _P, _P, _F, _F, _P, _L, _L, _L, _P],
     "dbmm_sgd_momentum": [_L, _P, _P, _P, _P, _F, _F, _F, _I, _P],
+    "dbmm_workspace_bytes_adapter_train_step": [_L, _L, _L, _I],
+    "dbmm_adapter_train_step": [_P] * 26 + [_F, _P, _F, _F, _F, _F, _I, _P, _P, _P, _L, _L, _L, _L, _P, _Z, _P],
+    "dbmm_gather_rows": [_P, _P, _P, _L, _L, _L, _P],
     "dbmm_group_count": [_P, _P, _P, _P, _L, _L, _L, _P],
     "dbmm_group_loss_sum": [_P, _P, _P, _L, _L, _P],
 }
@@ -92,6 +95,7 @@ _RESTYPES = {
     "dbmm_workspace_bytes_igemm": c_size_t,
     "dbmm_debug_last_igemm": None,
     "dbmm_workspace_bytes_adapter_bwd": c_size_t,
+    "dbmm_workspace_bytes_adapter_train_step": c_size_t,
 }
 
 EXPORTS = tuple(_SIGS)

@@ -237,6 +237,44 @@ class CustomCLIP(nn.Module):
         tn = self._text("group" if use_group else "class", features.device)
         return _SimCEFn.apply(z, z_old, tn, self.temperature, getattr(self, "ebd_weight", 0.5), labels)
 
+    def _step_adapters(self):
+        """(trainable adapter, frozen old adapter or None)"""
+        return self.adapter, None
+
+    def train_step(self, features, labels, optimizer, use_group=False):
+        """The whole step body of final_main.py:455-466 / :610-623 -- forward, mean CE, backward and
+        the SGD-momentum update -- as ONE C call (~20 launches back to back, no autograd graph, no
+        host round trip).  Uses the optimiser's lr / momentum / weight_decay and its
+        `momentum_buffer` state, so it can be mixed freely with `loss.backward(); optimizer.step()`.
+        Requires train mode.  Returns (mean CE, logits, per-row CE), all on the device."""
+        if not self.training:
+            raise RuntimeError("train_step needs classifier.train()")
+        new_ad, old_ad = self._step_adapters()
+
+        def pack(ad):
+            l0, bn, l3 = ad.layers[0], ad.layers[1], ad.layers[3]
+            return (l0.weight, l0.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked,
+                    l3.weight, l3.bias)
+        new = pack(new_ad)
+        trainable = [new[0], new[1], new[2], new[3], new[7], new[8]]
+        group = optimizer.param_groups[0]
+        owned = {id(p) for g in optimizer.param_groups for p in g["params"]}
+        if len(optimizer.param_groups) != 1 or any(id(p) not in owned for p in trainable):
+            raise RuntimeError("train_step: the optimiser must hold the adapter's six tensors in one param group")
+        first = any("momentum_buffer" not in optimizer.state[p] for p in trainable)
+        bufs = []
+        for p in trainable:
+            st = optimizer.state[p]
+            if "momentum_buffer" not in st or st["momentum_buffer"] is None:
+                st["momentum_buffer"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+            bufs.append(st["momentum_buffer"])
+        tn = self._text("group" if use_group else "class", features.device)
+        with torch.no_grad():
+            return ops.adapter_train_step(
+                features.detach().contiguous(), labels.contiguous(), [t.data for t in new], bufs,
+                [t.data for t in pack(old_ad)] if old_ad is not None else None, getattr(self, "ebd_weight", 0.5), tn,
+                self.temperature, group["lr"], group.get("momentum", 0.0), group.get("weight_decay", 0.0), first)
+
 
 class MultipleAdapter(CustomCLIP):
     """final_main.py:97-158.  Quirks kept: the old adapter also runs in
@@ -263,6 +301,9 @@ class MultipleAdapter(CustomCLIP):
         with torch.no_grad():
             z_old = self.old_cls.adapter(features)     # detached branch; BN stats still update in train mode
         return self.new_adapter(features), z_old
+
+    def _step_adapters(self):
+        return self.new_adapter, self.old_cls.adapter
 
 
 # ---------------------------------------------------------------------------------------

@@ -113,17 +113,22 @@ __global__ __launch_bounds__(256) void bn1d_bwd_apply_kernel(const float* __rest
     }
 }
 
-// out[j] = sum_b x[b][j]: 64 columns x 4 row-lanes per block, deterministic order
+// out[j] = sum_b x[b][j]: 16 columns (4 float4 lanes) x 64 row-lanes per block, fixed summation
+// order (row-lane partial sums, then an LDS tree) => deterministic.  N % 4 == 0.
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, int B, int N,
                                                      float* __restrict__ out) {
-    __shared__ float red[4][64];
-    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
-    const int j = blockIdx.x * 64 + cl;
-    float s = 0.f;
-    if (j < N) for (int b = rl; b < B; b += 4) s += x[(long long)b * N + j];
-    red[rl][cl] = s;
+    __shared__ f32x4 red[64][4];
+    const int cg = threadIdx.x & 3, rl = threadIdx.x >> 2;
+    const int j = blockIdx.x * 16 + cg * 4;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (j < N) for (int b = rl; b < B; b += 64) s += *(const f32x4*)(x + (long long)b * N + j);
+    red[rl][cg] = s;
     __syncthreads();
-    if (rl == 0 && j < N) out[j] = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+    for (int o = 32; o > 0; o >>= 1) {
+        if (rl < o) red[rl][cg] += red[rl + o][cg];
+        __syncthreads();
+    }
+    if (rl == 0 && j < N) *(f32x4*)(out + j) = red[0][cg];
 }
 
 // tn[c][:] = text[:, c] / ||text[:, c]||
@@ -317,6 +322,20 @@ __global__ __launch_bounds__(256) void group_loss_sum_kernel(const float* __rest
     }
 }
 
+// out[i][:] = table[idx[i]][:]  (float4 lanes; indices clamped into the table)
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ table,
+                                                          const long long* __restrict__ idx, float* __restrict__ out,
+                                                          int D4, long long n_rows, long long total) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long r = i / D4;
+        const int c = (int)(i - r * D4);
+        long long src = idx[r];
+        src = src < 0 ? 0 : (src >= n_rows ? n_rows - 1 : src);
+        ((f32x4*)out)[i] = ((const f32x4*)table)[src * D4 + c];
+    }
+}
+
 inline unsigned grid_for(long long total) {
     const long long blocks = (total + 255) / 256;
     return (unsigned)(blocks < 8192 ? (blocks > 0 ? blocks : 1) : 8192);
@@ -393,7 +412,7 @@ extern "C" int dbmm_adapter_bwd(const float* x, const float* dz, const float* h,
     // dW2[D][H] = dz^T r   (reduction over the batch: both operands K-major)
     rc = dbmm_gemm_bias_act(dz, D, 1, r, H, 1, nullptr, nullptr, 0, dw2, H, D, H, B, 1.f, DBMM_ACT_NONE, stream);
     if (rc) return rc;
-    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((D + 63) / 64)), dim3(256), 0, s, dz, (int)B, (int)D, db2);
+    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((D + 15) / 16)), dim3(256), 0, s, dz, (int)B, (int)D, db2);
     DBMM_CHECK_LAUNCH();
     // dr[B][H] = dz W2   (W2 is [D][H]: K-major weight operand)
     rc = dbmm_gemm_bias_act(dz, D, 0, w2, H, 1, nullptr, nullptr, 0, dr, H, B, H, D, 1.f, DBMM_ACT_NONE, stream);
@@ -408,7 +427,7 @@ extern "C" int dbmm_adapter_bwd(const float* x, const float* dz, const float* h,
     // dW1[H][D] = dh^T x
     rc = dbmm_gemm_bias_act(dh, H, 1, x, D, 1, nullptr, nullptr, 0, dw1, D, H, D, B, 1.f, DBMM_ACT_NONE, stream);
     if (rc) return rc;
-    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((H + 63) / 64)), dim3(256), 0, s, dh, (int)B, (int)H, db1);
+    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((H + 15) / 16)), dim3(256), 0, s, dh, (int)B, (int)H, db1);
     DBMM_CHECK_LAUNCH();
     return DBMM_OK;
 }
@@ -509,7 +528,98 @@ extern "C" int dbmm_group_loss_sum(const float* loss_rows, const int64_t* g, flo
     return DBMM_OK;
 }
 
-extern "C" int dbmm_version(void) { return 100; }
+extern "C" int dbmm_gather_rows(const float* table, const int64_t* idx, float* out, int64_t n_rows, int64_t n_idx,
+                                int64_t D, void* stream) {
+    if (!table || !idx || !out) return DBMM_E_ARG;
+    if (n_rows <= 0 || n_idx <= 0 || D <= 0 || (D & 3)) return DBMM_E_SHAPE;
+    if (!dbmm_aligned16(table) || !dbmm_aligned16(out)) return DBMM_E_ALIGN;
+    const long long total = (long long)n_idx * (D / 4);
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, table,
+                       (const long long*)idx, out, (int)(D / 4), (long long)n_rows, total);
+    DBMM_CHECK_LAUNCH();
+    return DBMM_OK;
+}
+
+// ---- one call = one training step body (final_main.py:455-466 / :610-623) ----------------------
+// workspace layout (floats): h, r [B*H]x2 | z [B*D] | mean, invstd [H]x2 | (old: h, r, z, mean, invstd)
+// | inv_norm [B] | dz [B*D] | dw1 [H*D] db1 dgamma dbeta [H]x3 dw2 [D*H] db2 [D] | bwd scratch [2*B*H]
+static size_t train_step_floats(int64_t B, int64_t D, int64_t H, int with_old) {
+    size_t n = 2 * B * H + B * D + 2 * H;
+    if (with_old) n += 2 * B * H + B * D + 2 * H;
+    n += B + B * D + (H * D + 3 * H + D * H + D) + 2 * B * H;
+    return (n + 3) / 4 * 4 + 64;
+}
+
+extern "C" size_t dbmm_workspace_bytes_adapter_train_step(int64_t B, int64_t D, int64_t H, int with_old) {
+    return train_step_floats(B, D, H, with_old) * sizeof(float);
+}
+
+extern "C" int dbmm_adapter_train_step(const float* x, const int64_t* labels, float* w1, float* b1, float* gamma,
+                                       float* beta, float* rmean, float* rvar, int64_t* nbt, float* w2, float* b2,
+                                       float* m_w1, float* m_b1, float* m_gamma, float* m_beta, float* m_w2,
+                                       float* m_b2, const float* o_w1, const float* o_b1, const float* o_gamma,
+                                       const float* o_beta, float* o_rmean, float* o_rvar, int64_t* o_nbt,
+                                       const float* o_w2, const float* o_b2, float ebd_weight, const float* tn,
+                                       float temperature, float lr, float momentum, float weight_decay,
+                                       int first_step, float* logits, float* loss_rows, float* loss_mean, int64_t B,
+                                       int64_t D, int64_t H, int64_t C, void* workspace, size_t workspace_bytes,
+                                       void* stream) {
+    if (!x || !labels || !w1 || !b1 || !gamma || !beta || !rmean || !rvar || !w2 || !b2 || !m_w1 || !m_b1 ||
+        !m_gamma || !m_beta || !m_w2 || !m_b2 || !tn || !logits || !loss_rows || !loss_mean || !workspace)
+        return DBMM_E_ARG;
+    const int with_old = o_w1 != nullptr;
+    if (with_old && (!o_b1 || !o_gamma || !o_beta || !o_rmean || !o_rvar || !o_w2 || !o_b2)) return DBMM_E_ARG;
+    if (B < 2 || D <= 0 || H <= 0 || (D & 3) || (H & 3) || C <= 0 || C > 8) return DBMM_E_SHAPE;
+    if (workspace_bytes < dbmm_workspace_bytes_adapter_train_step(B, D, H, with_old)) return DBMM_E_WORKSPACE;
+    if (!dbmm_aligned16(workspace)) return DBMM_E_ALIGN;
+    auto up4 = [](size_t n) { return (n + 3) / 4 * 4; };
+    float* f = (float*)workspace;
+    float* h = f;            f += up4(B * H);
+    float* r = f;            f += up4(B * H);
+    float* z = f;            f += up4(B * D);
+    float* mean = f;         f += up4(H);
+    float* invstd = f;       f += up4(H);
+    float *oh = nullptr, *orr = nullptr, *oz = nullptr, *omean = nullptr, *oinv = nullptr;
+    if (with_old) {
+        oh = f; f += up4(B * H); orr = f; f += up4(B * H); oz = f; f += up4(B * D);
+        omean = f; f += up4(H); oinv = f; f += up4(H);
+    }
+    float* inv_norm = f;     f += up4(B);
+    float* dz = f;           f += up4(B * D);
+    float* dw1 = f;          f += up4(H * D);
+    float* db1 = f;          f += up4(H);
+    float* dgamma = f;       f += up4(H);
+    float* dbeta = f;        f += up4(H);
+    float* dw2 = f;          f += up4(D * H);
+    float* db2 = f;          f += up4(D);
+    float* bws = f;
+    const float eps = 1e-5f, bn_momentum = 0.1f;
+    int rc;
+    rc = dbmm_adapter_fwd(x, w1, b1, gamma, beta, rmean, rvar, nbt, w2, b2, h, mean, invstd, r, z, B, D, H, 1, eps,
+                          bn_momentum, stream);
+    if (rc) return rc;
+    if (with_old) {   // frozen branch: forward only, but BatchNorm still in train mode
+        rc = dbmm_adapter_fwd(x, o_w1, o_b1, o_gamma, o_beta, o_rmean, o_rvar, o_nbt, o_w2, o_b2, oh, omean, oinv, orr,
+                              oz, B, D, H, 1, eps, bn_momentum, stream);
+        if (rc) return rc;
+    }
+    rc = dbmm_l2norm_sim_ce_fwd(z, oz, ebd_weight, tn, labels, temperature, logits, loss_rows, loss_mean, nullptr,
+                                inv_norm, B, D, C, stream);
+    if (rc) return rc;
+    rc = dbmm_l2norm_sim_ce_bwd(z, inv_norm, ebd_weight, with_old, tn, logits, labels, nullptr, temperature, 1.f, dz, B,
+                                D, C, stream);
+    if (rc) return rc;
+    rc = dbmm_adapter_bwd(x, dz, h, mean, invstd, r, gamma, beta, w2, dw1, db1, dgamma, dbeta, dw2, db2, B, D, H, bws,
+                          (size_t)(2 * B * H) * sizeof(float), stream);
+    if (rc) return rc;
+    float* ps[6] = {w1, b1, gamma, beta, w2, b2};
+    const float* gs[6] = {dw1, db1, dgamma, dbeta, dw2, db2};
+    float* ms[6] = {m_w1, m_b1, m_gamma, m_beta, m_w2, m_b2};
+    const int64_t ns[6] = {H * D, H, H, H, D * H, D};
+    return dbmm_sgd_momentum(6, ps, gs, ms, ns, lr, momentum, weight_decay, first_step, stream);
+}
+
+extern "C" int dbmm_version(void) { return 101; }
 
 extern "C" const char* dbmm_error_string(int code) {
     switch (code) {

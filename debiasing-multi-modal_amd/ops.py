@@ -333,3 +333,46 @@ def group_loss_sum(loss_rows, g, sums):
     check(_lib.lib().dbmm_group_loss_sum(ptr(loss_rows), ptr(g), ptr(sums), loss_rows.shape[0], sums.shape[0], stream()),
           "group_loss_sum")
     return sums
+
+
+_step_ws = {}
+
+
+def adapter_train_step(x, labels, new, bufs, old, ebd_weight, tn, temperature, lr, momentum, weight_decay, first_step):
+    """one fused training-step body (dbmm_adapter_train_step).  `new` / `old` are tuples
+    (w1, b1, gamma, beta, running_mean, running_var, nbt, w2, b2); `bufs` the six momentum buffers
+    in the order (w1, b1, gamma, beta, w2, b2); `old` may be None."""
+    require_cuda(x, labels, tn)
+    _f32c(x)
+    B, D = x.shape
+    H = new[0].shape[0]
+    C = tn.shape[0]
+    dev = x.device
+    key = (dev.index, B, D, H, old is not None)
+    ws = _step_ws.get(key)
+    if ws is None:
+        nbytes = _lib.lib().dbmm_workspace_bytes_adapter_train_step(B, D, H, int(old is not None))
+        ws = torch.empty(nbytes // 4, device=dev, dtype=torch.float32)
+        if len(_step_ws) > 8:
+            _step_ws.clear()
+        _step_ws[key] = ws
+    logits = torch.empty((B, C), device=dev, dtype=torch.float32)
+    loss_rows = torch.empty((B,), device=dev, dtype=torch.float32)
+    loss_mean = torch.empty((), device=dev, dtype=torch.float32)
+    o = [ptr(t) for t in old] if old is not None else [None] * 9
+    check(_lib.lib().dbmm_adapter_train_step(
+        ptr(x), ptr(labels), *[ptr(t) for t in new], *[ptr(t) for t in bufs], *o, float(ebd_weight), ptr(tn),
+        float(temperature), float(lr), float(momentum), float(weight_decay), int(first_step), ptr(logits),
+        ptr(loss_rows), ptr(loss_mean), B, D, H, C, ptr(ws), ws.numel() * 4, stream()), "adapter_train_step")
+    return loss_mean, logits, loss_rows
+
+
+def gather_rows(table, idx):
+    """out[i] = table[idx[i]] for a device-resident [N, D] fp32 table and int64 indices."""
+    require_cuda(table, idx)
+    _f32c(table)
+    idx = idx.contiguous()
+    out = torch.empty((idx.numel(), table.shape[1]), device=table.device, dtype=torch.float32)
+    check(_lib.lib().dbmm_gather_rows(ptr(table), ptr(idx), ptr(out), table.shape[0], idx.numel(), table.shape[1],
+                                      stream()), "gather_rows")
+    return out

@@ -173,6 +173,10 @@ def clip_state_dict(seed, arch="RN50", **over):
         "tiny-RN": dict(kind="rn", layers=(1, 1, 1, 1), width=64, embed=128, res=64, twidth=64, tlayers=2, vocab=512),
         "tiny-RN-w32": dict(kind="rn", layers=(1, 2, 1, 1), width=32, embed=64, res=96, twidth=64, tlayers=2, vocab=512),
         "tiny-ViT": dict(kind="vit", patch=16, width=128, layers=2, embed=64, res=64, twidth=64, tlayers=2, vocab=512),
+        # ViT-L/14@336px geometry (577 tokens, 16 heads, patch K = 588) with 2 layers: exercises the
+        # multi-tile attention core and the K-tail GEMM path without the 24-layer cost
+        "ViT-L14-336-2L": dict(kind="vit", patch=14, width=1024, layers=2, embed=768, res=336, twidth=64, tlayers=1,
+                               vocab=512),
     }
     c = dict(cfgs[arch]); c.update(over)
     if c["kind"] == "rn":

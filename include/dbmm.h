@@ -225,6 +225,29 @@ int dbmm_sgd_momentum(int64_t n, float* const* params, const float* const* grads
                       float* const* bufs, const int64_t* sizes, float lr, float momentum,
                       float weight_decay, int first_step, void* stream);
 
+/* One training-step body in one call (final_main.py:455-466, :610-623): adapter forward (train-mode
+ * BN), optional frozen old adapter (MultipleAdapter: pass o_* = NULL for CustomCLIP), fused
+ * normalise + logits + CE, backward, SGD-momentum on the six trainable tensors (m_* = momentum
+ * buffers).  ~20 kernel launches enqueued back to back, no host round trips.  tn = [C][D] from
+ * dbmm_text_colnorm.  Outputs: logits [B][C], loss_rows [B], loss_mean [1]. */
+size_t dbmm_workspace_bytes_adapter_train_step(int64_t B, int64_t D, int64_t H, int with_old);
+int dbmm_adapter_train_step(const float* x, const int64_t* labels, float* w1, float* b1, float* gamma,
+                            float* beta, float* running_mean, float* running_var, int64_t* nbt,
+                            float* w2, float* b2, float* m_w1, float* m_b1, float* m_gamma,
+                            float* m_beta, float* m_w2, float* m_b2, const float* o_w1,
+                            const float* o_b1, const float* o_gamma, const float* o_beta,
+                            float* o_running_mean, float* o_running_var, int64_t* o_nbt,
+                            const float* o_w2, const float* o_b2, float ebd_weight, const float* tn,
+                            float temperature, float lr, float momentum, float weight_decay,
+                            int first_step, float* logits, float* loss_rows, float* loss_mean,
+                            int64_t B, int64_t D, int64_t H, int64_t C, void* workspace,
+                            size_t workspace_bytes, void* stream);
+
+/* out[i][:] = table[idx[i]][:] -- batch assembly from a device-resident embedding table
+ * (replaces the DataLoader + per-item DataFrame lookups of data/ *_embeddings*.py) */
+int dbmm_gather_rows(const float* table, const int64_t* idx, float* out, int64_t n_rows,
+                     int64_t n_idx, int64_t D, void* stream);
+
 /* update_dict (final_main.py:383-391) on device: counts[g][0] += 1, counts[g][1] += (argmax
  * logits == y) for every row; counts is int64 [G][2], accumulated (not cleared). */
 int dbmm_group_count(const float* logits, const int64_t* y, const int64_t* g, int64_t* counts,

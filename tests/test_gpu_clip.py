@@ -62,7 +62,7 @@ def test_encode_text_vs_golden(arch, golden, models):
     assert relerr(out.cpu(), g["text_embedding"]) < 5e-5
 
 
-@pytest.mark.parametrize("arch,B", [("tiny-RN", 5), ("tiny-ViT", 3), ("RN50", 3)])
+@pytest.mark.parametrize("arch,B", [("tiny-RN", 5), ("tiny-ViT", 3), ("RN50", 3), ("ViT-L14-336-2L", 2)])
 def test_encode_image_vs_oracle_other_inputs(arch, B, models):
     """fresh seed / odd batch (ragged M tiles) against the oracle run here on the CPU."""
     seed = 11

@@ -48,9 +48,22 @@ def main():
 
             def dropin():
                 loss = crit(clf(x.detach()), y); opt.zero_grad(); loss.backward(); opt.step()
-            tf, td = timeit(fused, 50, 5), timeit(dropin, 50, 5)
-            print(f"adapter step B={B}: fused {tf * 1e6:.0f} us ({B / tf:.0f} samples/s), "
-                  f"drop-in {td * 1e6:.0f} us ({B / td:.0f} samples/s)")
+            def onecall():
+                clf.train_step(x, y, opt)
+            tf, td, to = timeit(fused, 50, 5), timeit(dropin, 50, 5), timeit(onecall, 200, 10)
+            print(f"adapter step B={B}: one-call train_step {to * 1e6:.0f} us ({B / to:.0f} samples/s), "
+                  f"autograd+fused CE {tf * 1e6:.0f} us, drop-in {td * 1e6:.0f} us")
+            if B == 256:
+                from dbmm_amd import trainer
+                N = 64 * 256
+                table = trainer.EmbeddingTable(synth.normal(7, "tab", (N, D), 0.5).numpy(), *[t.numpy() for t in synth.labels(8, N)[:2]])
+                trainer.train_epoch(table, clf, opt, B)
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                for _ in range(3):
+                    trainer.train_epoch(table, clf, opt, B)
+                torch.cuda.synchronize(); te = (time.perf_counter() - t0) / 3
+                print(f"device-resident epoch: {N} samples, bs {B}: {te * 1e3:.1f} ms/epoch = {te / (N // B) * 1e6:.0f} us/step "
+                      f"({N / te:.0f} samples/s) incl. batch gather + group counters")
     if "vit" in which:
         model = build_model(synth.clip_state_dict(2, "ViT-B/32")).cuda()
         for B in (64, 512):
