@@ -12,7 +12,7 @@ from ctypes import c_float, c_int, c_int64, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(_HERE, "libdbmm_hip.so")
+LIB_PATH = os.environ.get("DBMM_LIB") or os.path.join(_HERE, "libdbmm_hip.so")   # DBMM_LIB: developer override
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 
 _lib = None
@@ -25,7 +25,7 @@ def sources():
 def build(force=False, verbose=False):
     """hipcc --offload-arch=gfx950 -> libdbmm_hip.so (in-tree, so it travels with the repo)."""
     srcs = sources()
-    deps = srcs + glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(INCLUDE, "dbmm.h")]
+    deps = srcs + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.inc")) + [os.path.join(INCLUDE, "dbmm.h")]
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -63,6 +63,10 @@ _SIGS = {
     "dbmm_debug_last_igemm": [_P],
     "dbmm_conv_bn_act_ws": [_P, _P, _P, _P, _P, _L, _L, _L, _L, _L, _L, _L, _L, _L, _I, _I, _P, _Z, _P],
     "dbmm_gemm_bias_act_ws": [_P, _L, _I, _P, _L, _I, _P, _P, _L, _P, _L, _L, _L, _L, _F, _I, _P, _Z, _P],
+    "dbmm_split_planes_bytes": [_L, _L],
+    "dbmm_split_weight_planes": [_P, _P, _L, _L, _P],
+    "dbmm_conv_bn_act_x3": [_P, _P, _P, _P, _P, _P, _L, _L, _L, _L, _L, _L, _L, _L, _L, _I, _P, _Z, _P],
+    "dbmm_gemm_bias_act_x3": [_P, _L, _P, _P, _L, _P, _P, _L, _P, _L, _L, _L, _L, _F, _I, _P, _Z, _P],
     "dbmm_gemm_batched": [_P, _L, _L, _I, _P, _L, _L, _I, _P, _L, _P, _L, _L, _L, _L, _L, _L, _F, _I, _P],
     "dbmm_conv_stem_s2": [_P, _P, _P, _P, _L, _L, _L, _L, _P],
     "dbmm_avgpool2d": [_P, _P, _L, _L, _L, _L, _L, _P],
@@ -93,6 +97,7 @@ _RESTYPES = {
     "dbmm_error_string": ctypes.c_char_p,
     "dbmm_workspace_bytes_attnpool": c_size_t,
     "dbmm_workspace_bytes_igemm": c_size_t,
+    "dbmm_split_planes_bytes": c_size_t,
     "dbmm_debug_last_igemm": None,
     "dbmm_workspace_bytes_adapter_bwd": c_size_t,
     "dbmm_workspace_bytes_adapter_train_step": c_size_t,

@@ -108,8 +108,12 @@ def _fold_bn(conv_w, bn):
 
 
 def _pack_conv(w64):
-    """[Cout][Cin][kh][kw] fp64 (BN folded) -> (packed fp32 weight, layout id) for ops.conv_bn_act."""
-    return ops.pack_conv_weight(w64)
+    """[Cout][Cin][kh][kw] fp64 (BN folded) -> (packed fp32 weight, layout id, bf16 planes or None)
+    for ops.conv_bn_act.  The planes feed the split-precision kernel (three bf16 values per fp32
+    weight); shapes it does not cover fall back to the fp32-MFMA kernel inside the library."""
+    w, wl = ops.pack_conv_weight(w64)
+    planes = ops.split_planes(w) if (w.is_cuda and w.shape[0] > 32 and w.shape[1] % 16 == 0) else None
+    return w, wl, planes
 
 
 class ModifiedResNet(nn.Module):
@@ -174,25 +178,26 @@ class ModifiedResNet(nn.Module):
         P = self._plan or self._compile()
         x = x.float().contiguous()                      # NCHW image at the boundary
         x = ops.conv_stem_s2(x, *P["stem1"])            # -> NHWC from here on
-        x = ops.conv_bn_act(x, P["stem2"][0], P["stem2"][2], None, 3, 3, 1, 1, ops.ACT_RELU, P["stem2"][1])
-        x = ops.conv_bn_act(x, P["stem3"][0], P["stem3"][2], None, 3, 3, 1, 1, ops.ACT_RELU, P["stem3"][1])
+        conv = lambda t, c, res, k, pad, act: ops.conv_bn_act(t, c[0], c[3], res, k, k, 1, pad, act, c[1], c[2])
+        x = conv(x, P["stem2"], None, 3, 1, ops.ACT_RELU)
+        x = conv(x, P["stem3"], None, 3, 1, ops.ACT_RELU)
         x = ops.avgpool2d(x, 2)
         stages = {"stem": x}
         bi = 0
         for li in (1, 2, 3, 4):
             for _ in getattr(self, f"layer{li}"):
                 e = P["blocks"][bi]; bi += 1
-                out = ops.conv_bn_act(x, e["c1"][0], e["c1"][2], None, 1, 1, 1, 0, ops.ACT_RELU, e["c1"][1])
-                out = ops.conv_bn_act(out, e["c2"][0], e["c2"][2], None, 3, 3, 1, 1, ops.ACT_RELU, e["c2"][1])
+                out = conv(x, e["c1"], None, 1, 0, ops.ACT_RELU)
+                out = conv(out, e["c2"], None, 3, 1, ops.ACT_RELU)
                 if e["stride"] > 1:
                     out = ops.avgpool2d(out, e["stride"])
                 identity = x
                 if "ds" in e:
                     if e["stride"] > 1:
                         identity = ops.avgpool2d(x, e["stride"])
-                    identity = ops.conv_bn_act(identity, e["ds"][0], e["ds"][2], None, 1, 1, 1, 0, ops.ACT_NONE, e["ds"][1])
+                    identity = conv(identity, e["ds"], None, 1, 0, ops.ACT_NONE)
                 # conv3 + bn3, residual add and the final ReLU fused into one epilogue
-                x = ops.conv_bn_act(out, e["c3"][0], e["c3"][2], identity, 1, 1, 1, 0, ops.ACT_RELU, e["c3"][1])
+                x = conv(out, e["c3"], identity, 1, 0, ops.ACT_RELU)
             stages[f"layer{li}"] = x
         a = P["attn"]
         out = ops.attnpool(x, a["pos"], a["wq"], a["bq"], a["wkv"], a["bkv"], a["wc"], a["bc"], self.attnpool.num_heads)
@@ -227,19 +232,32 @@ class Transformer(nn.Module):
         self.causal = attn_mask is not None
         self.resblocks = nn.Sequential(*[ResidualAttentionBlock(width, heads) for _ in range(layers)])
 
+    def _apply(self, fn, *a, **k):
+        self._planes = None
+        return super()._apply(fn, *a, **k)
+
+    @torch.no_grad()
+    def _split_planes(self):
+        """bf16 planes of the four projection weights of every block (split-precision GEMMs)"""
+        self._planes = [tuple(ops.split_planes(w.detach().contiguous()) for w in
+                              (b.attn.in_proj_weight, b.attn.out_proj.weight, b.mlp.c_fc.weight, b.mlp.c_proj.weight))
+                        for b in self.resblocks]
+        return self._planes
+
     @torch.no_grad()
     def run(self, x, B, L):
         """x [B*L, E] batch-first rows.  Pre-LN blocks (clip/model.py:189-192): the residual
         adds and QuickGELU are GEMM epilogues."""
         E = self.width
-        for blk in self.resblocks:
+        planes = getattr(self, "_planes", None) or self._split_planes()
+        for blk, (p_in, p_out, p_fc, p_proj) in zip(self.resblocks, planes):
             h = ops.layernorm(x, blk.ln_1.weight, blk.ln_1.bias)
-            qkv = ops.gemm(h, blk.attn.in_proj_weight, blk.attn.in_proj_bias)
+            qkv = ops.gemm(h, blk.attn.in_proj_weight, blk.attn.in_proj_bias, w_planes=p_in)
             o = ops.mha_core(qkv, B, L, E, self.heads, self.causal)
-            x = ops.gemm(o, blk.attn.out_proj.weight, blk.attn.out_proj.bias, residual=x)
+            x = ops.gemm(o, blk.attn.out_proj.weight, blk.attn.out_proj.bias, residual=x, w_planes=p_out)
             h = ops.layernorm(x, blk.ln_2.weight, blk.ln_2.bias)
-            h = ops.gemm(h, blk.mlp.c_fc.weight, blk.mlp.c_fc.bias, act=ops.ACT_QUICKGELU)
-            x = ops.gemm(h, blk.mlp.c_proj.weight, blk.mlp.c_proj.bias, residual=x)
+            h = ops.gemm(h, blk.mlp.c_fc.weight, blk.mlp.c_fc.bias, act=ops.ACT_QUICKGELU, w_planes=p_fc)
+            x = ops.gemm(h, blk.mlp.c_proj.weight, blk.mlp.c_proj.bias, residual=x, w_planes=p_proj)
         return x
 
 

@@ -64,6 +64,8 @@ struct IgemmP {
     unsigned a_bytes, w_bytes;          // FAST loader: buffer extents (< 2 GiB)
     int sk_blocks;                      // stream-K: resident grid size (0 = one tile per block)
     float* sk_ws;                       // stream-K: [sk_blocks][2][BM*BN] partial accumulators
+    const unsigned short* w3;           // split path: W as three bf16 planes [3][N][ldw]
+    unsigned w3_bytes;
 };
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -460,70 +462,231 @@ __device__ __forceinline__ void igemm_tile(const IgemmP& p, float* lds, int tile
         return;
     }
     {
-    constexpr int LPR = WTN / 4;              // lanes per output row
-    constexpr int RPI = 64 / LPR;             // rows per wave instruction
-    constexpr int NIT = 32 / RPI;             // instructions per 32-row half tile
-    const bool vec_ok = ((p.N & 3) == 0) && ((p.ldc & 3) == 0) && (!p.res || (p.ldr & 3) == 0);
-    if (vec_ok) {
-        float* Ls = lds + wave * (32 * LROW);
-        const int ec = (lane % LPR) * 4, er = lane / LPR;
-        const int n = n0 + wn0 + ec;
-        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-        if (p.bias && n < p.N) bv = *(const f32x4*)(p.bias + n);
-        const float* __restrict__ resp = p.res;
-        float* __restrict__ cp = p.c;
+#include "igemm_epilogue.inc"
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Split-precision tile ("x3"): every fp32 operand value is the exact sum of three bf16 values
+// (hi + mid + lo, 8 + 8 + 8 mantissa bits); a product a*b is accumulated as the six bf16 x bf16
+// partial products down to 2^-16 relative size (hh, hm, mh, mm, hl, lh -- each exact in the
+// fp32 accumulator) on v_mfma_f32_32x32x16_bf16.  Six bf16 MFMAs cover 16 k values in 6 x 32
+// cycles where the fp32-input MFMA needs 8 x 64: 2.67x the fp32-MFMA rate at fp32-level
+// accuracy (the dropped terms are <= 2^-24 relative, the size of an fp32 rounding).
+// A (activations) stays fp32 in HBM and is split by the loader on its way into LDS; W comes
+// pre-split (dbmm_split_weight_planes).  LDS per stage: 3 planes x (BM + BN) rows x 16 bf16,
+// 16-B chunk index XOR (row >> 3) & 1 -> conflict-free ds_read_b128 fragment reads.
+// ---------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16;
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void split3(float x, u16& hi, u16& mid, u16& lo) {
+    const __bf16 h = (__bf16)x;
+    const float r1 = x - (float)h;
+    const __bf16 m = (__bf16)r1;
+    const float r2 = r1 - (float)m;
+    const __bf16 l = (__bf16)r2;
+    hi = __builtin_bit_cast(u16, h); mid = __builtin_bit_cast(u16, m); lo = __builtin_bit_cast(u16, l);
+}
+
+template <int BM, int BN>
+struct GeoX3 {   // LDS floats for the split path (bf16 planes, two stages) vs the epilogue staging
+    static constexpr int STAGE_U16 = 3 * (BM + BN) * 16;
+    static constexpr int TILE_FLOATS = 2 * STAGE_U16 / 2;
+};
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int AMODE>
+__device__ __forceinline__ void igemm_tile_x3(const IgemmP& p, float* lds, int tile, int kb, int ke, float* partial) {
+    constexpr int BK = 16;
+    using G = Geo<BM, BN, WAVES_M, WAVES_N, BK>;
+    constexpr int TM = G::TM, TN = G::TN, WTN = G::WTN, LROW = G::LROW;
+    constexpr int ALD = BM / 64;                  // float4 loads per thread per chunk (64 rows x 4 k-quads per pass)
+    constexpr int STAGE = GeoX3<BM, BN>::STAGE_U16;
+    u16* Ap = (u16*)lds;                           // [2][3][BM][16] then [2][3][BN][16] per stage
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = (tile / p.tiles_n) * BM, n0 = (tile % p.tiles_n) * BN;
+    const int wm0 = (wave / WAVES_N) * (TM * 32), wn0 = (wave % WAVES_N) * (TN * 32);
+    const int lc = tid & 3, lr = tid >> 2;         // A: k-quad lc of rows lr + 64*i
+    const int wr = tid >> 1, wc = tid & 1;         // W: 16-B chunk wc (8 bf16) of row wr, all 3 planes
+
+    unsigned fa_off[ALD], fa_mask[ALD];
+    int f_ci0 = 0, f_kh = 0, f_kw = 0, f_tap = 0;
+    __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.a, 0, (int)p.a_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.w3, 0, (int)p.w3_bytes, 0x00020000);
+    const unsigned plane_bytes = (unsigned)p.N * (unsigned)p.ldw * 2u;
+    const unsigned fw_off = (wr < BN && n0 + wr < p.N) ? ((unsigned)(n0 + wr) * (unsigned)p.ldw + wc * 8u) * 2u : OOR;
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            __syncthreads();                  // K loop (or previous half) done with this LDS
+    for (int i = 0; i < ALD; ++i) {
+        const int m = m0 + lr + 64 * i;
+        const bool rv = m < p.M;
+        if constexpr (AMODE == 0) {
+            fa_off[i] = rv ? (unsigned)m * (unsigned)p.lda * 4u + lc * 16u : OOR;
+            fa_mask[i] = 0;
+        } else {
+            const int hw = p.Ho * p.Wo;
+            const int n = m / hw, rem = m - n * hw;
+            const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+            const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
+            fa_off[i] = ((unsigned)(n * p.H + hi0) * (unsigned)p.W + (unsigned)wi0) * (unsigned)p.Cin * 4u + lc * 16u;
+            unsigned msk = 0;
+            for (int kh = 0; kh < p.KH; ++kh)
+                for (int kw = 0; kw < p.KW; ++kw)
+                    if (hi0 + kh >= 0 && hi0 + kh < p.H && wi0 + kw >= 0 && wi0 + kw < p.W)
+                        msk |= 1u << (kh * p.KW + kw);
+            fa_mask[i] = rv ? msk : 0u;
+        }
+    }
+    if constexpr (AMODE == 1) {
+        const int k = kb * BK;
+        f_tap = k / p.Cin; f_ci0 = k - f_tap * p.Cin;
+        f_kh = f_tap / p.KW; f_kw = f_tap - f_kh * p.KW;
+    }
+
+    // two register sets: the loads of chunk k+2 are issued while chunk k computes and chunk k+1
+    // (already landed) is split into LDS -- each chunk's MFMA phase is only 768 cycles per wave,
+    // one chunk of lead did not cover the L2 / Infinity-Cache latency (ablation: 31 % of the time)
+    f32x4 a_r0[ALD], a_r1[ALD];
+    u32x4 w_r0[3], w_r1[3];
+    auto load_chunk = [&](int k0, f32x4 (&a_reg)[ALD], u32x4 (&w_reg)[3]) {
+        if constexpr (AMODE == 0) {
+#pragma unroll
+            for (int i = 0; i < ALD; ++i) a_reg[i] = buf_load16(rsA, fa_off[i], (unsigned)k0 * 4u);
+        } else {
+            const unsigned delta = ((unsigned)(f_kh * p.W + f_kw) * (unsigned)p.Cin + (unsigned)f_ci0) * 4u;
+            const unsigned bit = 1u << f_tap;
+#pragma unroll
+            for (int i = 0; i < ALD; ++i)
+                a_reg[i] = buf_load16(rsA, (fa_mask[i] & bit) ? fa_off[i] + delta : OOR, 0u);
+            f_ci0 += BK;
+            if (f_ci0 == p.Cin) {
+                f_ci0 = 0; ++f_tap;
+                if (++f_kw == p.KW) { f_kw = 0; ++f_kh; }
+            }
+        }
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+            w_reg[pl] = __builtin_amdgcn_raw_buffer_load_b128(rsW, fw_off, pl * plane_bytes + (unsigned)k0 * 2u, 0);
+    };
+    auto store_chunk = [&](int stage, const f32x4 (&a_reg)[ALD], const u32x4 (&w_reg)[3]) {
+        u16* Ab = Ap + stage * STAGE;              // planes [3][BM][16]
+        u16* Wb = Ab + 3 * BM * 16;                // planes [3][BN][16]
+#pragma unroll
+        for (int i = 0; i < ALD; ++i) {
+            const int row = lr + 64 * i;
+            u16 h[4], m[4], l[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) split3(a_reg[i][j], h[j], m[j], l[j]);
+            const int off = row * 16 + ((((lc >> 1) ^ ((row >> 3) & 1))) << 3) + ((lc & 1) << 2);
+            *(u32x2*)(Ab + 0 * BM * 16 + off) = (u32x2){(unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16)};
+            *(u32x2*)(Ab + 1 * BM * 16 + off) = (u32x2){(unsigned)m[0] | ((unsigned)m[1] << 16), (unsigned)m[2] | ((unsigned)m[3] << 16)};
+            *(u32x2*)(Ab + 2 * BM * 16 + off) = (u32x2){(unsigned)l[0] | ((unsigned)l[1] << 16), (unsigned)l[2] | ((unsigned)l[3] << 16)};
+        }
+        if (wr < BN) {
+            const int off = wr * 16 + ((wc ^ ((wr >> 3) & 1)) << 3);
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) *(u32x4*)(Wb + pl * BN * 16 + off) = w_reg[pl];
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int fr = lane & 31, fh = lane >> 5;
+    const int fch = (fh ^ ((fr >> 3) & 1)) << 3;    // swizzled chunk of this lane's 8 k values (u16 units)
+
+    auto compute = [&](int stage) {
+        const u16* Ab = Ap + stage * STAGE;
+        const u16* Wb = Ab + 3 * BM * 16;
+        bf16x8 af[TM][3], wf[TN][3];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i][pl] = *(const bf16x8*)(Ab + pl * BM * 16 + (wm0 + i * 32 + fr) * 16 + fch);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) wf[j][pl] = *(const bf16x8*)(Wb + pl * BN * 16 + (wn0 + j * 32 + fr) * 16 + fch);
+        }
+        // smallest partial products first: (h,l) (l,h) (m,m) (h,m) (m,h) (h,h)
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PA[q]], wf[j][PB[q]], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    __syncthreads();
+    load_chunk(kb * BK, a_r0, w_r0);
+    if (kb + 1 < ke) load_chunk((kb + 1) * BK, a_r1, w_r1);
+    store_chunk(0, a_r0, w_r0);
+    __syncthreads();
+
+    // chunk kc lives in LDS stage (kc-kb)&1; set r1 holds chunk kc+1 on even steps, r0 on odd ones
+    for (int kc = kb; kc < ke; kc += 2) {
+        if (kc + 2 < ke) load_chunk((kc + 2) * BK, a_r0, w_r0);
+        compute(0);
+        if (kc + 1 < ke) store_chunk(1, a_r1, w_r1);
+        __syncthreads();
+        if (kc + 1 >= ke) break;
+        if (kc + 3 < ke) load_chunk((kc + 3) * BK, a_r1, w_r1);
+        compute(1);
+        if (kc + 2 < ke) store_chunk(0, a_r0, w_r0);
+        __syncthreads();
+    }
+
+    if (partial) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    Ls[((r & 3) + 8 * (r >> 2) + 4 * fh) * LROW + j * 32 + fr] = acc[i][j][r];
-            __syncthreads();
-            const int mb = m0 + wm0 + i * 32 + er;
-            f32x4 rv[NIT];
-#pragma unroll
-            for (int t = 0; t < NIT; ++t) {
-                const int m = mb + t * RPI;
-                rv[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if (resp && m < p.M && n < p.N) rv[t] = *(const f32x4*)(resp + (long long)m * p.ldr + n);
-            }
-#pragma unroll
-            for (int t = 0; t < NIT; ++t) {
-                const int m = mb + t * RPI;
-                f32x4 v = (*(const f32x4*)(Ls + (er + t * RPI) * LROW + ec) + bv) * p.alpha + rv[t];
-                if (p.act == DBMM_ACT_RELU) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
-                } else if (p.act == DBMM_ACT_QUICKGELU) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) v[q] = v[q] / (1.f + expf(-1.702f * v[q]));
-                }
-                if (m < p.M && n < p.N) *(f32x4*)(cp + (long long)m * p.ldc + n) = v;
-            }
-        }
+                for (int r = 0; r < 16; ++r) partial[((i * TN + j) * 16 + r) * 256 + tid] = acc[i][j][r];
         return;
     }
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wn0 + j * 32 + fr;
-        if (n >= p.N) continue;
-        const float bv = p.bias ? p.bias[n] : 0.f;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-                if (m >= p.M) continue;
-                float v = (acc[i][j][r] + bv) * p.alpha;
-                if (p.res) v += p.res[(long long)m * p.ldr + n];
-                if (p.act == DBMM_ACT_RELU) v = fmaxf(v, 0.f);
-                else if (p.act == DBMM_ACT_QUICKGELU) v = v / (1.f + expf(-1.702f * v));
-                p.c[(long long)m * p.ldc + n] = v;
-            }
+    {
+#include "igemm_epilogue.inc"
+    }
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int AMODE, int MINB, int SK>
+__global__ __launch_bounds__(256, MINB) void igemm_x3_kernel(const IgemmP p) {
+    using G = Geo<BM, BN, WAVES_M, WAVES_N, 16>;
+    constexpr int LDSF = GeoX3<BM, BN>::TILE_FLOATS > G::EPI_FLOATS ? GeoX3<BM, BN>::TILE_FLOATS : G::EPI_FLOATS;
+    __shared__ __attribute__((aligned(16))) float lds[LDSF];
+    const int nk = p.K / 16;
+    if constexpr (!SK) {
+        igemm_tile_x3<BM, BN, WAVES_M, WAVES_N, AMODE>(p, lds, xcd_remap(blockIdx.x, p.n_tiles), 0, nk, nullptr);
+    } else {
+        const long long U = (long long)p.n_tiles * nk;
+        long long u = U * blockIdx.x / p.sk_blocks;
+        const long long u1 = U * (blockIdx.x + 1) / p.sk_blocks;
+        for (int seg = 0; u < u1; ++seg) {
+            const int tile = (int)(u / nk), kb = (int)(u - (long long)tile * nk);
+            const int ke = (int)((u1 - u < nk - kb) ? kb + (u1 - u) : nk);
+            float* partial = (kb == 0 && ke == nk)
+                                 ? nullptr
+                                 : p.sk_ws + ((size_t)blockIdx.x * 2 + (seg ? 1 : 0)) * (size_t)(BM * BN);
+            igemm_tile_x3<BM, BN, WAVES_M, WAVES_N, AMODE>(p, lds, tile, kb, ke, partial);
+            u += ke - kb;
         }
     }
+}
+
+// fp32 [N][K] -> three bf16 planes [3][N][K] (hi, mid, lo)
+__global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ w, u16* __restrict__ out,
+                                                           long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        u16 h, m, l;
+        split3(w[i], h, m, l);
+        out[i] = h; out[n + i] = m; out[2 * n + i] = l;
     }
 }
 
@@ -618,6 +781,29 @@ int launch_cfg(IgemmP& p, hipStream_t s, int nbatch, void* ws, size_t ws_bytes) 
     }
     const dim3 grid(p.sk_blocks ? p.sk_blocks : p.n_tiles, nbatch);
     bool launched = false;
+    if constexpr ((AMODE == 0 || AMODE == 1) && WMODE == 0 && BK == 16 && BM == 128 && (BN == 128 || BN == 64)) {
+        // split-precision path: needs pre-split weights and the FAST loader's preconditions
+        static const int x3_allow = [] { const char* e = getenv("DBMM_IGEMM_X3"); return e ? atoi(e) : 1; }();
+        if (x3_allow && p.w3 && nbatch == 1 && fast_ok<AMODE, WMODE, BK>(p)) {
+            constexpr int MB = BN == 128 ? 2 : 3;   // register budget for the two prefetch sets (no spills)
+            if (p.sk_blocks) {   // the resident grid is sized for this kernel's occupancy
+                p.sk_blocks = NUM_CUS * MB;
+                if ((long long)p.n_tiles * (p.K / 16) < 4LL * p.sk_blocks) p.sk_blocks = 0;
+            }
+            const dim3 g3(p.sk_blocks ? p.sk_blocks : p.n_tiles, 1);
+            if (p.sk_blocks)
+                hipLaunchKernelGGL((igemm_x3_kernel<BM, BN, WM, WN, AMODE, MB, 1>), g3, dim3(256), 0, s, p);
+            else
+                hipLaunchKernelGGL((igemm_x3_kernel<BM, BN, WM, WN, AMODE, MB, 0>), g3, dim3(256), 0, s, p);
+            g_last_cfg[8] = 3; g_last_cfg[10] = 0;
+            DBMM_CHECK_LAUNCH();
+            if (p.sk_blocks) {
+                hipLaunchKernelGGL((igemm_fixup_kernel<BM, BN, WM, WN, BK>), dim3(p.sk_blocks - 1), dim3(256), 0, s, p);
+                DBMM_CHECK_LAUNCH();
+            }
+            return DBMM_OK;
+        }
+    }
     {
         const int c[11] = {BM, BN, WM, WN, AMODE, WMODE, BK, MINB, 0, p.sk_blocks ? 1 : 0, 0};
         for (int i = 0; i < 11; ++i) g_last_cfg[i] = c[i];
@@ -687,9 +873,16 @@ inline void set_extents(IgemmP& p, long long a_bytes, long long w_bytes) {
     p.w_bytes = (w_bytes > 0 && w_bytes < lim) ? (unsigned)w_bytes : 0u;
 }
 
+// w3 (optional): the same weight as three bf16 planes from dbmm_split_weight_planes
+inline void set_planes(IgemmP& p, const void* w3, long long N, long long ldw) {
+    const long long bytes = 3 * N * ldw * 2;
+    p.w3 = (w3 && bytes < 0x7FFFFFF0LL && dbmm_aligned16(w3)) ? (const unsigned short*)w3 : nullptr;
+    p.w3_bytes = p.w3 ? (unsigned)bytes : 0u;
+}
+
 int gemm_impl(const float* a, int64_t lda, int trans_a, const float* w, int64_t ldw, int trans_w, const float* bias,
               const float* residual, int64_t ldr, float* c, int64_t ldc, int64_t M, int64_t N, int64_t K, float alpha,
-              int act, void* ws, size_t wsb, void* stream) {
+              int act, void* ws, size_t wsb, void* stream, const void* w3 = nullptr) {
     if (!a || !w || !c) return DBMM_E_ARG;
     if (M <= 0 || N <= 0 || K <= 0 || M > INT32_MAX || N > INT32_MAX || K > INT32_MAX) return DBMM_E_SHAPE;
     if (act < 0 || act > 2) return DBMM_E_ARG;
@@ -704,6 +897,7 @@ int gemm_impl(const float* a, int64_t lda, int trans_a, const float* w, int64_t 
     p.lda = lda; p.ldw = ldw; p.ldr = ldr; p.ldc = ldc;
     p.M = (int)M; p.N = (int)N; p.K = (int)K; p.act = act; p.alpha = alpha;
     set_extents(p, trans_a ? 0 : ((M - 1) * lda + K) * 4, trans_w ? 0 : ((N - 1) * ldw + K) * 4);
+    if (!trans_a && !trans_w) set_planes(p, w3, N, ldw);
     hipStream_t s = (hipStream_t)stream;
     if (!trans_a && !trans_w) return launch_modes<0, 0>(p, s, 1, ws, wsb);
     if (!trans_a && trans_w) return launch_modes<0, 1>(p, s, 1, ws, wsb);
@@ -713,7 +907,7 @@ int gemm_impl(const float* a, int64_t lda, int trans_a, const float* w, int64_t 
 
 int conv_impl(const float* x, const float* w, const float* bias, const float* residual, float* y, int64_t B, int64_t H,
               int64_t W, int64_t Cin, int64_t Cout, int64_t KH, int64_t KW, int64_t stride, int64_t pad, int act,
-              int w_layout, void* ws, size_t wsb, void* stream) {
+              int w_layout, void* ws, size_t wsb, void* stream, const void* w3 = nullptr) {
     if (w_layout != DBMM_WL_TAP_MAJOR && w_layout != DBMM_WL_CHUNK_MAJOR) return DBMM_E_ARG;
     if (w_layout == DBMM_WL_CHUNK_MAJOR && (Cin & 15)) return DBMM_E_SHAPE;
     if (!x || !w || !y) return DBMM_E_ARG;
@@ -733,6 +927,7 @@ int conv_impl(const float* x, const float* w, const float* bias, const float* re
     p.H = (int)H; p.W = (int)W; p.Cin = (int)Cin; p.Ho = (int)Ho; p.Wo = (int)Wo;
     p.KH = (int)KH; p.KW = (int)KW; p.stride = (int)stride; p.pad = (int)pad; p.wl = w_layout;
     set_extents(p, B * H * W * Cin * 4, Cout * K * 4);
+    if (w_layout == DBMM_WL_TAP_MAJOR) set_planes(p, w3, Cout, K);
     hipStream_t s = (hipStream_t)stream;
     if (KH == 1 && KW == 1 && stride == 1 && pad == 0) return launch_modes<0, 0>(p, s, 1, ws, wsb);  // plain GEMM
     return launch_modes<1, 0>(p, s, 1, ws, wsb);
@@ -804,6 +999,35 @@ extern "C" int dbmm_conv_bn_act_ws(const float* x, const float* w, const float* 
                                    size_t workspace_bytes, void* stream) {
     return conv_impl(x, w, bias, residual, y, B, H, W, Cin, Cout, KH, KW, stride, pad, act, w_layout, workspace,
                      workspace_bytes, stream);
+}
+
+extern "C" size_t dbmm_split_planes_bytes(int64_t N, int64_t K) { return (size_t)(3 * N * K) * 2; }
+
+extern "C" int dbmm_split_weight_planes(const float* w, void* planes, int64_t N, int64_t K, void* stream) {
+    if (!w || !planes) return DBMM_E_ARG;
+    if (N <= 0 || K <= 0) return DBMM_E_SHAPE;
+    const long long n = (long long)N * K;
+    const long long blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0,
+                       (hipStream_t)stream, w, (u16*)planes, n);
+    DBMM_CHECK_LAUNCH();
+    return DBMM_OK;
+}
+
+extern "C" int dbmm_conv_bn_act_x3(const float* x, const float* w, const void* w_planes, const float* bias,
+                                   const float* residual, float* y, int64_t B, int64_t H, int64_t W, int64_t Cin,
+                                   int64_t Cout, int64_t KH, int64_t KW, int64_t stride, int64_t pad, int act,
+                                   void* workspace, size_t workspace_bytes, void* stream) {
+    return conv_impl(x, w, bias, residual, y, B, H, W, Cin, Cout, KH, KW, stride, pad, act, DBMM_WL_TAP_MAJOR, workspace,
+                     workspace_bytes, stream, w_planes);
+}
+
+extern "C" int dbmm_gemm_bias_act_x3(const float* a, int64_t lda, const float* w, const void* w_planes, int64_t ldw,
+                                     const float* bias, const float* residual, int64_t ldr, float* c, int64_t ldc,
+                                     int64_t M, int64_t N, int64_t K, float alpha, int act, void* workspace,
+                                     size_t workspace_bytes, void* stream) {
+    return gemm_impl(a, lda, 0, w, ldw, 0, bias, residual, ldr, c, ldc, M, N, K, alpha, act, workspace, workspace_bytes,
+                     stream, w_planes);
 }
 
 extern "C" int dbmm_conv1x1_bn_act(const float* x, const float* w, const float* bias, const float* residual,

@@ -37,6 +37,8 @@ def _last_igemm_tag():
     """exact instantiation of the igemm launch just issued, spelled like rocprofv3's kernel name"""
     cfg = (ctypes.c_int * 11)()
     _lib.lib().dbmm_debug_last_igemm(cfg)
+    if cfg[8] == 3:     # split-precision kernel: <BM, BN, WAVES_M, WAVES_N, AMODE, MINB, SK>
+        return f"igemm_x3_kernel<{cfg[0]}, {cfg[1]}, {cfg[2]}, {cfg[3]}, {cfg[4]}, {2 if cfg[1] == 128 else 3}, {cfg[9]}>"
     return "igemm_f32_kernel<" + ", ".join(str(v) for v in cfg) + ">"
 
 
@@ -77,8 +79,18 @@ def _f32c(t):
     return t
 
 
+def split_planes(w):
+    """fp32 [N][K] weight -> three bf16 planes [3][N][K] (hi, mid, lo) for the split-precision kernels"""
+    require_cuda(w)
+    _f32c(w)
+    N, K = w.shape[0], w.numel() // w.shape[0]
+    planes = torch.empty((3, N, K), device=w.device, dtype=torch.bfloat16)
+    check(_lib.lib().dbmm_split_weight_planes(ptr(w), ptr(planes), N, K, stream()), "split_weight_planes")
+    return planes
+
+
 def gemm(a, w, bias=None, residual=None, act=ACT_NONE, alpha=1.0, trans_a=False, trans_w=False,
-         M=None, N=None, K=None, lda=None, out=None):
+         M=None, N=None, K=None, lda=None, out=None, w_planes=None):
     """c = act(alpha * (op(a) @ op(w)^T + bias) + residual); see dbmm_gemm_bias_act."""
     require_cuda(a, w)
     _f32c(w)
@@ -97,6 +109,12 @@ def gemm(a, w, bias=None, residual=None, act=ACT_NONE, alpha=1.0, trans_a=False,
         out = torch.empty((M, N), device=a.device, dtype=torch.float32)
     ldr = residual.shape[-1] if residual is not None else 0
     ws = igemm_workspace(a.device)
+    if w_planes is not None and not trans_a and not trans_w:
+        with _Timed(M, N, K, 0, 0):
+            check(_lib.lib().dbmm_gemm_bias_act_x3(ptr(a), lda, ptr(w), ptr(w_planes), w.shape[-1], ptr(bias),
+                                                   ptr(residual), ldr, ptr(out), out.shape[-1], M, N, K, float(alpha),
+                                                   act, ptr(ws), ws.numel() * 4, stream()), "gemm_bias_act_x3")
+        return out
     with _Timed(M, N, K, 2 if trans_a else 0, int(trans_w)):
         check(_lib.lib().dbmm_gemm_bias_act_ws(ptr(a), lda, int(trans_a), ptr(w), w.shape[-1], int(trans_w), ptr(bias),
                                                ptr(residual), ldr, ptr(out), out.shape[-1], M, N, K, float(alpha), act,
@@ -122,7 +140,7 @@ def pack_conv_weight(w_oihw, chunk_major=False):
     return w_oihw.permute(0, 2, 3, 1).contiguous().float().reshape(Cout, kh * kw * Cin), WL_TAP_MAJOR
 
 
-def conv_bn_act(x, w, bias, residual, kh, kw, stride, pad, act, w_layout=WL_TAP_MAJOR):
+def conv_bn_act(x, w, bias, residual, kh, kw, stride, pad, act, w_layout=WL_TAP_MAJOR, w_planes=None):
     """x NHWC [B,H,W,Cin]; w packed [Cout][K] (BN folded) in `w_layout` order (default
     [Cout][kh][kw][Cin]; see pack_conv_weight); returns NHWC."""
     require_cuda(x, w)
@@ -135,6 +153,11 @@ def conv_bn_act(x, w, bias, residual, kh, kw, stride, pad, act, w_layout=WL_TAP_
     plain = kh == 1 and kw == 1 and stride == 1 and pad == 0
     with _Timed(B * Ho * Wo, Cout, kh * kw * Cin, 0 if plain else 1, 0):
         ws = igemm_workspace(x.device)
+        if w_planes is not None and w_layout == WL_TAP_MAJOR:
+            check(_lib.lib().dbmm_conv_bn_act_x3(ptr(x), ptr(w), ptr(w_planes), ptr(bias), ptr(residual), ptr(y), B, H, W,
+                                                 Cin, Cout, kh, kw, stride, pad, act, ptr(ws), ws.numel() * 4, stream()),
+                  "conv_bn_act_x3")
+            return y
         check(_lib.lib().dbmm_conv_bn_act_ws(ptr(x), ptr(w), ptr(bias), ptr(residual), ptr(y), B, H, W, Cin, Cout, kh,
                                              kw, stride, pad, act, int(w_layout), ptr(ws), ws.numel() * 4, stream()),
               "conv_bn_act")

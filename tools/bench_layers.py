@@ -51,20 +51,21 @@ def main():
             x = torch.randn(a.batch, H, H, Cin, device=dev)
             w, wl = ops.pack_conv_weight(torch.randn(Cout, Cin, k, k, device=dev) * (Cin * k * k) ** -0.5,
                                          chunk_major=os.environ.get("BENCH_WL") == "1")
+            pl = ops.split_planes(w) if os.environ.get("BENCH_X3") == "1" and wl == 0 else None
             b = torch.randn(Cout, device=dev)
             r = torch.randn(a.batch, H, H, Cout, device=dev) if res else None
             pad = 1 if k == 3 else 0
             for _ in range(2):
-                ops.conv_bn_act(x, w, b, r, k, k, 1, pad, ops.ACT_RELU, wl)
+                ops.conv_bn_act(x, w, b, r, k, k, 1, pad, ops.ACT_RELU, wl, pl)
             ts = []
             for _ in range(a.iters):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record(); ops.conv_bn_act(x, w, b, r, k, k, 1, pad, ops.ACT_RELU, wl); e1.record()
+                e0.record(); ops.conv_bn_act(x, w, b, r, k, k, 1, pad, ops.ACT_RELU, wl, pl); e1.record()
                 torch.cuda.synchronize()
                 ts.append(e0.elapsed_time(e1))
             ts.sort(); ms = ts[len(ts) // 2]
             seen[key] = ms
-            del x, w, r
+            del x, w, r, pl
         M = a.batch * H * H
         fl = 2.0 * M * Cout * Cin * k * k
         by = 4.0 * M * (Cin + Cout * (2 if res else 1))
