@@ -781,6 +781,10 @@ int launch_cfg(IgemmP& p, hipStream_t s, int nbatch, void* ws, size_t ws_bytes) 
     }
     const dim3 grid(p.sk_blocks ? p.sk_blocks : p.n_tiles, nbatch);
     bool launched = false;
+    {
+        const int c[11] = {BM, BN, WM, WN, AMODE, WMODE, BK, MINB, 0, p.sk_blocks ? 1 : 0, 0};
+        for (int i = 0; i < 11; ++i) g_last_cfg[i] = c[i];
+    }
     if constexpr ((AMODE == 0 || AMODE == 1) && WMODE == 0 && BK == 16 && BM == 128 && (BN == 128 || BN == 64)) {
         // split-precision path: needs pre-split weights and the FAST loader's preconditions
         static const int x3_allow = [] { const char* e = getenv("DBMM_IGEMM_X3"); return e ? atoi(e) : 1; }();
@@ -795,7 +799,7 @@ int launch_cfg(IgemmP& p, hipStream_t s, int nbatch, void* ws, size_t ws_bytes) 
                 hipLaunchKernelGGL((igemm_x3_kernel<BM, BN, WM, WN, AMODE, MB, 1>), g3, dim3(256), 0, s, p);
             else
                 hipLaunchKernelGGL((igemm_x3_kernel<BM, BN, WM, WN, AMODE, MB, 0>), g3, dim3(256), 0, s, p);
-            g_last_cfg[8] = 3; g_last_cfg[10] = 0;
+            g_last_cfg[8] = 3; g_last_cfg[9] = p.sk_blocks ? 1 : 0; g_last_cfg[10] = 0;
             DBMM_CHECK_LAUNCH();
             if (p.sk_blocks) {
                 hipLaunchKernelGGL((igemm_fixup_kernel<BM, BN, WM, WN, BK>), dim3(p.sk_blocks - 1), dim3(256), 0, s, p);
@@ -804,10 +808,7 @@ int launch_cfg(IgemmP& p, hipStream_t s, int nbatch, void* ws, size_t ws_bytes) 
             return DBMM_OK;
         }
     }
-    {
-        const int c[11] = {BM, BN, WM, WN, AMODE, WMODE, BK, MINB, 0, p.sk_blocks ? 1 : 0, 0};
-        for (int i = 0; i < 11; ++i) g_last_cfg[i] = c[i];
-    }
+
     if constexpr (AMODE != 2 && WMODE == 0) {
         if (fast_ok<AMODE, WMODE, BK>(p)) {
             static const int dma = [] { const char* e = getenv("DBMM_IGEMM_DMA"); return e ? atoi(e) : 1; }();

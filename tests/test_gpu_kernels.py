@@ -315,3 +315,46 @@ def test_gemm_streamk_split_shapes():
     outc = ops.conv_bn_act(x.permute(0, 2, 3, 1).contiguous().to(DEV), wc.permute(0, 2, 3, 1).contiguous().to(DEV),
                            None, None, 3, 3, 1, 1, ops.ACT_RELU)
     assert relerr(outc.cpu(), refc) < 2e-5
+
+
+X3_SHAPES = [(512, 256, 1024), (1000, 128, 64), (300, 64, 576), (25088, 512, 1152), (130, 192, 48)]
+
+
+@pytest.mark.parametrize("M,N,K", X3_SHAPES)
+def test_gemm_split_precision(M, N, K):
+    """three-bf16-plane operands, six partial products: fp32-level accuracy (checked against an
+    fp64 reference, and no worse than the fp32-MFMA kernel), incl. a stream-K shape."""
+    a = rnd(1, "a", (M, K)); w = rnd(2, "w", (N, K), K ** -0.5); b = rnd(3, "b", (N,)); r = rnd(4, "r", (M, N))
+    ref = torch.relu(a.double() @ w.double().t() + b.double() + r.double())
+    ad, wd, bd, rd = a.to(DEV), w.to(DEV), b.to(DEV), r.to(DEV)
+    planes = ops.split_planes(wd)
+    assert planes.shape == (3, N, K) and planes.dtype == torch.bfloat16
+    # the three planes sum back to the fp32 weight exactly
+    assert torch.equal(planes.float().sum(0), wd) or relerr(planes.double().sum(0).cpu(), w.double()) < 1e-9
+    o3 = ops.gemm(ad, wd, bd, residual=rd, act=ops.ACT_RELU, w_planes=planes)
+    o32 = ops.gemm(ad, wd, bd, residual=rd, act=ops.ACT_RELU)
+    e3, e32 = relerr(o3.cpu().double(), ref), relerr(o32.cpu().double(), ref)
+    assert e3 < 5e-6 and e3 < 5 * e32 + 5e-7, (e3, e32)
+
+
+@pytest.mark.parametrize("B,H,Cin,Cout,k", [(2, 16, 32, 128, 3), (3, 14, 64, 64, 3), (2, 9, 16, 48, 3),
+                                            (4, 7, 512, 256, 3), (128, 14, 256, 256, 3), (2, 12, 64, 256, 1)])
+def test_conv_split_precision(B, H, Cin, Cout, k):
+    x = rnd(1, "x", (B, Cin, H, H)); w = rnd(2, "w", (Cout, Cin, k, k), (Cin * k * k) ** -0.5); b = rnd(3, "b", (Cout,), 0.1)
+    ref = torch.relu(F.conv2d(x.double(), w.double(), b.double(), padding=k // 2)).permute(0, 2, 3, 1)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    wp, wl = ops.pack_conv_weight(w.to(DEV))
+    planes = ops.split_planes(wp)
+    o3 = ops.conv_bn_act(xd, wp, b.to(DEV), None, k, k, 1, k // 2, ops.ACT_RELU, wl, planes)
+    o32 = ops.conv_bn_act(xd, wp, b.to(DEV), None, k, k, 1, k // 2, ops.ACT_RELU, wl)
+    e3, e32 = relerr(o3.cpu().double(), ref), relerr(o32.cpu().double(), ref)
+    assert e3 < 5e-6 and e3 < 5 * e32 + 5e-7, (e3, e32)
+
+
+def test_split_precision_falls_back_when_ineligible():
+    """K % 16 != 0 -> the library runs the fp32-MFMA kernel even when planes are given"""
+    M, N, K = 200, 136, 588
+    a = rnd(1, "a", (M, K)); w = rnd(2, "w", (N, K), K ** -0.5)
+    planes = ops.split_planes(w.to(DEV))
+    out = ops.gemm(a.to(DEV), w.to(DEV), w_planes=planes)
+    assert relerr(out.cpu(), a @ w.t()) < 2e-5
