@@ -65,7 +65,7 @@ _SIGS = {
     "dbmm_gemm_bias_act_ws": [_P, _L, _I, _P, _L, _I, _P, _P, _L, _P, _L, _L, _L, _L, _F, _I, _P, _Z, _P],
     "dbmm_split_planes_bytes": [_L, _L],
     "dbmm_split_weight_planes": [_P, _P, _L, _L, _P],
-    "dbmm_conv_bn_act_x3": [_P, _P, _P, _P, _P, _P, _L, _L, _L, _L, _L, _L, _L, _L, _L, _I, _P, _Z, _P],
+    "dbmm_conv_bn_act_x3": [_P, _P, _P, _P, _P, _P, _L, _L, _L, _L, _L, _L, _L, _L, _L, _I, _I, _P, _Z, _P],
     "dbmm_gemm_bias_act_x3": [_P, _L, _P, _P, _L, _P, _P, _L, _P, _L, _L, _L, _L, _F, _I, _P, _Z, _P],
     "dbmm_gemm_batched": [_P, _L, _L, _I, _P, _L, _L, _I, _P, _L, _P, _L, _L, _L, _L, _L, _L, _F, _I, _P],
     "dbmm_conv_stem_s2": [_P, _P, _P, _P, _L, _L, _L, _L, _P],

@@ -538,8 +538,13 @@ __device__ __forceinline__ void igemm_tile_x3(const IgemmP& p, float* lds, int t
         }
     }
     if constexpr (AMODE == 1) {
-        const int k = kb * BK;
-        f_tap = k / p.Cin; f_ci0 = k - f_tap * p.Cin;
+        if (p.wl == DBMM_WL_CHUNK_MAJOR) {       // K = (cin/16, kh, kw, 16): taps cycle fastest
+            const int taps = p.KH * p.KW;
+            f_tap = kb % taps; f_ci0 = (kb / taps) * 16;
+        } else {
+            const int k = kb * BK;
+            f_tap = k / p.Cin; f_ci0 = k - f_tap * p.Cin;
+        }
         f_kh = f_tap / p.KW; f_kw = f_tap - f_kh * p.KW;
     }
 
@@ -558,10 +563,16 @@ __device__ __forceinline__ void igemm_tile_x3(const IgemmP& p, float* lds, int t
 #pragma unroll
             for (int i = 0; i < ALD; ++i)
                 a_reg[i] = buf_load16(rsA, (fa_mask[i] & bit) ? fa_off[i] + delta : OOR, 0u);
-            f_ci0 += BK;
-            if (f_ci0 == p.Cin) {
-                f_ci0 = 0; ++f_tap;
+            if (p.wl == DBMM_WL_CHUNK_MAJOR) {
+                ++f_tap;
                 if (++f_kw == p.KW) { f_kw = 0; ++f_kh; }
+                if (f_tap == p.KH * p.KW) { f_tap = 0; f_kh = 0; f_kw = 0; f_ci0 += 16; }
+            } else {
+                f_ci0 += BK;
+                if (f_ci0 == p.Cin) {
+                    f_ci0 = 0; ++f_tap;
+                    if (++f_kw == p.KW) { f_kw = 0; ++f_kh; }
+                }
             }
         }
 #pragma unroll
@@ -928,7 +939,7 @@ int conv_impl(const float* x, const float* w, const float* bias, const float* re
     p.H = (int)H; p.W = (int)W; p.Cin = (int)Cin; p.Ho = (int)Ho; p.Wo = (int)Wo;
     p.KH = (int)KH; p.KW = (int)KW; p.stride = (int)stride; p.pad = (int)pad; p.wl = w_layout;
     set_extents(p, B * H * W * Cin * 4, Cout * K * 4);
-    if (w_layout == DBMM_WL_TAP_MAJOR) set_planes(p, w3, Cout, K);
+    set_planes(p, w3, Cout, K);   // planes carry the same K order as `w`
     hipStream_t s = (hipStream_t)stream;
     if (KH == 1 && KW == 1 && stride == 1 && pad == 0) return launch_modes<0, 0>(p, s, 1, ws, wsb);  // plain GEMM
     return launch_modes<1, 0>(p, s, 1, ws, wsb);
@@ -1018,8 +1029,8 @@ extern "C" int dbmm_split_weight_planes(const float* w, void* planes, int64_t N,
 extern "C" int dbmm_conv_bn_act_x3(const float* x, const float* w, const void* w_planes, const float* bias,
                                    const float* residual, float* y, int64_t B, int64_t H, int64_t W, int64_t Cin,
                                    int64_t Cout, int64_t KH, int64_t KW, int64_t stride, int64_t pad, int act,
-                                   void* workspace, size_t workspace_bytes, void* stream) {
-    return conv_impl(x, w, bias, residual, y, B, H, W, Cin, Cout, KH, KW, stride, pad, act, DBMM_WL_TAP_MAJOR, workspace,
+                                   int w_layout, void* workspace, size_t workspace_bytes, void* stream) {
+    return conv_impl(x, w, bias, residual, y, B, H, W, Cin, Cout, KH, KW, stride, pad, act, w_layout, workspace,
                      workspace_bytes, stream, w_planes);
 }
 

@@ -153,10 +153,10 @@ def conv_bn_act(x, w, bias, residual, kh, kw, stride, pad, act, w_layout=WL_TAP_
     plain = kh == 1 and kw == 1 and stride == 1 and pad == 0
     with _Timed(B * Ho * Wo, Cout, kh * kw * Cin, 0 if plain else 1, 0):
         ws = igemm_workspace(x.device)
-        if w_planes is not None and w_layout == WL_TAP_MAJOR:
+        if w_planes is not None:
             check(_lib.lib().dbmm_conv_bn_act_x3(ptr(x), ptr(w), ptr(w_planes), ptr(bias), ptr(residual), ptr(y), B, H, W,
-                                                 Cin, Cout, kh, kw, stride, pad, act, ptr(ws), ws.numel() * 4, stream()),
-                  "conv_bn_act_x3")
+                                                 Cin, Cout, kh, kw, stride, pad, act, int(w_layout), ptr(ws),
+                                                 ws.numel() * 4, stream()), "conv_bn_act_x3")
             return y
         check(_lib.lib().dbmm_conv_bn_act_ws(ptr(x), ptr(w), ptr(bias), ptr(residual), ptr(y), B, H, W, Cin, Cout, kh,
                                              kw, stride, pad, act, int(w_layout), ptr(ws), ws.numel() * 4, stream()),

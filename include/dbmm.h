@@ -96,14 +96,14 @@ int dbmm_gemm_bias_act_ws(const float* a, int64_t lda, int trans_a, const float*
  * matrix cores (2.67x the fp32-MFMA rate, dropped terms <= 2^-24 relative = fp32-level accuracy).
  * w_planes = the weight split once by dbmm_split_weight_planes ([3][N][K] bf16,
  * dbmm_split_planes_bytes(N, K) bytes); activations stay fp32 and are split on the fly.  `w`
- * (fp32, (kh,kw,cin) order) is still required: shapes the split kernel does not cover (K or Cin
+ * (fp32, same K order as the planes, see w_layout) is still required: shapes the split kernel does not cover (K or Cin
  * not a multiple of 16, N <= 32, operands >= 2 GiB) run on the fp32-MFMA kernel. */
 size_t dbmm_split_planes_bytes(int64_t N, int64_t K);
 int dbmm_split_weight_planes(const float* w, void* planes, int64_t N, int64_t K, void* stream);
 int dbmm_conv_bn_act_x3(const float* x, const float* w, const void* w_planes, const float* bias,
                         const float* residual, float* y, int64_t B, int64_t H, int64_t W, int64_t Cin,
                         int64_t Cout, int64_t KH, int64_t KW, int64_t stride, int64_t pad, int act,
-                        void* workspace, size_t workspace_bytes, void* stream);
+                        int w_layout, void* workspace, size_t workspace_bytes, void* stream);
 int dbmm_gemm_bias_act_x3(const float* a, int64_t lda, const float* w, const void* w_planes, int64_t ldw,
                           const float* bias, const float* residual, int64_t ldr, float* c, int64_t ldc,
                           int64_t M, int64_t N, int64_t K, float alpha, int act, void* workspace,

@@ -51,7 +51,7 @@ def main():
             x = torch.randn(a.batch, H, H, Cin, device=dev)
             w, wl = ops.pack_conv_weight(torch.randn(Cout, Cin, k, k, device=dev) * (Cin * k * k) ** -0.5,
                                          chunk_major=os.environ.get("BENCH_WL") == "1")
-            pl = ops.split_planes(w) if os.environ.get("BENCH_X3") == "1" and wl == 0 else None
+            pl = ops.split_planes(w) if os.environ.get("BENCH_X3") == "1" else None
             b = torch.randn(Cout, device=dev)
             r = torch.randn(a.batch, H, H, Cout, device=dev) if res else None
             pad = 1 if k == 3 else 0
