@@ -42,12 +42,15 @@ from dbmm_amd import adapter, dp, ops, optim, synth  # noqa: E402
 from dbmm_amd.clip.model import build_model  # noqa: E402
 
 FP32_MFMA_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md, chip table (v_mfma_f32_32x32x2_f32)
-BF16_MFMA_PEAK_TFLOPS = 2500.0         # dense bf16 MFMA, same table
-X3_PRODUCTS = 6                        # bf16 x bf16 partial products the split-precision kernel issues per fp32 product
+F16_MFMA_PEAK_TFLOPS = 2500.0          # dense fp16 MFMA, same table (same rate as bf16)
+# 16-bit partial products a split-precision kernel issues per fp32 product, by plane count
+SPLIT_PRODUCTS = {2: 3, 3: 6}
 RN50_GFLOP_PER_IMG = 11.59             # SURVEY.md section 8d (conv 5.367 + attn-pool 0.426 GMAC)
 # dominant kernel: 3x3 implicit-GEMM conv, 128x128 tile, one tile per workgroup
-DOMINANT_X3 = "igemm_x3_kernel<128, 128, 2, 2, 1, 2, 0>"                   # split-precision path (default)
-DOMINANT_F32 = "igemm_f32_kernel<128, 128, 2, 2, 1, 0, 16, 4, 1, 0, 1>"    # fp32-MFMA path (DBMM_IGEMM_X3=0)
+# (template arguments <BM, BN, WAVES_M, WAVES_N, AMODE=1 (conv), MINB, SK=0, NP>; NP = 2: fp16 pair, 3: bf16 triple)
+DOMINANT_SPLIT = ("igemm_x3_kernel<128, 128, 2, 2, 1, 2, 0, 2>",            # default path
+                  "igemm_x3_kernel<128, 128, 2, 2, 1, 2, 0, 3>")            # DBMM_CONV_SPLIT=bf16
+DOMINANT_F32 = "igemm_f32_kernel<128, 128, 2, 2, 1, 0, 16, 4, 1, 0, 1>"    # fp32-MFMA path (DBMM_CONV_SPLIT=off)
 
 
 def write_text_jsons(D):
@@ -177,9 +180,10 @@ def main():
 
     if rank == 0:
         value = B * args.steps / dt
-        DOMINANT = DOMINANT_X3 if DOMINANT_X3 in prof else DOMINANT_F32
-        split = DOMINANT == DOMINANT_X3
-        peak = BF16_MFMA_PEAK_TFLOPS / X3_PRODUCTS if split else FP32_MFMA_PEAK_TFLOPS
+        DOMINANT = next((k for k in DOMINANT_SPLIT if k in prof), DOMINANT_F32)
+        split = DOMINANT in DOMINANT_SPLIT
+        n_prod = SPLIT_PRODUCTS[int(DOMINANT.rstrip(">").split(",")[-1])] if split else 1
+        peak = F16_MFMA_PEAK_TFLOPS / n_prod if split else FP32_MFMA_PEAK_TFLOPS
         n, fl, ms = prof.get(DOMINANT, (0, 0.0, 0.0))
         ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         traffic = None          # HBM-side bytes per launch of the dominant kernel from the committed PMC passes
@@ -202,9 +206,9 @@ def main():
             "roofline": {"bound": "mfma", "kernel": DOMINANT, "achieved": round(ach, 2),
                          "peak": round(peak, 1), "unit": "TFLOP/s",
                          "frac": round(ach / peak, 4), "traffic": traffic,
-                         "peak_basis": ("dense bf16 MFMA 2500 TFLOP/s / 6 partial products per fp32 product"
+                         "peak_basis": (f"dense 16-bit MFMA 2500 TFLOP/s / {n_prod} partial products per fp32 product"
                                         if split else "fp32-input MFMA 157.3 TFLOP/s"),
-                         "executed_mfma_tflops": round(ach * (X3_PRODUCTS if split else 1), 1),
+                         "executed_mfma_tflops": round(ach * n_prod, 1),
                          "achieved_over_fp32_mfma_peak": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
                          "launches": n, "avg_launch_ms": round(ms / n, 4) if n else None,
                          "flops_per_launch_avg": fl / n if n else None,

@@ -66,6 +66,9 @@ _SIGS = {
     "dbmm_split_planes_bytes": [_L, _L],
     "dbmm_split_weight_planes": [_P, _P, _L, _L, _P],
     "dbmm_conv_bn_act_x3": [_P, _P, _P, _P, _P, _P, _L, _L, _L, _L, _L, _L, _L, _L, _L, _I, _I, _P, _Z, _P],
+    "dbmm_split_planes_f16_bytes": [_L, _L],
+    "dbmm_split_weight_planes_f16": [_P, _P, _L, _L, _I, _P],
+    "dbmm_conv_bn_act_x2": [_P, _P, _P, _P, _I, _P, _P, _P, _P, _L, _L, _L, _L, _L, _L, _L, _L, _L, _I, _I, _P, _Z, _P],
     "dbmm_gemm_bias_act_x3": [_P, _L, _P, _P, _L, _P, _P, _L, _P, _L, _L, _L, _L, _F, _I, _P, _Z, _P],
     "dbmm_gemm_batched": [_P, _L, _L, _I, _P, _L, _L, _I, _P, _L, _P, _L, _L, _L, _L, _L, _L, _F, _I, _P],
     "dbmm_conv_stem_s2": [_P, _P, _P, _P, _L, _L, _L, _L, _P],
@@ -98,6 +101,7 @@ _RESTYPES = {
     "dbmm_workspace_bytes_attnpool": c_size_t,
     "dbmm_workspace_bytes_igemm": c_size_t,
     "dbmm_split_planes_bytes": c_size_t,
+    "dbmm_split_planes_f16_bytes": c_size_t,
     "dbmm_debug_last_igemm": None,
     "dbmm_workspace_bytes_adapter_bwd": c_size_t,
     "dbmm_workspace_bytes_adapter_train_step": c_size_t,

@@ -13,6 +13,7 @@ C ABI (ops.py).  Activations are fp32 NHWC / batch-first tokens.  Compute dtype 
 (fp32-input MFMA), which is what the 1e-3 logit parity against the reference's CPU path
 needs; there is no fp16 cast of the weights, `.dtype` reports float32.
 """
+import os
 from collections import OrderedDict
 from typing import Tuple, Union
 
@@ -107,13 +108,24 @@ def _fold_bn(conv_w, bn):
     return w, b
 
 
-def _pack_conv(w64):
-    """[Cout][Cin][kh][kw] fp64 (BN folded) -> (packed fp32 weight, layout id, bf16 planes or None)
-    for ops.conv_bn_act.  The planes feed the split-precision kernel (three bf16 values per fp32
-    weight); shapes it does not cover fall back to the fp32-MFMA kernel inside the library."""
+# how the conv weights are split for the matrix cores: "f16" = fp16 pair + per-tensor power-of-two
+# scales (three partial products), "bf16" = bf16 triple (six), "off" = fp32-input MFMA only.
+# All three are fp32-accurate; the switch exists for ablation runs.
+CONV_SPLIT = os.environ.get("DBMM_CONV_SPLIT", "f16")
+
+
+def _pack_conv(w64, bias):
+    """[Cout][Cin][kh][kw] fp64 (BN folded) -> dict of ops.conv_bn_act operands: packed fp32 weight,
+    layout id, bias, and the pre-split planes for the split-precision kernels (shapes those do not
+    cover fall back to the fp32-MFMA kernel inside the library)."""
     w, wl = ops.pack_conv_weight(w64)
-    planes = ops.split_planes(w) if (w.is_cuda and w.shape[0] > 32 and w.shape[1] % 16 == 0) else None
-    return w, wl, planes
+    c = dict(w=w, wl=wl, b=bias.float().contiguous(), p3=None, ph=None, we=0)
+    if w.is_cuda and w.shape[0] > 32 and w.shape[1] % 16 == 0:
+        if CONV_SPLIT == "f16":
+            c["ph"], c["we"] = ops.split_planes_f16(w)
+        elif CONV_SPLIT == "bf16":
+            c["p3"] = ops.split_planes(w)
+    return c
 
 
 class ModifiedResNet(nn.Module):
@@ -150,17 +162,17 @@ class ModifiedResNet(nn.Module):
         P["stem1"] = (w.permute(2, 3, 1, 0).contiguous().float(), b.float().contiguous())   # [kh][kw][cin][cout]
         for i in (2, 3):
             w, b = _fold_bn(getattr(self, f"conv{i}").weight, getattr(self, f"bn{i}"))
-            P[f"stem{i}"] = _pack_conv(w) + (b.float().contiguous(),)
+            P[f"stem{i}"] = _pack_conv(w, b)
         blocks = []
         for li in (1, 2, 3, 4):
             for blk in getattr(self, f"layer{li}"):
                 e = {"stride": blk.stride}
                 for i in (1, 2, 3):
                     w, b = _fold_bn(getattr(blk, f"conv{i}").weight, getattr(blk, f"bn{i}"))
-                    e[f"c{i}"] = _pack_conv(w) + (b.float().contiguous(),)
+                    e[f"c{i}"] = _pack_conv(w, b)
                 if blk.downsample is not None:
                     w, b = _fold_bn(getattr(blk.downsample, "0").weight, getattr(blk.downsample, "1"))
-                    e["ds"] = _pack_conv(w) + (b.float().contiguous(),)
+                    e["ds"] = _pack_conv(w, b)
                 blocks.append(e)
         P["blocks"] = blocks
         ap = self.attnpool
@@ -178,26 +190,37 @@ class ModifiedResNet(nn.Module):
         P = self._plan or self._compile()
         x = x.float().contiguous()                      # NCHW image at the boundary
         x = ops.conv_stem_s2(x, *P["stem1"])            # -> NHWC from here on
-        conv = lambda t, c, res, k, pad, act: ops.conv_bn_act(t, c[0], c[3], res, k, k, 1, pad, act, c[1], c[2])
-        x = conv(x, P["stem2"], None, 3, 1, ops.ACT_RELU)
-        x = conv(x, P["stem3"], None, 3, 1, ops.ACT_RELU)
+        # One device scalar per conv output: its epilogue leaves max|y| there and the consumer
+        # derives its fp16 scale from it (an average pool passes its input's bound on).
+        n_slots = 2 + 4 * len(P["blocks"])
+        amax = torch.zeros(n_slots, device=x.device, dtype=torch.float32)
+        slot = [0]
+
+        def conv(t, t_am, c, res, k, pad, act):
+            y_am = amax[slot[0]:slot[0] + 1]; slot[0] += 1
+            y = ops.conv_bn_act(t, c["w"], c["b"], res, k, k, 1, pad, act, c["wl"], w_planes=c["p3"],
+                                w_planes_f16=c["ph"], w_exp=c["we"], x_absmax=t_am, y_absmax=y_am)
+            return y, y_am
+
+        x, am = conv(x, None, P["stem2"], None, 3, 1, ops.ACT_RELU)
+        x, am = conv(x, am, P["stem3"], None, 3, 1, ops.ACT_RELU)
         x = ops.avgpool2d(x, 2)
         stages = {"stem": x}
         bi = 0
         for li in (1, 2, 3, 4):
             for _ in getattr(self, f"layer{li}"):
                 e = P["blocks"][bi]; bi += 1
-                out = conv(x, e["c1"], None, 1, 0, ops.ACT_RELU)
-                out = conv(out, e["c2"], None, 3, 1, ops.ACT_RELU)
+                out, oam = conv(x, am, e["c1"], None, 1, 0, ops.ACT_RELU)
+                out, oam = conv(out, oam, e["c2"], None, 3, 1, ops.ACT_RELU)
                 if e["stride"] > 1:
                     out = ops.avgpool2d(out, e["stride"])
                 identity = x
                 if "ds" in e:
                     if e["stride"] > 1:
                         identity = ops.avgpool2d(x, e["stride"])
-                    identity = conv(identity, e["ds"], None, 1, 0, ops.ACT_NONE)
+                    identity, _ = conv(identity, am, e["ds"], None, 1, 0, ops.ACT_NONE)
                 # conv3 + bn3, residual add and the final ReLU fused into one epilogue
-                x = conv(out, e["c3"], identity, 1, 0, ops.ACT_RELU)
+                x, am = conv(out, oam, e["c3"], identity, 1, 0, ops.ACT_RELU)
             stages[f"layer{li}"] = x
         a = P["attn"]
         out = ops.attnpool(x, a["pos"], a["wq"], a["bq"], a["wkv"], a["bkv"], a["wc"], a["bc"], self.attnpool.num_heads)

@@ -66,7 +66,25 @@ struct IgemmP {
     float* sk_ws;                       // stream-K: [sk_blocks][2][BM*BN] partial accumulators
     const unsigned short* w3;           // split path: W as three bf16 planes [3][N][ldw]
     unsigned w3_bytes;
+    const unsigned short* wh;           // fp16-pair path: W * 2^w_exp as two fp16 planes [2][N][ldw]
+    unsigned wh_bytes;
+    int w_exp;
+    const float* a_absmax;              // fp16-pair path: device scalar >= max|A| (null: path not in use)
+    float* absmax_out;                  // optional device scalar: atomic max of |C| over the written outputs
 };
+
+// fp16-pair path: A is scaled by 2^s so that max|A| * 2^s lies in [2^13, 2^14) (fp16 tops out at
+// 65504; the fp32 accumulator is rescaled by 2^-(s + w_exp) in the epilogue -- powers of two,
+// so the scaling itself is exact).
+__device__ __forceinline__ int a_scale_exp(const float* a_absmax) {
+    const unsigned b = __float_as_uint(*a_absmax) & 0x7fffffffu;
+    int s = b ? 13 - ((int)(b >> 23) - 127) : 0;
+    return s < -60 ? -60 : (s > 60 ? 60 : s);
+}
+__device__ __forceinline__ float pow2f(int e) { return __uint_as_float((unsigned)(e + 127) << 23); }
+__device__ __forceinline__ float igemm_acc_scale(const IgemmP& p) {
+    return p.a_absmax ? pow2f(-a_scale_exp(p.a_absmax) - p.w_exp) : 1.f;
+}
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr unsigned OOR = 0x80000000u;   // >= any accepted extent, and OOR + (K offset) cannot wrap
@@ -461,6 +479,7 @@ __device__ __forceinline__ void igemm_tile(const IgemmP& p, float* lds, int tile
                 for (int r = 0; r < 16; ++r) partial[((i * TN + j) * 16 + r) * 256 + tid] = acc[i][j][r];
         return;
     }
+    const float acc_scale = igemm_acc_scale(p);   // 1 unless this is the fix-up of an fp16-pair launch
     {
 #include "igemm_epilogue.inc"
     }
@@ -478,6 +497,7 @@ __device__ __forceinline__ void igemm_tile(const IgemmP& p, float* lds, int tile
 // 16-B chunk index XOR (row >> 3) & 1 -> conflict-free ds_read_b128 fragment reads.
 // ---------------------------------------------------------------------------------------------
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned short u16;
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
@@ -490,20 +510,31 @@ __device__ __forceinline__ void split3(float x, u16& hi, u16& mid, u16& lo) {
     hi = __builtin_bit_cast(u16, h); mid = __builtin_bit_cast(u16, m); lo = __builtin_bit_cast(u16, l);
 }
 
-template <int BM, int BN>
-struct GeoX3 {   // LDS floats for the split path (bf16 planes, two stages) vs the epilogue staging
-    static constexpr int STAGE_U16 = 3 * (BM + BN) * 16;
+// fp16-pair variant (NP = 2): with per-tensor power-of-two scaling an fp32 value is hi + lo of
+// two fp16 values to 2^-22 relative (abs floor 2^-39 of the tensor maximum), so THREE products
+// (hl, lh, hh) on v_mfma_f32_32x32x16_f16 reach the accuracy the six bf16 products do -- half
+// the MFMA work, a third less LDS traffic and half the split arithmetic.  It needs an upper
+// bound of max|A| on the device (p.a_absmax, written by the producing launch's epilogue).
+__device__ __forceinline__ void split2h(float xs, u16& hi, u16& lo) {
+    const _Float16 h = (_Float16)xs;
+    const _Float16 l = (_Float16)(xs - (float)h);
+    hi = __builtin_bit_cast(u16, h); lo = __builtin_bit_cast(u16, l);
+}
+
+template <int BM, int BN, int NP>
+struct GeoX3 {   // LDS floats for the split path (NP 16-bit planes, two stages) vs the epilogue staging
+    static constexpr int STAGE_U16 = NP * (BM + BN) * 16;
     static constexpr int TILE_FLOATS = 2 * STAGE_U16 / 2;
 };
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int AMODE>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int AMODE, int NP>
 __device__ __forceinline__ void igemm_tile_x3(const IgemmP& p, float* lds, int tile, int kb, int ke, float* partial) {
     constexpr int BK = 16;
     using G = Geo<BM, BN, WAVES_M, WAVES_N, BK>;
     constexpr int TM = G::TM, TN = G::TN, WTN = G::WTN, LROW = G::LROW;
     constexpr int ALD = BM / 64;                  // float4 loads per thread per chunk (64 rows x 4 k-quads per pass)
-    constexpr int STAGE = GeoX3<BM, BN>::STAGE_U16;
-    u16* Ap = (u16*)lds;                           // [2][3][BM][16] then [2][3][BN][16] per stage
+    constexpr int STAGE = GeoX3<BM, BN, NP>::STAGE_U16;
+    u16* Ap = (u16*)lds;                           // per stage: [NP][BM][16] then [NP][BN][16]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m0 = (tile / p.tiles_n) * BM, n0 = (tile % p.tiles_n) * BN;
     const int wm0 = (wave / WAVES_N) * (TM * 32), wn0 = (wave % WAVES_N) * (TN * 32);
@@ -513,7 +544,10 @@ __device__ __forceinline__ void igemm_tile_x3(const IgemmP& p, float* lds, int t
     unsigned fa_off[ALD], fa_mask[ALD];
     int f_ci0 = 0, f_kh = 0, f_kw = 0, f_tap = 0;
     __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.a, 0, (int)p.a_bytes, 0x00020000);
-    __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.w3, 0, (int)p.w3_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)(NP == 3 ? p.w3 : p.wh), 0,
+                                                                   (int)(NP == 3 ? p.w3_bytes : p.wh_bytes), 0x00020000);
+    float a_sc = 1.f;
+    if constexpr (NP == 2) a_sc = pow2f(a_scale_exp(p.a_absmax));
     const unsigned plane_bytes = (unsigned)p.N * (unsigned)p.ldw * 2u;
     const unsigned fw_off = (wr < BN && n0 + wr < p.N) ? ((unsigned)(n0 + wr) * (unsigned)p.ldw + wc * 8u) * 2u : OOR;
 #pragma unroll
@@ -552,8 +586,8 @@ __device__ __forceinline__ void igemm_tile_x3(const IgemmP& p, float* lds, int t
     // (already landed) is split into LDS -- each chunk's MFMA phase is only 768 cycles per wave,
     // one chunk of lead did not cover the L2 / Infinity-Cache latency (ablation: 31 % of the time)
     f32x4 a_r0[ALD], a_r1[ALD];
-    u32x4 w_r0[3], w_r1[3];
-    auto load_chunk = [&](int k0, f32x4 (&a_reg)[ALD], u32x4 (&w_reg)[3]) {
+    u32x4 w_r0[NP], w_r1[NP];
+    auto load_chunk = [&](int k0, f32x4 (&a_reg)[ALD], u32x4 (&w_reg)[NP]) {
         if constexpr (AMODE == 0) {
 #pragma unroll
             for (int i = 0; i < ALD; ++i) a_reg[i] = buf_load16(rsA, fa_off[i], (unsigned)k0 * 4u);
@@ -576,27 +610,31 @@ __device__ __forceinline__ void igemm_tile_x3(const IgemmP& p, float* lds, int t
             }
         }
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
+        for (int pl = 0; pl < NP; ++pl)
             w_reg[pl] = __builtin_amdgcn_raw_buffer_load_b128(rsW, fw_off, pl * plane_bytes + (unsigned)k0 * 2u, 0);
     };
-    auto store_chunk = [&](int stage, const f32x4 (&a_reg)[ALD], const u32x4 (&w_reg)[3]) {
-        u16* Ab = Ap + stage * STAGE;              // planes [3][BM][16]
-        u16* Wb = Ab + 3 * BM * 16;                // planes [3][BN][16]
+    auto store_chunk = [&](int stage, const f32x4 (&a_reg)[ALD], const u32x4 (&w_reg)[NP]) {
+        u16* Ab = Ap + stage * STAGE;              // planes [NP][BM][16]
+        u16* Wb = Ab + NP * BM * 16;               // planes [NP][BN][16]
 #pragma unroll
         for (int i = 0; i < ALD; ++i) {
             const int row = lr + 64 * i;
             u16 h[4], m[4], l[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) split3(a_reg[i][j], h[j], m[j], l[j]);
+            for (int j = 0; j < 4; ++j) {
+                if constexpr (NP == 3) split3(a_reg[i][j], h[j], m[j], l[j]);
+                else split2h(a_reg[i][j] * a_sc, h[j], m[j]);
+            }
             const int off = row * 16 + ((((lc >> 1) ^ ((row >> 3) & 1))) << 3) + ((lc & 1) << 2);
             *(u32x2*)(Ab + 0 * BM * 16 + off) = (u32x2){(unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16)};
             *(u32x2*)(Ab + 1 * BM * 16 + off) = (u32x2){(unsigned)m[0] | ((unsigned)m[1] << 16), (unsigned)m[2] | ((unsigned)m[3] << 16)};
-            *(u32x2*)(Ab + 2 * BM * 16 + off) = (u32x2){(unsigned)l[0] | ((unsigned)l[1] << 16), (unsigned)l[2] | ((unsigned)l[3] << 16)};
+            if constexpr (NP == 3)
+                *(u32x2*)(Ab + 2 * BM * 16 + off) = (u32x2){(unsigned)l[0] | ((unsigned)l[1] << 16), (unsigned)l[2] | ((unsigned)l[3] << 16)};
         }
         if (wr < BN) {
             const int off = wr * 16 + ((wc ^ ((wr >> 3) & 1)) << 3);
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) *(u32x4*)(Wb + pl * BN * 16 + off) = w_reg[pl];
+            for (int pl = 0; pl < NP; ++pl) *(u32x4*)(Wb + pl * BN * 16 + off) = w_reg[pl];
         }
     };
 
@@ -613,24 +651,33 @@ __device__ __forceinline__ void igemm_tile_x3(const IgemmP& p, float* lds, int t
 
     auto compute = [&](int stage) {
         const u16* Ab = Ap + stage * STAGE;
-        const u16* Wb = Ab + 3 * BM * 16;
-        bf16x8 af[TM][3], wf[TN][3];
+        const u16* Wb = Ab + NP * BM * 16;
+        u32x4 af[TM][NP], wf[TN][NP];
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) {
+        for (int pl = 0; pl < NP; ++pl) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) af[i][pl] = *(const bf16x8*)(Ab + pl * BM * 16 + (wm0 + i * 32 + fr) * 16 + fch);
+            for (int i = 0; i < TM; ++i) af[i][pl] = *(const u32x4*)(Ab + pl * BM * 16 + (wm0 + i * 32 + fr) * 16 + fch);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) wf[j][pl] = *(const bf16x8*)(Wb + pl * BN * 16 + (wn0 + j * 32 + fr) * 16 + fch);
+            for (int j = 0; j < TN; ++j) wf[j][pl] = *(const u32x4*)(Wb + pl * BN * 16 + (wn0 + j * 32 + fr) * 16 + fch);
         }
-        // smallest partial products first: (h,l) (l,h) (m,m) (h,m) (m,h) (h,h)
+        // smallest partial products first: bf16 (h,l) (l,h) (m,m) (h,m) (m,h) (h,h); fp16 (h,l) (l,h) (h,h)
+        constexpr int NQ = NP == 3 ? 6 : 3;
 #pragma unroll
-        for (int q = 0; q < 6; ++q) {
-            constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
+        for (int q = 0; q < NQ; ++q) {
+            constexpr int PA3[6] = {0, 2, 1, 0, 1, 0}, PB3[6] = {2, 0, 1, 1, 0, 0};
+            constexpr int PA2[3] = {0, 1, 0}, PB2[3] = {1, 0, 0};
+            const int pa = NP == 3 ? PA3[q] : PA2[q], pb = NP == 3 ? PB3[q] : PB2[q];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PA[q]], wf[j][PB[q]], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < TN; ++j) {
+                    if constexpr (NP == 3)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[i][pa]),
+                                                                            __builtin_bit_cast(bf16x8, wf[j][pb]), acc[i][j], 0, 0, 0);
+                    else
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[i][pa]),
+                                                                           __builtin_bit_cast(f16x8, wf[j][pb]), acc[i][j], 0, 0, 0);
+                }
         }
     };
 
@@ -662,19 +709,20 @@ __device__ __forceinline__ void igemm_tile_x3(const IgemmP& p, float* lds, int t
                 for (int r = 0; r < 16; ++r) partial[((i * TN + j) * 16 + r) * 256 + tid] = acc[i][j][r];
         return;
     }
+    const float acc_scale = NP == 2 ? igemm_acc_scale(p) : 1.f;
     {
 #include "igemm_epilogue.inc"
     }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int AMODE, int MINB, int SK>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int AMODE, int MINB, int SK, int NP>
 __global__ __launch_bounds__(256, MINB) void igemm_x3_kernel(const IgemmP p) {
     using G = Geo<BM, BN, WAVES_M, WAVES_N, 16>;
-    constexpr int LDSF = GeoX3<BM, BN>::TILE_FLOATS > G::EPI_FLOATS ? GeoX3<BM, BN>::TILE_FLOATS : G::EPI_FLOATS;
+    constexpr int LDSF = GeoX3<BM, BN, NP>::TILE_FLOATS > G::EPI_FLOATS ? GeoX3<BM, BN, NP>::TILE_FLOATS : G::EPI_FLOATS;
     __shared__ __attribute__((aligned(16))) float lds[LDSF];
     const int nk = p.K / 16;
     if constexpr (!SK) {
-        igemm_tile_x3<BM, BN, WAVES_M, WAVES_N, AMODE>(p, lds, xcd_remap(blockIdx.x, p.n_tiles), 0, nk, nullptr);
+        igemm_tile_x3<BM, BN, WAVES_M, WAVES_N, AMODE, NP>(p, lds, xcd_remap(blockIdx.x, p.n_tiles), 0, nk, nullptr);
     } else {
         const long long U = (long long)p.n_tiles * nk;
         long long u = U * blockIdx.x / p.sk_blocks;
@@ -685,7 +733,7 @@ __global__ __launch_bounds__(256, MINB) void igemm_x3_kernel(const IgemmP p) {
             float* partial = (kb == 0 && ke == nk)
                                  ? nullptr
                                  : p.sk_ws + ((size_t)blockIdx.x * 2 + (seg ? 1 : 0)) * (size_t)(BM * BN);
-            igemm_tile_x3<BM, BN, WAVES_M, WAVES_N, AMODE>(p, lds, tile, kb, ke, partial);
+            igemm_tile_x3<BM, BN, WAVES_M, WAVES_N, AMODE, NP>(p, lds, tile, kb, ke, partial);
             u += ke - kb;
         }
     }
@@ -698,6 +746,16 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
         u16 h, m, l;
         split3(w[i], h, m, l);
         out[i] = h; out[n + i] = m; out[2 * n + i] = l;
+    }
+}
+
+// fp32 [N][K] * sc -> two fp16 planes [2][N][K] (hi, lo)
+__global__ __launch_bounds__(256) void split_planes_h_kernel(const float* __restrict__ w, u16* __restrict__ out,
+                                                             long long n, float sc) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        u16 h, l;
+        split2h(w[i] * sc, h, l);
+        out[i] = h; out[n + i] = l;
     }
 }
 
@@ -771,6 +829,8 @@ constexpr int NUM_CUS = 256;
 // name the exact instantiation rocprofv3 reports); not used by any compute path
 thread_local int g_last_cfg[11] = {0};
 
+constexpr int X2_MINB(int BN) { return BN == 128 ? 2 : 3; }
+
 template <int BM, int BN, int WM, int WN, int AMODE, int WMODE, int BK, int MINB>
 int launch_cfg(IgemmP& p, hipStream_t s, int nbatch, void* ws, size_t ws_bytes) {
     const int tiles_m = (p.M + BM - 1) / BM;
@@ -799,6 +859,27 @@ int launch_cfg(IgemmP& p, hipStream_t s, int nbatch, void* ws, size_t ws_bytes) 
     if constexpr ((AMODE == 0 || AMODE == 1) && WMODE == 0 && BK == 16 && BM == 128 && (BN == 128 || BN == 64)) {
         // split-precision path: needs pre-split weights and the FAST loader's preconditions
         static const int x3_allow = [] { const char* e = getenv("DBMM_IGEMM_X3"); return e ? atoi(e) : 1; }();
+        static const int x2_allow = [] { const char* e = getenv("DBMM_IGEMM_X2"); return e ? atoi(e) : 1; }();
+        if (x2_allow && p.wh && p.a_absmax && nbatch == 1 && fast_ok<AMODE, WMODE, BK>(p)) {
+            constexpr int MB = X2_MINB(BN);
+            if (p.sk_blocks) {
+                p.sk_blocks = NUM_CUS * MB;
+                if ((long long)p.n_tiles * (p.K / 16) < 4LL * p.sk_blocks) p.sk_blocks = 0;
+            }
+            const dim3 g3(p.sk_blocks ? p.sk_blocks : p.n_tiles, 1);
+            if (p.sk_blocks)
+                hipLaunchKernelGGL((igemm_x3_kernel<BM, BN, WM, WN, AMODE, MB, 1, 2>), g3, dim3(256), 0, s, p);
+            else
+                hipLaunchKernelGGL((igemm_x3_kernel<BM, BN, WM, WN, AMODE, MB, 0, 2>), g3, dim3(256), 0, s, p);
+            g_last_cfg[7] = MB; g_last_cfg[8] = 2; g_last_cfg[9] = p.sk_blocks ? 1 : 0; g_last_cfg[10] = 0;
+            DBMM_CHECK_LAUNCH();
+            if (p.sk_blocks) {   // the fix-up needs a_absmax / w_exp too: its epilogue rescales the sums
+                hipLaunchKernelGGL((igemm_fixup_kernel<BM, BN, WM, WN, BK>), dim3(p.sk_blocks - 1), dim3(256), 0, s, p);
+                DBMM_CHECK_LAUNCH();
+            }
+            return DBMM_OK;
+        }
+        p.a_absmax = nullptr;   // every other kernel takes A unscaled
         if (x3_allow && p.w3 && nbatch == 1 && fast_ok<AMODE, WMODE, BK>(p)) {
             constexpr int MB = BN == 128 ? 2 : 3;   // register budget for the two prefetch sets (no spills)
             if (p.sk_blocks) {   // the resident grid is sized for this kernel's occupancy
@@ -807,10 +888,10 @@ int launch_cfg(IgemmP& p, hipStream_t s, int nbatch, void* ws, size_t ws_bytes) 
             }
             const dim3 g3(p.sk_blocks ? p.sk_blocks : p.n_tiles, 1);
             if (p.sk_blocks)
-                hipLaunchKernelGGL((igemm_x3_kernel<BM, BN, WM, WN, AMODE, MB, 1>), g3, dim3(256), 0, s, p);
+                hipLaunchKernelGGL((igemm_x3_kernel<BM, BN, WM, WN, AMODE, MB, 1, 3>), g3, dim3(256), 0, s, p);
             else
-                hipLaunchKernelGGL((igemm_x3_kernel<BM, BN, WM, WN, AMODE, MB, 0>), g3, dim3(256), 0, s, p);
-            g_last_cfg[8] = 3; g_last_cfg[9] = p.sk_blocks ? 1 : 0; g_last_cfg[10] = 0;
+                hipLaunchKernelGGL((igemm_x3_kernel<BM, BN, WM, WN, AMODE, MB, 0, 3>), g3, dim3(256), 0, s, p);
+            g_last_cfg[7] = MB; g_last_cfg[8] = 3; g_last_cfg[9] = p.sk_blocks ? 1 : 0; g_last_cfg[10] = 0;
             DBMM_CHECK_LAUNCH();
             if (p.sk_blocks) {
                 hipLaunchKernelGGL((igemm_fixup_kernel<BM, BN, WM, WN, BK>), dim3(p.sk_blocks - 1), dim3(256), 0, s, p);
@@ -820,6 +901,7 @@ int launch_cfg(IgemmP& p, hipStream_t s, int nbatch, void* ws, size_t ws_bytes) 
         }
     }
 
+    p.a_absmax = nullptr;
     if constexpr (AMODE != 2 && WMODE == 0) {
         if (fast_ok<AMODE, WMODE, BK>(p)) {
             static const int dma = [] { const char* e = getenv("DBMM_IGEMM_DMA"); return e ? atoi(e) : 1; }();
@@ -885,16 +967,33 @@ inline void set_extents(IgemmP& p, long long a_bytes, long long w_bytes) {
     p.w_bytes = (w_bytes > 0 && w_bytes < lim) ? (unsigned)w_bytes : 0u;
 }
 
-// w3 (optional): the same weight as three bf16 planes from dbmm_split_weight_planes
-inline void set_planes(IgemmP& p, const void* w3, long long N, long long ldw) {
-    const long long bytes = 3 * N * ldw * 2;
-    p.w3 = (w3 && bytes < 0x7FFFFFF0LL && dbmm_aligned16(w3)) ? (const unsigned short*)w3 : nullptr;
-    p.w3_bytes = p.w3 ? (unsigned)bytes : 0u;
+// Optional operands of the split-precision paths.
+//   w3: the weight as three bf16 planes (dbmm_split_weight_planes);
+//   wh / w_exp / a_absmax: the weight * 2^w_exp as two fp16 planes (dbmm_split_weight_planes_f16)
+//       and a device scalar >= max|A| -- both needed for the fp16-pair kernel;
+//   absmax_out: device scalar that receives (atomic max) max|C| of this launch.
+struct SplitArgs {
+    const void* w3 = nullptr;
+    const void* wh = nullptr;
+    int w_exp = 0;
+    const float* a_absmax = nullptr;
+    float* absmax_out = nullptr;
+};
+
+inline void set_planes(IgemmP& p, const SplitArgs& sx, long long N, long long ldw) {
+    const long long b3 = 3 * N * ldw * 2, b2 = 2 * N * ldw * 2;
+    p.w3 = (sx.w3 && b3 < 0x7FFFFFF0LL && dbmm_aligned16(sx.w3)) ? (const unsigned short*)sx.w3 : nullptr;
+    p.w3_bytes = p.w3 ? (unsigned)b3 : 0u;
+    const bool h_ok = sx.wh && sx.a_absmax && b2 < 0x7FFFFFF0LL && dbmm_aligned16(sx.wh) && sx.w_exp >= -40 && sx.w_exp <= 40;
+    p.wh = h_ok ? (const unsigned short*)sx.wh : nullptr;
+    p.wh_bytes = h_ok ? (unsigned)b2 : 0u;
+    p.w_exp = h_ok ? sx.w_exp : 0;
+    p.a_absmax = h_ok ? sx.a_absmax : nullptr;   // launch_cfg clears it again when another kernel runs
 }
 
 int gemm_impl(const float* a, int64_t lda, int trans_a, const float* w, int64_t ldw, int trans_w, const float* bias,
               const float* residual, int64_t ldr, float* c, int64_t ldc, int64_t M, int64_t N, int64_t K, float alpha,
-              int act, void* ws, size_t wsb, void* stream, const void* w3 = nullptr) {
+              int act, void* ws, size_t wsb, void* stream, const SplitArgs& sx = SplitArgs()) {
     if (!a || !w || !c) return DBMM_E_ARG;
     if (M <= 0 || N <= 0 || K <= 0 || M > INT32_MAX || N > INT32_MAX || K > INT32_MAX) return DBMM_E_SHAPE;
     if (act < 0 || act > 2) return DBMM_E_ARG;
@@ -909,7 +1008,8 @@ int gemm_impl(const float* a, int64_t lda, int trans_a, const float* w, int64_t 
     p.lda = lda; p.ldw = ldw; p.ldr = ldr; p.ldc = ldc;
     p.M = (int)M; p.N = (int)N; p.K = (int)K; p.act = act; p.alpha = alpha;
     set_extents(p, trans_a ? 0 : ((M - 1) * lda + K) * 4, trans_w ? 0 : ((N - 1) * ldw + K) * 4);
-    if (!trans_a && !trans_w) set_planes(p, w3, N, ldw);
+    if (!trans_a && !trans_w) set_planes(p, sx, N, ldw);
+    p.absmax_out = sx.absmax_out;
     hipStream_t s = (hipStream_t)stream;
     if (!trans_a && !trans_w) return launch_modes<0, 0>(p, s, 1, ws, wsb);
     if (!trans_a && trans_w) return launch_modes<0, 1>(p, s, 1, ws, wsb);
@@ -919,7 +1019,7 @@ int gemm_impl(const float* a, int64_t lda, int trans_a, const float* w, int64_t 
 
 int conv_impl(const float* x, const float* w, const float* bias, const float* residual, float* y, int64_t B, int64_t H,
               int64_t W, int64_t Cin, int64_t Cout, int64_t KH, int64_t KW, int64_t stride, int64_t pad, int act,
-              int w_layout, void* ws, size_t wsb, void* stream, const void* w3 = nullptr) {
+              int w_layout, void* ws, size_t wsb, void* stream, const SplitArgs& sx = SplitArgs()) {
     if (w_layout != DBMM_WL_TAP_MAJOR && w_layout != DBMM_WL_CHUNK_MAJOR) return DBMM_E_ARG;
     if (w_layout == DBMM_WL_CHUNK_MAJOR && (Cin & 15)) return DBMM_E_SHAPE;
     if (!x || !w || !y) return DBMM_E_ARG;
@@ -939,7 +1039,8 @@ int conv_impl(const float* x, const float* w, const float* bias, const float* re
     p.H = (int)H; p.W = (int)W; p.Cin = (int)Cin; p.Ho = (int)Ho; p.Wo = (int)Wo;
     p.KH = (int)KH; p.KW = (int)KW; p.stride = (int)stride; p.pad = (int)pad; p.wl = w_layout;
     set_extents(p, B * H * W * Cin * 4, Cout * K * 4);
-    set_planes(p, w3, Cout, K);   // planes carry the same K order as `w`
+    set_planes(p, sx, Cout, K);   // planes carry the same K order as `w`
+    p.absmax_out = sx.absmax_out;
     hipStream_t s = (hipStream_t)stream;
     if (KH == 1 && KW == 1 && stride == 1 && pad == 0) return launch_modes<0, 0>(p, s, 1, ws, wsb);  // plain GEMM
     return launch_modes<1, 0>(p, s, 1, ws, wsb);
@@ -1030,16 +1131,41 @@ extern "C" int dbmm_conv_bn_act_x3(const float* x, const float* w, const void* w
                                    const float* residual, float* y, int64_t B, int64_t H, int64_t W, int64_t Cin,
                                    int64_t Cout, int64_t KH, int64_t KW, int64_t stride, int64_t pad, int act,
                                    int w_layout, void* workspace, size_t workspace_bytes, void* stream) {
+    SplitArgs sx; sx.w3 = w_planes;
     return conv_impl(x, w, bias, residual, y, B, H, W, Cin, Cout, KH, KW, stride, pad, act, w_layout, workspace,
-                     workspace_bytes, stream, w_planes);
+                     workspace_bytes, stream, sx);
+}
+
+extern "C" size_t dbmm_split_planes_f16_bytes(int64_t N, int64_t K) { return (size_t)(2 * N * K) * 2; }
+
+extern "C" int dbmm_split_weight_planes_f16(const float* w, void* planes, int64_t N, int64_t K, int w_exp, void* stream) {
+    if (!w || !planes) return DBMM_E_ARG;
+    if (N <= 0 || K <= 0 || w_exp < -40 || w_exp > 40) return DBMM_E_SHAPE;
+    const long long n = (long long)N * K;
+    const long long blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(split_planes_h_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0,
+                       (hipStream_t)stream, w, (u16*)planes, n, ldexpf(1.f, w_exp));
+    DBMM_CHECK_LAUNCH();
+    return DBMM_OK;
+}
+
+extern "C" int dbmm_conv_bn_act_x2(const float* x, const float* x_absmax, const float* w, const void* w_planes_f16,
+                                   int w_exp, const float* bias, const float* residual, float* y, float* y_absmax,
+                                   int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int64_t KH, int64_t KW,
+                                   int64_t stride, int64_t pad, int act, int w_layout, void* workspace,
+                                   size_t workspace_bytes, void* stream) {
+    SplitArgs sx; sx.wh = w_planes_f16; sx.w_exp = w_exp; sx.a_absmax = x_absmax; sx.absmax_out = y_absmax;
+    return conv_impl(x, w, bias, residual, y, B, H, W, Cin, Cout, KH, KW, stride, pad, act, w_layout, workspace,
+                     workspace_bytes, stream, sx);
 }
 
 extern "C" int dbmm_gemm_bias_act_x3(const float* a, int64_t lda, const float* w, const void* w_planes, int64_t ldw,
                                      const float* bias, const float* residual, int64_t ldr, float* c, int64_t ldc,
                                      int64_t M, int64_t N, int64_t K, float alpha, int act, void* workspace,
                                      size_t workspace_bytes, void* stream) {
+    SplitArgs sx; sx.w3 = w_planes;
     return gemm_impl(a, lda, 0, w, ldw, 0, bias, residual, ldr, c, ldc, M, N, K, alpha, act, workspace, workspace_bytes,
-                     stream, w_planes);
+                     stream, sx);
 }
 
 extern "C" int dbmm_conv1x1_bn_act(const float* x, const float* w, const float* bias, const float* residual,

@@ -3,6 +3,7 @@ with torch's caching allocator, pass raw pointers + the current HIP stream, rais
 Every function requires HIP tensors -- there is no CPU path here.
 """
 import ctypes
+import math
 
 import torch
 
@@ -37,8 +38,8 @@ def _last_igemm_tag():
     """exact instantiation of the igemm launch just issued, spelled like rocprofv3's kernel name"""
     cfg = (ctypes.c_int * 11)()
     _lib.lib().dbmm_debug_last_igemm(cfg)
-    if cfg[8] == 3:     # split-precision kernel: <BM, BN, WAVES_M, WAVES_N, AMODE, MINB, SK>
-        return f"igemm_x3_kernel<{cfg[0]}, {cfg[1]}, {cfg[2]}, {cfg[3]}, {cfg[4]}, {2 if cfg[1] == 128 else 3}, {cfg[9]}>"
+    if cfg[8] in (2, 3):   # split-precision kernels: <BM, BN, WAVES_M, WAVES_N, AMODE, MINB, SK, NP>
+        return f"igemm_x3_kernel<{cfg[0]}, {cfg[1]}, {cfg[2]}, {cfg[3]}, {cfg[4]}, {cfg[7]}, {cfg[9]}, {cfg[8]}>"
     return "igemm_f32_kernel<" + ", ".join(str(v) for v in cfg) + ">"
 
 
@@ -87,6 +88,19 @@ def split_planes(w):
     planes = torch.empty((3, N, K), device=w.device, dtype=torch.bfloat16)
     check(_lib.lib().dbmm_split_weight_planes(ptr(w), ptr(planes), N, K, stream()), "split_weight_planes")
     return planes
+
+
+def split_planes_f16(w):
+    """fp32 [N][K] weight -> (two fp16 planes [2][N][K] of w * 2^w_exp, w_exp) for the fp16-pair
+    kernel; w_exp puts max|w| just below 2^14 (one host read of the maximum, at plan time)"""
+    require_cuda(w)
+    _f32c(w)
+    N, K = w.shape[0], w.numel() // w.shape[0]
+    m = float(w.abs().max())
+    w_exp = 0 if not (m > 0.0 and math.isfinite(m)) else max(-40, min(40, 13 - math.frexp(m)[1] + 1))
+    planes = torch.empty((2, N, K), device=w.device, dtype=torch.float16)
+    check(_lib.lib().dbmm_split_weight_planes_f16(ptr(w), ptr(planes), N, K, w_exp, stream()), "split_weight_planes_f16")
+    return planes, w_exp
 
 
 def gemm(a, w, bias=None, residual=None, act=ACT_NONE, alpha=1.0, trans_a=False, trans_w=False,
@@ -140,9 +154,13 @@ def pack_conv_weight(w_oihw, chunk_major=False):
     return w_oihw.permute(0, 2, 3, 1).contiguous().float().reshape(Cout, kh * kw * Cin), WL_TAP_MAJOR
 
 
-def conv_bn_act(x, w, bias, residual, kh, kw, stride, pad, act, w_layout=WL_TAP_MAJOR, w_planes=None):
+def conv_bn_act(x, w, bias, residual, kh, kw, stride, pad, act, w_layout=WL_TAP_MAJOR, w_planes=None,
+                w_planes_f16=None, w_exp=0, x_absmax=None, y_absmax=None):
     """x NHWC [B,H,W,Cin]; w packed [Cout][K] (BN folded) in `w_layout` order (default
-    [Cout][kh][kw][Cin]; see pack_conv_weight); returns NHWC."""
+    [Cout][kh][kw][Cin]; see pack_conv_weight); returns NHWC.
+    w_planes: bf16 triple (split_planes) -> split-precision kernel.
+    w_planes_f16 / w_exp (split_planes_f16) + x_absmax (1-element device tensor >= max|x|) ->
+    fp16-pair kernel; y_absmax (1-element device tensor, zeroed by the caller) receives max|y|."""
     require_cuda(x, w)
     _f32c(x); _f32c(w)
     B, H, W, Cin = x.shape
@@ -153,6 +171,12 @@ def conv_bn_act(x, w, bias, residual, kh, kw, stride, pad, act, w_layout=WL_TAP_
     plain = kh == 1 and kw == 1 and stride == 1 and pad == 0
     with _Timed(B * Ho * Wo, Cout, kh * kw * Cin, 0 if plain else 1, 0):
         ws = igemm_workspace(x.device)
+        if w_planes_f16 is not None or y_absmax is not None:
+            check(_lib.lib().dbmm_conv_bn_act_x2(ptr(x), ptr(x_absmax), ptr(w), ptr(w_planes_f16), int(w_exp), ptr(bias),
+                                                 ptr(residual), ptr(y), ptr(y_absmax), B, H, W, Cin, Cout, kh, kw, stride,
+                                                 pad, act, int(w_layout), ptr(ws), ws.numel() * 4, stream()),
+                  "conv_bn_act_x2")
+            return y
         if w_planes is not None:
             check(_lib.lib().dbmm_conv_bn_act_x3(ptr(x), ptr(w), ptr(w_planes), ptr(bias), ptr(residual), ptr(y), B, H, W,
                                                  Cin, Cout, kh, kw, stride, pad, act, int(w_layout), ptr(ws),

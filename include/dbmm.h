@@ -109,6 +109,23 @@ int dbmm_gemm_bias_act_x3(const float* a, int64_t lda, const float* w, const voi
                           int64_t M, int64_t N, int64_t K, float alpha, int act, void* workspace,
                           size_t workspace_bytes, void* stream);
 
+/* fp16-pair variant ("x2"): with a per-tensor power-of-two scale an fp32 value is hi + lo of two
+ * fp16 values to 2^-22 relative, so three fp16 x fp16 partial products (hl, lh, hh) give
+ * fp32-level accuracy at HALF the matrix-core work of the bf16 triple.  The scale of the
+ * activations comes from a device scalar x_absmax >= max|x| that the producing launch wrote
+ * through its y_absmax argument (atomic max over |y|; the caller zeroes the scalar beforehand;
+ * an average pool may reuse its input's scalar: any upper bound works, a bound 2^k too large
+ * costs k bits of the 2^-39 absolute floor).  w_planes_f16 = w * 2^w_exp split by
+ * dbmm_split_weight_planes_f16 ([2][N][K] fp16); choose w_exp so that max|w| * 2^w_exp < 2^15.
+ * x_absmax or w_planes_f16 may be NULL (fp32-MFMA kernel, y_absmax still honoured). */
+size_t dbmm_split_planes_f16_bytes(int64_t N, int64_t K);
+int dbmm_split_weight_planes_f16(const float* w, void* planes, int64_t N, int64_t K, int w_exp, void* stream);
+int dbmm_conv_bn_act_x2(const float* x, const float* x_absmax, const float* w, const void* w_planes_f16,
+                        int w_exp, const float* bias, const float* residual, float* y, float* y_absmax,
+                        int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int64_t KH, int64_t KW,
+                        int64_t stride, int64_t pad, int act, int w_layout, void* workspace,
+                        size_t workspace_bytes, void* stream);
+
 /* profiling aid: the 11 template arguments <BM,BN,WAVES_M,WAVES_N,AMODE,WMODE,BK,MINB,FAST,SK,DMA>
  * of the calling thread's most recent igemm launch (= the kernel name rocprofv3 reports). */
 void dbmm_debug_last_igemm(int* out11);

@@ -6,7 +6,7 @@ import torch
 import torch.nn.functional as F
 
 import clip_oracle as CO
-from conftest import relerr
+from conftest import ROOT, relerr
 from dbmm_amd import ops, synth
 
 pytestmark = pytest.mark.gpu
@@ -358,3 +358,98 @@ def test_split_precision_falls_back_when_ineligible():
     planes = ops.split_planes(w.to(DEV))
     out = ops.gemm(a.to(DEV), w.to(DEV), w_planes=planes)
     assert relerr(out.cpu(), a @ w.t()) < 2e-5
+
+
+def _x2_conv(xd, wp, wl, bd, rd, k, act, x_bound):
+    ph, we = ops.split_planes_f16(wp)
+    yam = torch.zeros(1, device=DEV)
+    out = ops.conv_bn_act(xd, wp, bd, rd, k, k, 1, k // 2, act, wl, w_planes_f16=ph, w_exp=we,
+                          x_absmax=x_bound, y_absmax=yam)
+    return out, yam, ph, we
+
+
+@pytest.mark.parametrize("B,H,Cin,Cout,k,res", [(2, 16, 32, 128, 3, False), (3, 14, 64, 64, 3, True), (2, 9, 16, 48, 3, False),
+                                                (4, 7, 512, 256, 3, False), (128, 14, 256, 256, 3, True),
+                                                (2, 12, 64, 256, 1, True), (64, 28, 128, 128, 3, False)])
+def test_conv_fp16_pair(B, H, Cin, Cout, k, res):
+    """fp16 hi+lo operands with power-of-two scales, three partial products: fp32-level accuracy
+    against an fp64 reference (no worse than the fp32-MFMA kernel); the output-maximum scalar
+    equals max|y| exactly; the planes reproduce the scaled weight to 2^-22."""
+    x = rnd(1, "x", (B, Cin, H, H)); w = rnd(2, "w", (Cout, Cin, k, k), (Cin * k * k) ** -0.5); b = rnd(3, "b", (Cout,), 0.1)
+    r = rnd(4, "r", (B, Cout, H, H)) if res else None
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=k // 2)
+    if res:
+        ref = ref + r.double()
+    ref = torch.relu(ref).permute(0, 2, 3, 1)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    rd = r.permute(0, 2, 3, 1).contiguous().to(DEV) if res else None
+    wp, wl = ops.pack_conv_weight(w.to(DEV))
+    o2, yam, ph, we = _x2_conv(xd, wp, wl, b.to(DEV), rd, k, ops.ACT_RELU, xd.abs().max().reshape(1))
+    assert ph.shape == (2, Cout, Cin * k * k) and ph.dtype == torch.float16
+    back = ph.double().sum(0) * 2.0 ** -we
+    assert (back - wp.double()).abs().max().item() <= 2.0 ** -21 * wp.abs().max().item()
+    assert 2.0 ** 13 <= wp.abs().max().item() * 2.0 ** we < 2.0 ** 14
+    o32 = ops.conv_bn_act(xd, wp, b.to(DEV), rd, k, k, 1, k // 2, ops.ACT_RELU, wl)
+    e2, e32 = relerr(o2.cpu().double(), ref), relerr(o32.cpu().double(), ref)
+    assert e2 < 5e-6 and e2 < 5 * e32 + 5e-7, (e2, e32)
+    assert yam.item() == o2.abs().max().item()
+
+
+def test_conv_fp16_pair_loose_bound_and_outliers():
+    """any upper bound of max|x| works (an average pool hands its input's bound on), and a few
+    huge activations / tiny weights do not cost accuracy on the rest (absolute floor 2^-39 of the
+    tensor maximum, far below fp32 rounding of the sums)."""
+    B, H, Cin, Cout, k = 4, 14, 64, 128, 3
+    x = rnd(1, "x", (B, Cin, H, H)); w = rnd(2, "w", (Cout, Cin, k, k), (Cin * k * k) ** -0.5); b = rnd(3, "b", (Cout,), 0.1)
+    x[:, ::7, ::5, ::3] *= 300.0
+    x[:, 1::4] *= 1e-4
+    w[::5, ::11] *= 50.0
+    ref = torch.relu(F.conv2d(x.double(), w.double(), b.double(), padding=1)).permute(0, 2, 3, 1)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    wp, wl = ops.pack_conv_weight(w.to(DEV))
+    o32 = ops.conv_bn_act(xd, wp, b.to(DEV), None, k, k, 1, 1, ops.ACT_RELU, wl)
+    e32 = relerr(o32.cpu().double(), ref)
+    for slack in (1.0, 3.7, 64.0):
+        o2, yam, _, _ = _x2_conv(xd, wp, wl, b.to(DEV), None, k, ops.ACT_RELU, (xd.abs().max() * slack).reshape(1))
+        e2 = relerr(o2.cpu().double(), ref)
+        assert e2 < 5e-6 and e2 < 5 * e32 + 5e-7, (slack, e2, e32)
+        assert yam.item() == o2.abs().max().item()
+
+
+def test_conv_fp16_pair_stream_k():
+    """forced stream-K: the fix-up kernel applies the same power-of-two rescale"""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import torch, torch.nn.functional as F, sys
+        sys.path.insert(0, %r)
+        import dbmm_amd
+        from dbmm_amd import ops, synth
+        x = synth.normal(1, "x", (128, 256, 14, 14)); w = synth.normal(2, "w", (256, 256, 3, 3), 2304 ** -0.5)
+        ref = torch.relu(F.conv2d(x.double(), w.double(), None, padding=1)).permute(0, 2, 3, 1)
+        xd = x.permute(0, 2, 3, 1).contiguous().cuda(); wp, wl = ops.pack_conv_weight(w.cuda())
+        ph, we = ops.split_planes_f16(wp); yam = torch.zeros(1, device="cuda")
+        o = ops.conv_bn_act(xd, wp, None, None, 3, 3, 1, 1, ops.ACT_RELU, wl, w_planes_f16=ph, w_exp=we,
+                            x_absmax=xd.abs().max().reshape(1), y_absmax=yam)
+        tag = ops._last_igemm_tag()
+        e = ((o.cpu().double() - ref).abs().max() / ref.abs().max()).item()
+        assert tag.startswith("igemm_x3_kernel<") and tag.endswith(", 1, 2>"), tag
+        assert e < 5e-6, e
+        assert yam.item() == o.abs().max().item()
+        print("ok")
+    """ % ROOT)
+    import os
+    env = dict(os.environ, DBMM_IGEMM_STREAMK="2")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
+
+
+def test_conv_fp16_pair_without_bound_uses_fp32_kernel():
+    B, H, Cin, Cout, k = 2, 10, 32, 64, 3
+    x = rnd(1, "x", (B, Cin, H, H)); w = rnd(2, "w", (Cout, Cin, k, k), 0.05)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(DEV); wp, wl = ops.pack_conv_weight(w.to(DEV))
+    ph, we = ops.split_planes_f16(wp); yam = torch.zeros(1, device=DEV)
+    o = ops.conv_bn_act(xd, wp, None, None, k, k, 1, 1, ops.ACT_NONE, wl, w_planes_f16=ph, w_exp=we, y_absmax=yam)
+    assert ops._last_igemm_tag().startswith("igemm_f32_kernel<")
+    ref = F.conv2d(x, w, None, padding=1).permute(0, 2, 3, 1)
+    assert relerr(o.cpu(), ref) < 2e-5
+    assert yam.item() == o.abs().max().item()

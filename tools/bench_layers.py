@@ -51,21 +51,28 @@ def main():
             x = torch.randn(a.batch, H, H, Cin, device=dev)
             w, wl = ops.pack_conv_weight(torch.randn(Cout, Cin, k, k, device=dev) * (Cin * k * k) ** -0.5,
                                          chunk_major=os.environ.get("BENCH_WL") == "1")
-            pl = ops.split_planes(w) if os.environ.get("BENCH_X3") == "1" else None
+            mode = os.environ.get("BENCH_SPLIT", "f16")          # f16 | bf16 | off
+            kw = {}
+            if mode == "bf16":
+                kw = dict(w_planes=ops.split_planes(w))
+            elif mode == "f16":
+                ph, we = ops.split_planes_f16(w)
+                kw = dict(w_planes_f16=ph, w_exp=we, x_absmax=x.abs().max().reshape(1),
+                          y_absmax=torch.zeros(1, device=dev))
             b = torch.randn(Cout, device=dev)
             r = torch.randn(a.batch, H, H, Cout, device=dev) if res else None
             pad = 1 if k == 3 else 0
             for _ in range(2):
-                ops.conv_bn_act(x, w, b, r, k, k, 1, pad, ops.ACT_RELU, wl, pl)
+                ops.conv_bn_act(x, w, b, r, k, k, 1, pad, ops.ACT_RELU, wl, **kw)
             ts = []
             for _ in range(a.iters):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record(); ops.conv_bn_act(x, w, b, r, k, k, 1, pad, ops.ACT_RELU, wl, pl); e1.record()
+                e0.record(); ops.conv_bn_act(x, w, b, r, k, k, 1, pad, ops.ACT_RELU, wl, **kw); e1.record()
                 torch.cuda.synchronize()
                 ts.append(e0.elapsed_time(e1))
             ts.sort(); ms = ts[len(ts) // 2]
             seen[key] = ms
-            del x, w, r, pl
+            del x, w, r, kw
         M = a.batch * H * H
         fl = 2.0 * M * Cout * Cin * k * k
         by = 4.0 * M * (Cin + Cout * (2 if res else 1))
