@@ -47,9 +47,10 @@ F16_MFMA_PEAK_TFLOPS = 2500.0          # dense fp16 MFMA, same table (same rate 
 SPLIT_PRODUCTS = {2: 3, 3: 6}
 RN50_GFLOP_PER_IMG = 11.59             # SURVEY.md section 8d (conv 5.367 + attn-pool 0.426 GMAC)
 # dominant kernel: 3x3 implicit-GEMM conv, 128x128 tile, one tile per workgroup
-# (template arguments <BM, BN, WAVES_M, WAVES_N, AMODE=1 (conv), MINB, SK=0, NP>; NP = 2: fp16 pair, 3: bf16 triple)
-DOMINANT_SPLIT = ("igemm_x3_kernel<128, 128, 2, 2, 1, 2, 0, 2>",            # default path
-                  "igemm_x3_kernel<128, 128, 2, 2, 1, 2, 0, 3>")            # DBMM_CONV_SPLIT=bf16
+# (template arguments <BM, BN, WAVES_M, WAVES_N, AMODE=1 (conv), MINB, SK=0, NP, BK>; NP = 2: fp16 pair, 3: bf16 triple)
+DOMINANT_SPLIT = ("igemm_x3_kernel<128, 128, 2, 2, 1, 2, 0, 2, 32>",        # default path
+                  "igemm_x3_kernel<128, 128, 2, 2, 1, 2, 0, 2, 16>",        # DBMM_IGEMM_X2_BK=16
+                  "igemm_x3_kernel<128, 128, 2, 2, 1, 2, 0, 3, 16>")        # DBMM_CONV_SPLIT=bf16
 DOMINANT_F32 = "igemm_f32_kernel<128, 128, 2, 2, 1, 0, 16, 4, 1, 0, 1>"    # fp32-MFMA path (DBMM_CONV_SPLIT=off)
 
 
@@ -182,7 +183,7 @@ def main():
         value = B * args.steps / dt
         DOMINANT = next((k for k in DOMINANT_SPLIT if k in prof), DOMINANT_F32)
         split = DOMINANT in DOMINANT_SPLIT
-        n_prod = SPLIT_PRODUCTS[int(DOMINANT.rstrip(">").split(",")[-1])] if split else 1
+        n_prod = SPLIT_PRODUCTS[int(DOMINANT.rstrip(">").split(",")[-2])] if split else 1
         peak = F16_MFMA_PEAK_TFLOPS / n_prod if split else FP32_MFMA_PEAK_TFLOPS
         n, fl, ms = prof.get(DOMINANT, (0, 0.0, 0.0))
         ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0

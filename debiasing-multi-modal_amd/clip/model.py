@@ -120,7 +120,7 @@ def _pack_conv(w64, bias):
     cover fall back to the fp32-MFMA kernel inside the library)."""
     w, wl = ops.pack_conv_weight(w64)
     c = dict(w=w, wl=wl, b=bias.float().contiguous(), p3=None, ph=None, we=0)
-    if w.is_cuda and w.shape[0] > 32 and w.shape[1] % 16 == 0:
+    if w.is_cuda and w.shape[1] % 16 == 0 and (w.shape[0] > 32 or CONV_SPLIT == "f16"):
         if CONV_SPLIT == "f16":
             c["ph"], c["we"] = ops.split_planes_f16(w)
         elif CONV_SPLIT == "bf16":
@@ -189,12 +189,12 @@ class ModifiedResNet(nn.Module):
     def forward(self, x, return_stages=False):
         P = self._plan or self._compile()
         x = x.float().contiguous()                      # NCHW image at the boundary
-        x = ops.conv_stem_s2(x, *P["stem1"])            # -> NHWC from here on
         # One device scalar per conv output: its epilogue leaves max|y| there and the consumer
         # derives its fp16 scale from it (an average pool passes its input's bound on).
-        n_slots = 2 + 4 * len(P["blocks"])
+        n_slots = 3 + 4 * len(P["blocks"])
         amax = torch.zeros(n_slots, device=x.device, dtype=torch.float32)
-        slot = [0]
+        slot = [1]
+        x = ops.conv_stem_s2(x, *P["stem1"], y_absmax=amax[0:1])            # -> NHWC from here on
 
         def conv(t, t_am, c, res, k, pad, act):
             y_am = amax[slot[0]:slot[0] + 1]; slot[0] += 1
@@ -202,7 +202,7 @@ class ModifiedResNet(nn.Module):
                                 w_planes_f16=c["ph"], w_exp=c["we"], x_absmax=t_am, y_absmax=y_am)
             return y, y_am
 
-        x, am = conv(x, None, P["stem2"], None, 3, 1, ops.ACT_RELU)
+        x, am = conv(x, amax[0:1], P["stem2"], None, 3, 1, ops.ACT_RELU)
         x, am = conv(x, am, P["stem3"], None, 3, 1, ops.ACT_RELU)
         x = ops.avgpool2d(x, 2)
         stages = {"stem": x}

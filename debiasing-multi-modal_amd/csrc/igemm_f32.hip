@@ -521,27 +521,35 @@ __device__ __forceinline__ void split2h(float xs, u16& hi, u16& lo) {
     hi = __builtin_bit_cast(u16, h); lo = __builtin_bit_cast(u16, l);
 }
 
-template <int BM, int BN, int NP>
+template <int BM, int BN, int NP, int BK>
 struct GeoX3 {   // LDS floats for the split path (NP 16-bit planes, two stages) vs the epilogue staging
-    static constexpr int STAGE_U16 = NP * (BM + BN) * 16;
+    static constexpr int STAGE_U16 = NP * (BM + BN) * BK;
     static constexpr int TILE_FLOATS = 2 * STAGE_U16 / 2;
 };
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int AMODE, int NP>
+// LDS rows hold BK 16-bit values (32 or 64 B); XOR of the 16-B chunk index with row bits keeps
+// the 16 lanes of a ds_read_b128 group on distinct bank quads (same geometry as lds_swz above)
+template <int BK>
+__device__ __forceinline__ int x3_swz(int row) { return BK == 16 ? ((row >> 3) & 1) : ((row >> 2) & 3); }
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int AMODE, int NP, int BK>
 __device__ __forceinline__ void igemm_tile_x3(const IgemmP& p, float* lds, int tile, int kb, int ke, float* partial) {
-    constexpr int BK = 16;
+    static_assert(BK == 16 || BK == 32, "BK");
     using G = Geo<BM, BN, WAVES_M, WAVES_N, BK>;
     constexpr int TM = G::TM, TN = G::TN, WTN = G::WTN, LROW = G::LROW;
-    constexpr int ALD = BM / 64;                  // float4 loads per thread per chunk (64 rows x 4 k-quads per pass)
-    constexpr int STAGE = GeoX3<BM, BN, NP>::STAGE_U16;
-    u16* Ap = (u16*)lds;                           // per stage: [NP][BM][16] then [NP][BN][16]
+    constexpr int QPR = BK / 4, RPA = 256 / QPR;   // A: k-quads (4 fp32) per row, rows per pass of the 256 threads
+    constexpr int ALD = BM / RPA;                  // float4 loads per thread per chunk
+    constexpr int CPW = BK / 8, RPW = 256 / CPW;   // W: 16-B chunks (8 halves) per plane row, rows per pass
+    constexpr int WLD = (BN + RPW - 1) / RPW;      // b128 loads per thread per plane per chunk
+    constexpr int STAGE = GeoX3<BM, BN, NP, BK>::STAGE_U16;
+    u16* Ap = (u16*)lds;                           // per stage: [NP][BM][BK] then [NP][BN][BK]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m0 = (tile / p.tiles_n) * BM, n0 = (tile % p.tiles_n) * BN;
     const int wm0 = (wave / WAVES_N) * (TM * 32), wn0 = (wave % WAVES_N) * (TN * 32);
-    const int lc = tid & 3, lr = tid >> 2;         // A: k-quad lc of rows lr + 64*i
-    const int wr = tid >> 1, wc = tid & 1;         // W: 16-B chunk wc (8 bf16) of row wr, all 3 planes
+    const int lc = tid & (QPR - 1), lr = tid / QPR;   // A: k-quad lc of rows lr + RPA*i
+    const int wc = tid & (CPW - 1), wr = tid / CPW;   // W: chunk wc of rows wr + RPW*j, all planes
 
-    unsigned fa_off[ALD], fa_mask[ALD];
+    unsigned fa_off[ALD], fa_mask[ALD], fw_off[WLD];
     int f_ci0 = 0, f_kh = 0, f_kw = 0, f_tap = 0;
     __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.a, 0, (int)p.a_bytes, 0x00020000);
     __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)(NP == 3 ? p.w3 : p.wh), 0,
@@ -549,10 +557,14 @@ __device__ __forceinline__ void igemm_tile_x3(const IgemmP& p, float* lds, int t
     float a_sc = 1.f;
     if constexpr (NP == 2) a_sc = pow2f(a_scale_exp(p.a_absmax));
     const unsigned plane_bytes = (unsigned)p.N * (unsigned)p.ldw * 2u;
-    const unsigned fw_off = (wr < BN && n0 + wr < p.N) ? ((unsigned)(n0 + wr) * (unsigned)p.ldw + wc * 8u) * 2u : OOR;
+#pragma unroll
+    for (int j = 0; j < WLD; ++j) {
+        const int row = wr + RPW * j;
+        fw_off[j] = (row < BN && n0 + row < p.N) ? ((unsigned)(n0 + row) * (unsigned)p.ldw + wc * 8u) * 2u : OOR;
+    }
 #pragma unroll
     for (int i = 0; i < ALD; ++i) {
-        const int m = m0 + lr + 64 * i;
+        const int m = m0 + lr + RPA * i;
         const bool rv = m < p.M;
         if constexpr (AMODE == 0) {
             fa_off[i] = rv ? (unsigned)m * (unsigned)p.lda * 4u + lc * 16u : OOR;
@@ -572,7 +584,7 @@ __device__ __forceinline__ void igemm_tile_x3(const IgemmP& p, float* lds, int t
         }
     }
     if constexpr (AMODE == 1) {
-        if (p.wl == DBMM_WL_CHUNK_MAJOR) {       // K = (cin/16, kh, kw, 16): taps cycle fastest
+        if (BK == 16 && p.wl == DBMM_WL_CHUNK_MAJOR) {       // K = (cin/16, kh, kw, 16): taps cycle fastest
             const int taps = p.KH * p.KW;
             f_tap = kb % taps; f_ci0 = (kb / taps) * 16;
         } else {
@@ -583,11 +595,11 @@ __device__ __forceinline__ void igemm_tile_x3(const IgemmP& p, float* lds, int t
     }
 
     // two register sets: the loads of chunk k+2 are issued while chunk k computes and chunk k+1
-    // (already landed) is split into LDS -- each chunk's MFMA phase is only 768 cycles per wave,
-    // one chunk of lead did not cover the L2 / Infinity-Cache latency (ablation: 31 % of the time)
+    // (already landed) is split into LDS -- one chunk of lead did not cover the L2 / Infinity-
+    // Cache latency (ablation on the bf16 kernel: 31 % of the time)
     f32x4 a_r0[ALD], a_r1[ALD];
-    u32x4 w_r0[NP], w_r1[NP];
-    auto load_chunk = [&](int k0, f32x4 (&a_reg)[ALD], u32x4 (&w_reg)[NP]) {
+    u32x4 w_r0[NP * WLD], w_r1[NP * WLD];
+    auto load_chunk = [&](int k0, f32x4 (&a_reg)[ALD], u32x4 (&w_reg)[NP * WLD]) {
         if constexpr (AMODE == 0) {
 #pragma unroll
             for (int i = 0; i < ALD; ++i) a_reg[i] = buf_load16(rsA, fa_off[i], (unsigned)k0 * 4u);
@@ -597,7 +609,7 @@ __device__ __forceinline__ void igemm_tile_x3(const IgemmP& p, float* lds, int t
 #pragma unroll
             for (int i = 0; i < ALD; ++i)
                 a_reg[i] = buf_load16(rsA, (fa_mask[i] & bit) ? fa_off[i] + delta : OOR, 0u);
-            if (p.wl == DBMM_WL_CHUNK_MAJOR) {
+            if (BK == 16 && p.wl == DBMM_WL_CHUNK_MAJOR) {
                 ++f_tap;
                 if (++f_kw == p.KW) { f_kw = 0; ++f_kh; }
                 if (f_tap == p.KH * p.KW) { f_tap = 0; f_kh = 0; f_kw = 0; f_ci0 += 16; }
@@ -611,30 +623,36 @@ __device__ __forceinline__ void igemm_tile_x3(const IgemmP& p, float* lds, int t
         }
 #pragma unroll
         for (int pl = 0; pl < NP; ++pl)
-            w_reg[pl] = __builtin_amdgcn_raw_buffer_load_b128(rsW, fw_off, pl * plane_bytes + (unsigned)k0 * 2u, 0);
+#pragma unroll
+            for (int j = 0; j < WLD; ++j)
+                w_reg[pl * WLD + j] = __builtin_amdgcn_raw_buffer_load_b128(rsW, fw_off[j], pl * plane_bytes + (unsigned)k0 * 2u, 0);
     };
-    auto store_chunk = [&](int stage, const f32x4 (&a_reg)[ALD], const u32x4 (&w_reg)[NP]) {
-        u16* Ab = Ap + stage * STAGE;              // planes [NP][BM][16]
-        u16* Wb = Ab + NP * BM * 16;               // planes [NP][BN][16]
+    auto store_chunk = [&](int stage, const f32x4 (&a_reg)[ALD], const u32x4 (&w_reg)[NP * WLD]) {
+        u16* Ab = Ap + stage * STAGE;              // planes [NP][BM][BK]
+        u16* Wb = Ab + NP * BM * BK;               // planes [NP][BN][BK]
 #pragma unroll
         for (int i = 0; i < ALD; ++i) {
-            const int row = lr + 64 * i;
+            const int row = lr + RPA * i;
             u16 h[4], m[4], l[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 if constexpr (NP == 3) split3(a_reg[i][j], h[j], m[j], l[j]);
                 else split2h(a_reg[i][j] * a_sc, h[j], m[j]);
             }
-            const int off = row * 16 + ((((lc >> 1) ^ ((row >> 3) & 1))) << 3) + ((lc & 1) << 2);
-            *(u32x2*)(Ab + 0 * BM * 16 + off) = (u32x2){(unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16)};
-            *(u32x2*)(Ab + 1 * BM * 16 + off) = (u32x2){(unsigned)m[0] | ((unsigned)m[1] << 16), (unsigned)m[2] | ((unsigned)m[3] << 16)};
+            const int off = row * BK + ((((lc >> 1) ^ x3_swz<BK>(row))) << 3) + ((lc & 1) << 2);
+            *(u32x2*)(Ab + 0 * BM * BK + off) = (u32x2){(unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16)};
+            *(u32x2*)(Ab + 1 * BM * BK + off) = (u32x2){(unsigned)m[0] | ((unsigned)m[1] << 16), (unsigned)m[2] | ((unsigned)m[3] << 16)};
             if constexpr (NP == 3)
-                *(u32x2*)(Ab + 2 * BM * 16 + off) = (u32x2){(unsigned)l[0] | ((unsigned)l[1] << 16), (unsigned)l[2] | ((unsigned)l[3] << 16)};
+                *(u32x2*)(Ab + 2 * BM * BK + off) = (u32x2){(unsigned)l[0] | ((unsigned)l[1] << 16), (unsigned)l[2] | ((unsigned)l[3] << 16)};
         }
-        if (wr < BN) {
-            const int off = wr * 16 + ((wc ^ ((wr >> 3) & 1)) << 3);
 #pragma unroll
-            for (int pl = 0; pl < NP; ++pl) *(u32x4*)(Wb + pl * BN * 16 + off) = w_reg[pl];
+        for (int j = 0; j < WLD; ++j) {
+            const int row = wr + RPW * j;
+            if (row < BN) {
+                const int off = row * BK + ((wc ^ x3_swz<BK>(row)) << 3);
+#pragma unroll
+                for (int pl = 0; pl < NP; ++pl) *(u32x4*)(Wb + pl * BN * BK + off) = w_reg[pl * WLD + j];
+            }
         }
     };
 
@@ -647,37 +665,42 @@ __device__ __forceinline__ void igemm_tile_x3(const IgemmP& p, float* lds, int t
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int fr = lane & 31, fh = lane >> 5;
-    const int fch = (fh ^ ((fr >> 3) & 1)) << 3;    // swizzled chunk of this lane's 8 k values (u16 units)
 
     auto compute = [&](int stage) {
         const u16* Ab = Ap + stage * STAGE;
-        const u16* Wb = Ab + NP * BM * 16;
-        u32x4 af[TM][NP], wf[TN][NP];
+        const u16* Wb = Ab + NP * BM * BK;
 #pragma unroll
-        for (int pl = 0; pl < NP; ++pl) {
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            // this lane's 8 k values of sub-step ks: chunk 2*ks + fh, swizzled (tile row offsets are
+            // multiples of 32, so the swizzle depends on fr only)
+            const int fch = ((2 * ks + fh) ^ x3_swz<BK>(fr)) << 3;
+            u32x4 af[TM][NP], wf[TN][NP];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) af[i][pl] = *(const u32x4*)(Ab + pl * BM * 16 + (wm0 + i * 32 + fr) * 16 + fch);
+            for (int pl = 0; pl < NP; ++pl) {
 #pragma unroll
-            for (int j = 0; j < TN; ++j) wf[j][pl] = *(const u32x4*)(Wb + pl * BN * 16 + (wn0 + j * 32 + fr) * 16 + fch);
-        }
-        // smallest partial products first: bf16 (h,l) (l,h) (m,m) (h,m) (m,h) (h,h); fp16 (h,l) (l,h) (h,h)
-        constexpr int NQ = NP == 3 ? 6 : 3;
+                for (int i = 0; i < TM; ++i) af[i][pl] = *(const u32x4*)(Ab + pl * BM * BK + (wm0 + i * 32 + fr) * BK + fch);
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            constexpr int PA3[6] = {0, 2, 1, 0, 1, 0}, PB3[6] = {2, 0, 1, 1, 0, 0};
-            constexpr int PA2[3] = {0, 1, 0}, PB2[3] = {1, 0, 0};
-            const int pa = NP == 3 ? PA3[q] : PA2[q], pb = NP == 3 ? PB3[q] : PB2[q];
+                for (int j = 0; j < TN; ++j) wf[j][pl] = *(const u32x4*)(Wb + pl * BN * BK + (wn0 + j * 32 + fr) * BK + fch);
+            }
+            // smallest partial products first: bf16 (h,l) (l,h) (m,m) (h,m) (m,h) (h,h); fp16 (h,l) (l,h) (h,h)
+            constexpr int NQ = NP == 3 ? 6 : 3;
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+            for (int q = 0; q < NQ; ++q) {
+                constexpr int PA3[6] = {0, 2, 1, 0, 1, 0}, PB3[6] = {2, 0, 1, 1, 0, 0};
+                constexpr int PA2[3] = {0, 1, 0}, PB2[3] = {1, 0, 0};
+                const int pa = NP == 3 ? PA3[q] : PA2[q], pb = NP == 3 ? PB3[q] : PB2[q];
 #pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    if constexpr (NP == 3)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[i][pa]),
-                                                                            __builtin_bit_cast(bf16x8, wf[j][pb]), acc[i][j], 0, 0, 0);
-                    else
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[i][pa]),
-                                                                           __builtin_bit_cast(f16x8, wf[j][pb]), acc[i][j], 0, 0, 0);
-                }
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        if constexpr (NP == 3)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[i][pa]),
+                                                                                __builtin_bit_cast(bf16x8, wf[j][pb]), acc[i][j], 0, 0, 0);
+                        else
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[i][pa]),
+                                                                               __builtin_bit_cast(f16x8, wf[j][pb]), acc[i][j], 0, 0, 0);
+                    }
+            }
         }
     };
 
@@ -715,14 +738,14 @@ __device__ __forceinline__ void igemm_tile_x3(const IgemmP& p, float* lds, int t
     }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int AMODE, int MINB, int SK, int NP>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int AMODE, int MINB, int SK, int NP, int BK>
 __global__ __launch_bounds__(256, MINB) void igemm_x3_kernel(const IgemmP p) {
-    using G = Geo<BM, BN, WAVES_M, WAVES_N, 16>;
-    constexpr int LDSF = GeoX3<BM, BN, NP>::TILE_FLOATS > G::EPI_FLOATS ? GeoX3<BM, BN, NP>::TILE_FLOATS : G::EPI_FLOATS;
+    using G = Geo<BM, BN, WAVES_M, WAVES_N, BK>;
+    constexpr int LDSF = GeoX3<BM, BN, NP, BK>::TILE_FLOATS > G::EPI_FLOATS ? GeoX3<BM, BN, NP, BK>::TILE_FLOATS : G::EPI_FLOATS;
     __shared__ __attribute__((aligned(16))) float lds[LDSF];
-    const int nk = p.K / 16;
+    const int nk = p.K / BK;
     if constexpr (!SK) {
-        igemm_tile_x3<BM, BN, WAVES_M, WAVES_N, AMODE, NP>(p, lds, xcd_remap(blockIdx.x, p.n_tiles), 0, nk, nullptr);
+        igemm_tile_x3<BM, BN, WAVES_M, WAVES_N, AMODE, NP, BK>(p, lds, xcd_remap(blockIdx.x, p.n_tiles), 0, nk, nullptr);
     } else {
         const long long U = (long long)p.n_tiles * nk;
         long long u = U * blockIdx.x / p.sk_blocks;
@@ -733,7 +756,7 @@ __global__ __launch_bounds__(256, MINB) void igemm_x3_kernel(const IgemmP p) {
             float* partial = (kb == 0 && ke == nk)
                                  ? nullptr
                                  : p.sk_ws + ((size_t)blockIdx.x * 2 + (seg ? 1 : 0)) * (size_t)(BM * BN);
-            igemm_tile_x3<BM, BN, WAVES_M, WAVES_N, AMODE, NP>(p, lds, tile, kb, ke, partial);
+            igemm_tile_x3<BM, BN, WAVES_M, WAVES_N, AMODE, NP, BK>(p, lds, tile, kb, ke, partial);
             u += ke - kb;
         }
     }
@@ -829,7 +852,7 @@ constexpr int NUM_CUS = 256;
 // name the exact instantiation rocprofv3 reports); not used by any compute path
 thread_local int g_last_cfg[11] = {0};
 
-constexpr int X2_MINB(int BN) { return BN == 128 ? 2 : 3; }
+constexpr int X2_MINB(int BN) { return BN == 128 ? 2 : 3; }   // registers (128x128) / LDS (narrower tiles)
 
 template <int BM, int BN, int WM, int WN, int AMODE, int WMODE, int BK, int MINB>
 int launch_cfg(IgemmP& p, hipStream_t s, int nbatch, void* ws, size_t ws_bytes) {
@@ -856,30 +879,47 @@ int launch_cfg(IgemmP& p, hipStream_t s, int nbatch, void* ws, size_t ws_bytes) 
         const int c[11] = {BM, BN, WM, WN, AMODE, WMODE, BK, MINB, 0, p.sk_blocks ? 1 : 0, 0};
         for (int i = 0; i < 11; ++i) g_last_cfg[i] = c[i];
     }
-    if constexpr ((AMODE == 0 || AMODE == 1) && WMODE == 0 && BK == 16 && BM == 128 && (BN == 128 || BN == 64)) {
+    if constexpr ((AMODE == 0 || AMODE == 1) && WMODE == 0 && BK == 16 && BM == 128 && (BN == 128 || BN == 64 || BN == 32)) {
         // split-precision path: needs pre-split weights and the FAST loader's preconditions
         static const int x3_allow = [] { const char* e = getenv("DBMM_IGEMM_X3"); return e ? atoi(e) : 1; }();
         static const int x2_allow = [] { const char* e = getenv("DBMM_IGEMM_X2"); return e ? atoi(e) : 1; }();
+        static const int x2_bk = [] { const char* e = getenv("DBMM_IGEMM_X2_BK"); return e ? atoi(e) : 32; }();
         if (x2_allow && p.wh && p.a_absmax && nbatch == 1 && fast_ok<AMODE, WMODE, BK>(p)) {
             constexpr int MB = X2_MINB(BN);
+            // 32-deep K chunks (half the barriers) when a chunk never straddles a filter tap
+            const bool bk32 = x2_bk == 32 && (p.K % 32) == 0 &&
+                              (AMODE == 0 || ((p.Cin % 32) == 0 && p.wl == DBMM_WL_TAP_MAJOR));
+            const int nkx = p.K / (bk32 ? 32 : 16);
             if (p.sk_blocks) {
                 p.sk_blocks = NUM_CUS * MB;
-                if ((long long)p.n_tiles * (p.K / 16) < 4LL * p.sk_blocks) p.sk_blocks = 0;
+                if ((long long)p.n_tiles * nkx < 4LL * p.sk_blocks || nkx < 8) p.sk_blocks = 0;
             }
             const dim3 g3(p.sk_blocks ? p.sk_blocks : p.n_tiles, 1);
-            if (p.sk_blocks)
-                hipLaunchKernelGGL((igemm_x3_kernel<BM, BN, WM, WN, AMODE, MB, 1, 2>), g3, dim3(256), 0, s, p);
-            else
-                hipLaunchKernelGGL((igemm_x3_kernel<BM, BN, WM, WN, AMODE, MB, 0, 2>), g3, dim3(256), 0, s, p);
-            g_last_cfg[7] = MB; g_last_cfg[8] = 2; g_last_cfg[9] = p.sk_blocks ? 1 : 0; g_last_cfg[10] = 0;
+            if (bk32) {
+                if (p.sk_blocks)
+                    hipLaunchKernelGGL((igemm_x3_kernel<BM, BN, WM, WN, AMODE, MB, 1, 2, 32>), g3, dim3(256), 0, s, p);
+                else
+                    hipLaunchKernelGGL((igemm_x3_kernel<BM, BN, WM, WN, AMODE, MB, 0, 2, 32>), g3, dim3(256), 0, s, p);
+            } else {
+                if (p.sk_blocks)
+                    hipLaunchKernelGGL((igemm_x3_kernel<BM, BN, WM, WN, AMODE, MB, 1, 2, 16>), g3, dim3(256), 0, s, p);
+                else
+                    hipLaunchKernelGGL((igemm_x3_kernel<BM, BN, WM, WN, AMODE, MB, 0, 2, 16>), g3, dim3(256), 0, s, p);
+            }
+            g_last_cfg[6] = bk32 ? 32 : 16; g_last_cfg[7] = MB; g_last_cfg[8] = 2; g_last_cfg[9] = p.sk_blocks ? 1 : 0;
+            g_last_cfg[10] = 0;
             DBMM_CHECK_LAUNCH();
             if (p.sk_blocks) {   // the fix-up needs a_absmax / w_exp too: its epilogue rescales the sums
-                hipLaunchKernelGGL((igemm_fixup_kernel<BM, BN, WM, WN, BK>), dim3(p.sk_blocks - 1), dim3(256), 0, s, p);
+                if (bk32)
+                    hipLaunchKernelGGL((igemm_fixup_kernel<BM, BN, WM, WN, 32>), dim3(p.sk_blocks - 1), dim3(256), 0, s, p);
+                else
+                    hipLaunchKernelGGL((igemm_fixup_kernel<BM, BN, WM, WN, 16>), dim3(p.sk_blocks - 1), dim3(256), 0, s, p);
                 DBMM_CHECK_LAUNCH();
             }
             return DBMM_OK;
         }
         p.a_absmax = nullptr;   // every other kernel takes A unscaled
+        if constexpr (BN != 32)
         if (x3_allow && p.w3 && nbatch == 1 && fast_ok<AMODE, WMODE, BK>(p)) {
             constexpr int MB = BN == 128 ? 2 : 3;   // register budget for the two prefetch sets (no spills)
             if (p.sk_blocks) {   // the resident grid is sized for this kernel's occupancy
@@ -888,9 +928,9 @@ int launch_cfg(IgemmP& p, hipStream_t s, int nbatch, void* ws, size_t ws_bytes) 
             }
             const dim3 g3(p.sk_blocks ? p.sk_blocks : p.n_tiles, 1);
             if (p.sk_blocks)
-                hipLaunchKernelGGL((igemm_x3_kernel<BM, BN, WM, WN, AMODE, MB, 1, 3>), g3, dim3(256), 0, s, p);
+                hipLaunchKernelGGL((igemm_x3_kernel<BM, BN, WM, WN, AMODE, MB, 1, 3, 16>), g3, dim3(256), 0, s, p);
             else
-                hipLaunchKernelGGL((igemm_x3_kernel<BM, BN, WM, WN, AMODE, MB, 0, 3>), g3, dim3(256), 0, s, p);
+                hipLaunchKernelGGL((igemm_x3_kernel<BM, BN, WM, WN, AMODE, MB, 0, 3, 16>), g3, dim3(256), 0, s, p);
             g_last_cfg[7] = MB; g_last_cfg[8] = 3; g_last_cfg[9] = p.sk_blocks ? 1 : 0; g_last_cfg[10] = 0;
             DBMM_CHECK_LAUNCH();
             if (p.sk_blocks) {

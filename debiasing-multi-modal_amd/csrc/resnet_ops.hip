@@ -13,14 +13,16 @@ namespace {
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void stem_s2_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                       const float* __restrict__ bias, float* __restrict__ y,
-                                                      int B, int H, int W, int Ho, int Wo, int Cout) {
+                                                      float* __restrict__ y_absmax, int B, int H, int W, int Ho,
+                                                      int Wo, int Cout) {
     extern __shared__ __attribute__((aligned(16))) float sw[];  // [27][Cout] then bias[Cout]
     for (int i = threadIdx.x; i < 27 * Cout; i += blockDim.x) sw[i] = w[i];
     for (int i = threadIdx.x; i < Cout; i += blockDim.x) sw[27 * Cout + i] = bias ? bias[i] : 0.f;
     __syncthreads();
     const long long m = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long M = (long long)B * Ho * Wo;
-    if (m >= M) return;
+    float omax = 0.f;                       // outputs are post-ReLU: max == max|y|
+    if (m < M) {
     const int wo = (int)(m % Wo), ho = (int)((m / Wo) % Ho), n = (int)(m / ((long long)Wo * Ho));
     float xin[27];
 #pragma unroll
@@ -56,6 +58,14 @@ __global__ __launch_bounds__(256) void stem_s2_kernel(const float* __restrict__ 
         }
         *(f32x4*)(yo + c0) = o0;
         *(f32x4*)(yo + c0 + 4) = o1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) omax = fmaxf(omax, fmaxf(o0[j], o1[j]));
+    }
+    }
+    if (y_absmax) {
+        omax = wave_max(omax);
+        if ((threadIdx.x & 63) == 0 && omax > *(volatile const float*)y_absmax)
+            atomicMax((unsigned*)y_absmax, __float_as_uint(omax));
     }
 }
 
@@ -124,7 +134,7 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(float* __restrict__ s
 }  // namespace
 
 extern "C" int dbmm_conv_stem_s2(const float* x_nchw, const float* w, const float* bias, float* y_nhwc,
-                                 int64_t B, int64_t H, int64_t W, int64_t Cout, void* stream) {
+                                 float* y_absmax, int64_t B, int64_t H, int64_t W, int64_t Cout, void* stream) {
     if (!x_nchw || !w || !y_nhwc) return DBMM_E_ARG;
     if (B <= 0 || H <= 0 || W <= 0 || Cout <= 0 || (Cout & 7) || Cout > 512) return DBMM_E_SHAPE;
     if (!dbmm_aligned16(y_nhwc)) return DBMM_E_ALIGN;
@@ -133,7 +143,7 @@ extern "C" int dbmm_conv_stem_s2(const float* x_nchw, const float* w, const floa
     if (M > INT32_MAX) return DBMM_E_SHAPE;
     const size_t smem = (size_t)(28 * Cout) * sizeof(float);
     hipLaunchKernelGGL(stem_s2_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), smem, (hipStream_t)stream,
-                       x_nchw, w, bias, y_nhwc, (int)B, (int)H, (int)W, (int)Ho, (int)Wo, (int)Cout);
+                       x_nchw, w, bias, y_nhwc, y_absmax, (int)B, (int)H, (int)W, (int)Ho, (int)Wo, (int)Cout);
     DBMM_CHECK_LAUNCH();
     return DBMM_OK;
 }

@@ -38,8 +38,8 @@ def _last_igemm_tag():
     """exact instantiation of the igemm launch just issued, spelled like rocprofv3's kernel name"""
     cfg = (ctypes.c_int * 11)()
     _lib.lib().dbmm_debug_last_igemm(cfg)
-    if cfg[8] in (2, 3):   # split-precision kernels: <BM, BN, WAVES_M, WAVES_N, AMODE, MINB, SK, NP>
-        return f"igemm_x3_kernel<{cfg[0]}, {cfg[1]}, {cfg[2]}, {cfg[3]}, {cfg[4]}, {cfg[7]}, {cfg[9]}, {cfg[8]}>"
+    if cfg[8] in (2, 3):   # split-precision kernels: <BM, BN, WAVES_M, WAVES_N, AMODE, MINB, SK, NP, BK>
+        return f"igemm_x3_kernel<{cfg[0]}, {cfg[1]}, {cfg[2]}, {cfg[3]}, {cfg[4]}, {cfg[7]}, {cfg[9]}, {cfg[8]}, {cfg[6]}>"
     return "igemm_f32_kernel<" + ", ".join(str(v) for v in cfg) + ">"
 
 
@@ -188,7 +188,7 @@ def conv_bn_act(x, w, bias, residual, kh, kw, stride, pad, act, w_layout=WL_TAP_
     return y
 
 
-def conv_stem_s2(x_nchw, w, bias):
+def conv_stem_s2(x_nchw, w, bias, y_absmax=None):
     require_cuda(x_nchw, w)
     _f32c(x_nchw); _f32c(w)
     B, C, H, W = x_nchw.shape
@@ -196,7 +196,8 @@ def conv_stem_s2(x_nchw, w, bias):
         raise _lib.DbmmError("stem conv expects 3 input channels")
     Cout = w.shape[-1]
     y = torch.empty((B, (H - 1) // 2 + 1, (W - 1) // 2 + 1, Cout), device=x_nchw.device, dtype=torch.float32)
-    check(_lib.lib().dbmm_conv_stem_s2(ptr(x_nchw), ptr(w), ptr(bias), ptr(y), B, H, W, Cout, stream()), "conv_stem_s2")
+    check(_lib.lib().dbmm_conv_stem_s2(ptr(x_nchw), ptr(w), ptr(bias), ptr(y), ptr(y_absmax), B, H, W, Cout, stream()),
+          "conv_stem_s2")
     return y
 
 

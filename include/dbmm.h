@@ -143,9 +143,10 @@ int dbmm_gemm_batched(const float* a, int64_t lda, int64_t stride_a, int trans_a
  * ------------------------------------------------------------------------------------ */
 
 /* stem conv1: 3x3 stride 2 pad 1 on the NCHW image, BN folded, ReLU, NHWC out
- * (clip/model.py:108-110,140).  w is [3][3][3][Cout] = (kh, kw, cin, cout). */
+ * (clip/model.py:108-110,140).  w is [3][3][3][Cout] = (kh, kw, cin, cout).  y_absmax (optional,
+ * zeroed by the caller) receives max|y| like dbmm_conv_bn_act_x2's. */
 int dbmm_conv_stem_s2(const float* x_nchw, const float* w, const float* bias, float* y_nhwc,
-                      int64_t B, int64_t H, int64_t W, int64_t Cout, void* stream);
+                      float* y_absmax, int64_t B, int64_t H, int64_t W, int64_t Cout, void* stream);
 
 /* AvgPool2d(k) with kernel = stride = k, NHWC (clip/model.py:25,37,117). C % 4 == 0. */
 int dbmm_avgpool2d(const float* x, float* y, int64_t B, int64_t H, int64_t W, int64_t C,

@@ -106,8 +106,10 @@ def test_conv_chunk_major_weights(B, H, Cin, Cout):
 def test_conv_stem_s2(B, R, Cout):
     x = rnd(1, "x", (B, 3, R, R)); w = rnd(2, "w", (Cout, 3, 3, 3), 27 ** -0.5); b = rnd(3, "b", (Cout,), 0.1)
     ref = F.relu(F.conv2d(x, w, b, stride=2, padding=1)).permute(0, 2, 3, 1)
-    out = ops.conv_stem_s2(x.to(DEV), w.permute(2, 3, 1, 0).contiguous().to(DEV), b.to(DEV))
+    am = torch.zeros(1, device=DEV)
+    out = ops.conv_stem_s2(x.to(DEV), w.permute(2, 3, 1, 0).contiguous().to(DEV), b.to(DEV), y_absmax=am)
     assert relerr(out.cpu(), ref) < 1e-5
+    assert am.item() == out.max().item()
 
 
 @pytest.mark.parametrize("k", [2, 7])
@@ -370,7 +372,8 @@ def _x2_conv(xd, wp, wl, bd, rd, k, act, x_bound):
 
 @pytest.mark.parametrize("B,H,Cin,Cout,k,res", [(2, 16, 32, 128, 3, False), (3, 14, 64, 64, 3, True), (2, 9, 16, 48, 3, False),
                                                 (4, 7, 512, 256, 3, False), (128, 14, 256, 256, 3, True),
-                                                (2, 12, 64, 256, 1, True), (64, 28, 128, 128, 3, False)])
+                                                (2, 12, 64, 256, 1, True), (64, 28, 128, 128, 3, False),
+                                                (4, 20, 32, 32, 3, False), (3, 11, 48, 32, 3, True)])
 def test_conv_fp16_pair(B, H, Cin, Cout, k, res):
     """fp16 hi+lo operands with power-of-two scales, three partial products: fp32-level accuracy
     against an fp64 reference (no worse than the fp32-MFMA kernel); the output-maximum scalar
@@ -432,7 +435,7 @@ def test_conv_fp16_pair_stream_k():
                             x_absmax=xd.abs().max().reshape(1), y_absmax=yam)
         tag = ops._last_igemm_tag()
         e = ((o.cpu().double() - ref).abs().max() / ref.abs().max()).item()
-        assert tag.startswith("igemm_x3_kernel<") and tag.endswith(", 1, 2>"), tag
+        assert tag.startswith("igemm_x3_kernel<") and tag.endswith(", 1, 2, 32>"), tag   # SK = 1, NP = 2, BK = 32
         assert e < 5e-6, e
         assert yam.item() == o.abs().max().item()
         print("ok")
