@@ -554,6 +554,12 @@ __device__ __forceinline__ void igemm_tile_x3(const IgemmP& p, float* lds, int t
     __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.a, 0, (int)p.a_bytes, 0x00020000);
     __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)(NP == 3 ? p.w3 : p.wh), 0,
                                                                    (int)(NP == 3 ? p.w3_bytes : p.wh_bytes), 0x00020000);
+    // zero-extent twins: a load through them returns zeros without touching memory.  The chunk
+    // loads past the end of the K range go through these instead of being branched around -- a
+    // conditional load makes the compiler's vmcnt bookkeeping assume the worst path and wait for
+    // the NEWEST loads before the split, which silently turned the two-chunk prefetch into one.
+    __amdgpu_buffer_rsrc_t rsA0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.a, 0, 0, 0x00020000);
+    __amdgpu_buffer_rsrc_t rsW0 = __builtin_amdgcn_make_buffer_rsrc((void*)(NP == 3 ? p.w3 : p.wh), 0, 0, 0x00020000);
     float a_sc = 1.f;
     if constexpr (NP == 2) a_sc = pow2f(a_scale_exp(p.a_absmax));
     const unsigned plane_bytes = (unsigned)p.N * (unsigned)p.ldw * 2u;
@@ -599,16 +605,17 @@ __device__ __forceinline__ void igemm_tile_x3(const IgemmP& p, float* lds, int t
     // Cache latency (ablation on the bf16 kernel: 31 % of the time)
     f32x4 a_r0[ALD], a_r1[ALD];
     u32x4 w_r0[NP * WLD], w_r1[NP * WLD];
-    auto load_chunk = [&](int k0, f32x4 (&a_reg)[ALD], u32x4 (&w_reg)[NP * WLD]) {
+    auto load_chunk = [&](int k0, f32x4 (&a_reg)[ALD], u32x4 (&w_reg)[NP * WLD], bool valid) {
+        const __amdgpu_buffer_rsrc_t ra = valid ? rsA : rsA0, rw = valid ? rsW : rsW0;   // scalar selects
         if constexpr (AMODE == 0) {
 #pragma unroll
-            for (int i = 0; i < ALD; ++i) a_reg[i] = buf_load16(rsA, fa_off[i], (unsigned)k0 * 4u);
+            for (int i = 0; i < ALD; ++i) a_reg[i] = buf_load16(ra, fa_off[i], (unsigned)k0 * 4u);
         } else {
             const unsigned delta = ((unsigned)(f_kh * p.W + f_kw) * (unsigned)p.Cin + (unsigned)f_ci0) * 4u;
             const unsigned bit = 1u << f_tap;
 #pragma unroll
             for (int i = 0; i < ALD; ++i)
-                a_reg[i] = buf_load16(rsA, (fa_mask[i] & bit) ? fa_off[i] + delta : OOR, 0u);
+                a_reg[i] = buf_load16(ra, (fa_mask[i] & bit) ? fa_off[i] + delta : OOR, 0u);
             if (BK == 16 && p.wl == DBMM_WL_CHUNK_MAJOR) {
                 ++f_tap;
                 if (++f_kw == p.KW) { f_kw = 0; ++f_kh; }
@@ -625,7 +632,7 @@ __device__ __forceinline__ void igemm_tile_x3(const IgemmP& p, float* lds, int t
         for (int pl = 0; pl < NP; ++pl)
 #pragma unroll
             for (int j = 0; j < WLD; ++j)
-                w_reg[pl * WLD + j] = __builtin_amdgcn_raw_buffer_load_b128(rsW, fw_off[j], pl * plane_bytes + (unsigned)k0 * 2u, 0);
+                w_reg[pl * WLD + j] = __builtin_amdgcn_raw_buffer_load_b128(rw, fw_off[j], pl * plane_bytes + (unsigned)k0 * 2u, 0);
     };
     auto store_chunk = [&](int stage, const f32x4 (&a_reg)[ALD], const u32x4 (&w_reg)[NP * WLD]) {
         u16* Ab = Ap + stage * STAGE;              // planes [NP][BM][BK]
@@ -705,19 +712,19 @@ __device__ __forceinline__ void igemm_tile_x3(const IgemmP& p, float* lds, int t
     };
 
     __syncthreads();
-    load_chunk(kb * BK, a_r0, w_r0);
-    if (kb + 1 < ke) load_chunk((kb + 1) * BK, a_r1, w_r1);
+    load_chunk(kb * BK, a_r0, w_r0, true);
+    load_chunk((kb + 1) * BK, a_r1, w_r1, kb + 1 < ke);
     store_chunk(0, a_r0, w_r0);
     __syncthreads();
 
     // chunk kc lives in LDS stage (kc-kb)&1; set r1 holds chunk kc+1 on even steps, r0 on odd ones
     for (int kc = kb; kc < ke; kc += 2) {
-        if (kc + 2 < ke) load_chunk((kc + 2) * BK, a_r0, w_r0);
+        load_chunk((kc + 2) * BK, a_r0, w_r0, kc + 2 < ke);
         compute(0);
         if (kc + 1 < ke) store_chunk(1, a_r1, w_r1);
         __syncthreads();
         if (kc + 1 >= ke) break;
-        if (kc + 3 < ke) load_chunk((kc + 3) * BK, a_r1, w_r1);
+        load_chunk((kc + 3) * BK, a_r1, w_r1, kc + 3 < ke);
         compute(1);
         if (kc + 2 < ke) store_chunk(0, a_r0, w_r0);
         __syncthreads();
