@@ -719,14 +719,15 @@ __device__ __forceinline__ void igemm_tile_x3(const IgemmP& p, float* lds, int t
 
     // chunk kc lives in LDS stage (kc-kb)&1; set r1 holds chunk kc+1 on even steps, r0 on odd ones
     for (int kc = kb; kc < ke; kc += 2) {
+        // (no branches inside: a chunk past the end arrives as zeros through the zero-extent
+        //  descriptors and adds nothing; an odd chunk count costs one phantom chunk)
         load_chunk((kc + 2) * BK, a_r0, w_r0, kc + 2 < ke);
         compute(0);
-        if (kc + 1 < ke) store_chunk(1, a_r1, w_r1);
+        store_chunk(1, a_r1, w_r1);
         __syncthreads();
-        if (kc + 1 >= ke) break;
         load_chunk((kc + 3) * BK, a_r1, w_r1, kc + 3 < ke);
         compute(1);
-        if (kc + 2 < ke) store_chunk(0, a_r0, w_r0);
+        store_chunk(0, a_r0, w_r0);
         __syncthreads();
     }
 
