@@ -92,6 +92,8 @@ _SIGS = {
     "dbmm_sgd_momentum": [_L, _P, _P, _P, _P, _F, _F, _F, _I, _P],
     "dbmm_workspace_bytes_adapter_train_step": [_L, _L, _L, _I],
     "dbmm_adapter_train_step": [_P] * 26 + [_F, _P, _F, _F, _F, _F, _I, _P, _P, _P, _L, _L, _L, _L, _P, _Z, _P],
+    "dbmm_workspace_bytes_preprocess": [_L, _L],
+    "dbmm_resize_crop_normalize_u8": [_P, _L, _L, _P, _P, _L, _P, _P, _L, _L, _L, _L, _P, _P, _P, _P, _P, _Z, _P],
     "dbmm_gather_rows": [_P, _P, _P, _L, _L, _L, _P],
     "dbmm_group_count": [_P, _P, _P, _P, _L, _L, _L, _P],
     "dbmm_group_loss_sum": [_P, _P, _P, _L, _L, _P],
@@ -99,6 +101,7 @@ _SIGS = {
 _RESTYPES = {
     "dbmm_error_string": ctypes.c_char_p,
     "dbmm_workspace_bytes_attnpool": c_size_t,
+    "dbmm_workspace_bytes_preprocess": c_size_t,
     "dbmm_workspace_bytes_igemm": c_size_t,
     "dbmm_split_planes_bytes": c_size_t,
     "dbmm_split_planes_f16_bytes": c_size_t,

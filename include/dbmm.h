@@ -126,6 +126,24 @@ int dbmm_conv_bn_act_x2(const float* x, const float* x_absmax, const float* w, c
                         int64_t stride, int64_t pad, int act, int w_layout, void* workspace,
                         size_t workspace_bytes, void* stream);
 
+/* ---------------------------------------------------------------------------------------
+ * Device-side preprocessing (clip/clip.py:79-86: Resize(BICUBIC) -> CenterCrop -> ToTensor ->
+ * Normalize) of one decoded RGB uint8 image [H][W][3] resident on the device.  Integer
+ * resampling exactly as Pillow's 8-bit resampler (22-bit fixed-point coefficients, horizontal
+ * then vertical pass, each rounded to uint8); the caller supplies the coefficient tables of
+ * the R crop columns / rows (bounds = (first source index, tap count) pairs; the vertical
+ * bounds relative to row0; see preprocess.py::resample_coeffs) as device int32 arrays.
+ * mean3 / std3 are HOST pointers to 3 floats.  out_chw = float32 [3][R][R]; out_u8_hwc
+ * (optional) = the resized + cropped uint8 image [R][R][3].  workspace >=
+ * dbmm_workspace_bytes_preprocess(nrows, R) bytes.
+ * ------------------------------------------------------------------------------------ */
+size_t dbmm_workspace_bytes_preprocess(int64_t nrows, int64_t R);
+int dbmm_resize_crop_normalize_u8(const uint8_t* img_hwc, int64_t H, int64_t W, const int32_t* h_bounds,
+                                  const int32_t* h_coeffs, int64_t h_ksize, const int32_t* v_bounds,
+                                  const int32_t* v_coeffs, int64_t v_ksize, int64_t row0, int64_t nrows,
+                                  int64_t R, const float* mean3, const float* std3, float* out_chw,
+                                  uint8_t* out_u8_hwc, void* workspace, size_t workspace_bytes, void* stream);
+
 /* profiling aid: the 11 template arguments <BM,BN,WAVES_M,WAVES_N,AMODE,WMODE,BK,MINB,FAST,SK,DMA>
  * of the calling thread's most recent igemm launch (= the kernel name rocprofv3 reports). */
 void dbmm_debug_last_igemm(int* out11);
