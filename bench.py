@@ -44,13 +44,15 @@ from dbmm_amd.clip.model import build_model  # noqa: E402
 FP32_MFMA_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md, chip table (v_mfma_f32_32x32x2_f32)
 F16_MFMA_PEAK_TFLOPS = 2500.0          # dense fp16 MFMA, same table (same rate as bf16)
 # 16-bit partial products a split-precision kernel issues per fp32 product, by plane count
-SPLIT_PRODUCTS = {2: 3, 3: 6}
+SPLIT_PRODUCTS = {(2, 1): 2, (2, 2): 3, (3, 3): 6}
 RN50_GFLOP_PER_IMG = 11.59             # SURVEY.md section 8d (conv 5.367 + attn-pool 0.426 GMAC)
 # dominant kernel: 3x3 implicit-GEMM conv, 128x128 tile, one tile per workgroup
-# (template arguments <BM, BN, WAVES_M, WAVES_N, AMODE=1 (conv), MINB, SK=0, NP, BK>; NP = 2: fp16 pair, 3: bf16 triple)
-DOMINANT_SPLIT = ("igemm_x3_kernel<128, 128, 2, 2, 1, 2, 0, 2, 32>",        # default path
-                  "igemm_x3_kernel<128, 128, 2, 2, 1, 2, 0, 2, 16>",        # DBMM_IGEMM_X2_BK=16
-                  "igemm_x3_kernel<128, 128, 2, 2, 1, 2, 0, 3, 16>")        # DBMM_CONV_SPLIT=bf16
+# (template arguments <BM, BN, WAVES_M, WAVES_N, AMODE=1 (conv), MINB, SK=0, NP, NW, BK>; NP / NW = 16-bit planes
+#  of the activations / weights: 2, 1 = fp16 pair x exact fp16 weight; 2, 2 = fp16 pair x pair; 3, 3 = bf16 triple)
+DOMINANT_SPLIT = ("igemm_x3_kernel<128, 128, 2, 2, 1, 3, 0, 2, 1, 32>",     # default path
+                  "igemm_x3_kernel<128, 128, 2, 2, 1, 2, 0, 2, 2, 32>",     # weights not exact in fp16
+                  "igemm_x3_kernel<128, 128, 2, 2, 1, 2, 0, 2, 2, 16>",     # DBMM_IGEMM_X2_BK=16
+                  "igemm_x3_kernel<128, 128, 2, 2, 1, 2, 0, 3, 3, 16>")     # DBMM_CONV_SPLIT=bf16
 DOMINANT_F32 = "igemm_f32_kernel<128, 128, 2, 2, 1, 0, 16, 4, 1, 0, 1>"    # fp32-MFMA path (DBMM_CONV_SPLIT=off)
 
 
@@ -183,7 +185,7 @@ def main():
         value = B * args.steps / dt
         DOMINANT = next((k for k in DOMINANT_SPLIT if k in prof), DOMINANT_F32)
         split = DOMINANT in DOMINANT_SPLIT
-        n_prod = SPLIT_PRODUCTS[int(DOMINANT.rstrip(">").split(",")[-2])] if split else 1
+        n_prod = SPLIT_PRODUCTS[tuple(int(v) for v in DOMINANT.rstrip(">").split(",")[-3:-1])] if split else 1
         peak = F16_MFMA_PEAK_TFLOPS / n_prod if split else FP32_MFMA_PEAK_TFLOPS
         n, fl, ms = prof.get(DOMINANT, (0, 0.0, 0.0))
         ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0

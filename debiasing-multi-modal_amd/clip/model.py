@@ -14,6 +14,7 @@ C ABI (ops.py).  Activations are fp32 NHWC / batch-first tokens.  Compute dtype 
 needs; there is no fp16 cast of the weights, `.dtype` reports float32.
 """
 import os
+import re
 from collections import OrderedDict
 from typing import Tuple, Union
 
@@ -108,21 +109,41 @@ def _fold_bn(conv_w, bn):
     return w, b
 
 
+def _conv_bn(conv, bn):
+    """operands of one conv + eval-mode BatchNorm (see _pack_conv)"""
+    w, b = _fold_bn(conv.weight, bn)
+    scale = bn.weight.detach().double() / torch.sqrt(bn.running_var.detach().double() + bn.eps)
+    return _pack_conv(w, b, raw=conv.weight.detach().float(), scale=scale)
+
+
 # how the conv weights are split for the matrix cores: "f16" = fp16 pair + per-tensor power-of-two
 # scales (three partial products), "bf16" = bf16 triple (six), "off" = fp32-input MFMA only.
 # All three are fp32-accurate; the switch exists for ablation runs.
 CONV_SPLIT = os.environ.get("DBMM_CONV_SPLIT", "f16")
 
 
-def _pack_conv(w64, bias):
+def _pack_conv(w64, bias, raw=None, scale=None):
     """[Cout][Cin][kh][kw] fp64 (BN folded) -> dict of ops.conv_bn_act operands: packed fp32 weight,
     layout id, bias, and the pre-split planes for the split-precision kernels (shapes those do not
-    cover fall back to the fp32-MFMA kernel inside the library)."""
+    cover fall back to the fp32-MFMA kernel inside the library).
+    raw / scale: the conv weight as stored and the BatchNorm scale gamma / sqrt(var + eps).  The
+    reference keeps conv weights in fp16 (build_model, clip/model.py:433), so `raw` times a power
+    of two is exact in fp16: the fp16-pair kernel then needs ONE weight plane and two partial
+    products, with the BatchNorm scale applied to the accumulator in the epilogue (`sc`) instead
+    of being folded into (and de-fp16-ing) the weights."""
+    if raw is not None and CONV_SPLIT == "f16" and raw.is_cuda:
+        w, wl = ops.pack_conv_weight(raw)
+        K, cin = w.shape[1], raw.shape[1]
+        if K % 32 == 0 and (raw.shape[2] * raw.shape[3] == 1 or cin % 32 == 0):
+            ph, we, n = ops.split_planes_f16(w, allow_single=True)
+            if n == 1:
+                return dict(w=w, wl=wl, b=bias.float().contiguous(), p3=None, ph=ph, we=we,
+                            sc=scale.float().contiguous())
     w, wl = ops.pack_conv_weight(w64)
-    c = dict(w=w, wl=wl, b=bias.float().contiguous(), p3=None, ph=None, we=0)
+    c = dict(w=w, wl=wl, b=bias.float().contiguous(), p3=None, ph=None, we=0, sc=None)
     if w.is_cuda and w.shape[1] % 16 == 0 and (w.shape[0] > 32 or CONV_SPLIT == "f16"):
         if CONV_SPLIT == "f16":
-            c["ph"], c["we"] = ops.split_planes_f16(w)
+            c["ph"], c["we"], _ = ops.split_planes_f16(w)
         elif CONV_SPLIT == "bf16":
             c["p3"] = ops.split_planes(w)
     return c
@@ -161,18 +182,15 @@ class ModifiedResNet(nn.Module):
         w, b = _fold_bn(self.conv1.weight, self.bn1)
         P["stem1"] = (w.permute(2, 3, 1, 0).contiguous().float(), b.float().contiguous())   # [kh][kw][cin][cout]
         for i in (2, 3):
-            w, b = _fold_bn(getattr(self, f"conv{i}").weight, getattr(self, f"bn{i}"))
-            P[f"stem{i}"] = _pack_conv(w, b)
+            P[f"stem{i}"] = _conv_bn(getattr(self, f"conv{i}"), getattr(self, f"bn{i}"))
         blocks = []
         for li in (1, 2, 3, 4):
             for blk in getattr(self, f"layer{li}"):
                 e = {"stride": blk.stride}
                 for i in (1, 2, 3):
-                    w, b = _fold_bn(getattr(blk, f"conv{i}").weight, getattr(blk, f"bn{i}"))
-                    e[f"c{i}"] = _pack_conv(w, b)
+                    e[f"c{i}"] = _conv_bn(getattr(blk, f"conv{i}"), getattr(blk, f"bn{i}"))
                 if blk.downsample is not None:
-                    w, b = _fold_bn(getattr(blk.downsample, "0").weight, getattr(blk.downsample, "1"))
-                    e["ds"] = _pack_conv(w, b)
+                    e["ds"] = _conv_bn(getattr(blk.downsample, "0"), getattr(blk.downsample, "1"))
                 blocks.append(e)
         P["blocks"] = blocks
         ap = self.attnpool
@@ -199,7 +217,7 @@ class ModifiedResNet(nn.Module):
         def conv(t, t_am, c, res, k, pad, act):
             y_am = amax[slot[0]:slot[0] + 1]; slot[0] += 1
             y = ops.conv_bn_act(t, c["w"], c["b"], res, k, k, 1, pad, act, c["wl"], w_planes=c["p3"],
-                                w_planes_f16=c["ph"], w_exp=c["we"], x_absmax=t_am, y_absmax=y_am)
+                                w_planes_f16=c["ph"], w_exp=c["we"], x_absmax=t_am, y_absmax=y_am, out_scale=c["sc"])
             return y, y_am
 
         x, am = conv(x, amax[0:1], P["stem2"], None, 3, 1, ops.ACT_RELU)
@@ -392,7 +410,24 @@ def build_model(state_dict: dict):
     transformer_layers = len({k.split(".")[2] for k in state_dict if k.startswith("transformer.resblocks")})
     model = CLIP(embed_dim, image_resolution, vision_layers, vision_width, vision_patch_size, context_length,
                  vocab_size, transformer_width, transformer_width // 64, transformer_layers)
-    sd = OrderedDict((k, v.float() if v.is_floating_point() else v) for k, v in state_dict.items()
+    sd = OrderedDict((k, _as_loaded(k, v)) for k, v in state_dict.items()
                      if k not in ("input_resolution", "context_length", "vocab_size"))
     model.load_state_dict(sd)
     return model.eval()
+
+
+# The reference converts conv / linear / attention-projection weights and biases and the two
+# projection matrices to fp16 BEFORE load_state_dict (convert_weights, clip/model.py:375-396,433),
+# so whatever the checkpoint holds is rounded to fp16 there; on the CPU path the model is then
+# cast back with .float() (clip/clip.py:139-141).  BatchNorm / LayerNorm parameters, positional
+# and class embeddings, the token table and logit_scale stay fp32.
+_FP16_KEYS = re.compile(r"(conv\d\.weight|downsample\.0\.weight|_proj\.(weight|bias)|in_proj_(weight|bias)"
+                        r"|c_fc\.(weight|bias))$")
+
+
+def _as_loaded(key, v):
+    if not v.is_floating_point():
+        return v
+    if _FP16_KEYS.search(key) or key in ("text_projection", "visual.proj"):
+        return v.half().float()
+    return v.float()

@@ -69,6 +69,8 @@ struct IgemmP {
     const unsigned short* wh;           // fp16-pair path: W * 2^w_exp as two fp16 planes [2][N][ldw]
     unsigned wh_bytes;
     int w_exp;
+    int nw;                             // fp16-pair path: W planes present (2 = hi + lo, 1 = W exact in fp16)
+    const float* oscale;                // optional per-output-channel scale applied to the accumulator (unfolded BN)
     const float* a_absmax;              // fp16-pair path: device scalar >= max|A| (null: path not in use)
     float* absmax_out;                  // optional device scalar: atomic max of |C| over the written outputs
 };
@@ -521,9 +523,9 @@ __device__ __forceinline__ void split2h(float xs, u16& hi, u16& lo) {
     hi = __builtin_bit_cast(u16, h); lo = __builtin_bit_cast(u16, l);
 }
 
-template <int BM, int BN, int NP, int BK>
-struct GeoX3 {   // LDS floats for the split path (NP 16-bit planes, two stages) vs the epilogue staging
-    static constexpr int STAGE_U16 = NP * (BM + BN) * BK;
+template <int BM, int BN, int NP, int NW, int BK>
+struct GeoX3 {   // LDS floats for the split path (NP / NW 16-bit planes of A / W, two stages) vs the epilogue staging
+    static constexpr int STAGE_U16 = (NP * BM + NW * BN) * BK;
     static constexpr int TILE_FLOATS = 2 * STAGE_U16 / 2;
 };
 
@@ -532,17 +534,18 @@ struct GeoX3 {   // LDS floats for the split path (NP 16-bit planes, two stages)
 template <int BK>
 __device__ __forceinline__ int x3_swz(int row) { return BK == 16 ? ((row >> 3) & 1) : ((row >> 2) & 3); }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int AMODE, int NP, int BK>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int AMODE, int NP, int NW, int BK>
 __device__ __forceinline__ void igemm_tile_x3(const IgemmP& p, float* lds, int tile, int kb, int ke, float* partial) {
     static_assert(BK == 16 || BK == 32, "BK");
+    static_assert((NP == 3 && NW == 3) || (NP == 2 && (NW == 2 || NW == 1)), "planes");
     using G = Geo<BM, BN, WAVES_M, WAVES_N, BK>;
     constexpr int TM = G::TM, TN = G::TN, WTN = G::WTN, LROW = G::LROW;
     constexpr int QPR = BK / 4, RPA = 256 / QPR;   // A: k-quads (4 fp32) per row, rows per pass of the 256 threads
     constexpr int ALD = BM / RPA;                  // float4 loads per thread per chunk
     constexpr int CPW = BK / 8, RPW = 256 / CPW;   // W: 16-B chunks (8 halves) per plane row, rows per pass
     constexpr int WLD = (BN + RPW - 1) / RPW;      // b128 loads per thread per plane per chunk
-    constexpr int STAGE = GeoX3<BM, BN, NP, BK>::STAGE_U16;
-    u16* Ap = (u16*)lds;                           // per stage: [NP][BM][BK] then [NP][BN][BK]
+    constexpr int STAGE = GeoX3<BM, BN, NP, NW, BK>::STAGE_U16;
+    u16* Ap = (u16*)lds;                           // per stage: [NP][BM][BK] then [NW][BN][BK]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m0 = (tile / p.tiles_n) * BM, n0 = (tile % p.tiles_n) * BN;
     const int wm0 = (wave / WAVES_N) * (TM * 32), wn0 = (wave % WAVES_N) * (TN * 32);
@@ -604,8 +607,8 @@ __device__ __forceinline__ void igemm_tile_x3(const IgemmP& p, float* lds, int t
     // (already landed) is split into LDS -- one chunk of lead did not cover the L2 / Infinity-
     // Cache latency (ablation on the bf16 kernel: 31 % of the time)
     f32x4 a_r0[ALD], a_r1[ALD];
-    u32x4 w_r0[NP * WLD], w_r1[NP * WLD];
-    auto load_chunk = [&](int k0, f32x4 (&a_reg)[ALD], u32x4 (&w_reg)[NP * WLD], bool valid) {
+    u32x4 w_r0[NW * WLD], w_r1[NW * WLD];
+    auto load_chunk = [&](int k0, f32x4 (&a_reg)[ALD], u32x4 (&w_reg)[NW * WLD], bool valid) {
         const __amdgpu_buffer_rsrc_t ra = valid ? rsA : rsA0, rw = valid ? rsW : rsW0;   // scalar selects
         if constexpr (AMODE == 0) {
 #pragma unroll
@@ -629,14 +632,14 @@ __device__ __forceinline__ void igemm_tile_x3(const IgemmP& p, float* lds, int t
             }
         }
 #pragma unroll
-        for (int pl = 0; pl < NP; ++pl)
+        for (int pl = 0; pl < NW; ++pl)
 #pragma unroll
             for (int j = 0; j < WLD; ++j)
                 w_reg[pl * WLD + j] = __builtin_amdgcn_raw_buffer_load_b128(rw, fw_off[j], pl * plane_bytes + (unsigned)k0 * 2u, 0);
     };
-    auto store_chunk = [&](int stage, const f32x4 (&a_reg)[ALD], const u32x4 (&w_reg)[NP * WLD]) {
+    auto store_chunk = [&](int stage, const f32x4 (&a_reg)[ALD], const u32x4 (&w_reg)[NW * WLD]) {
         u16* Ab = Ap + stage * STAGE;              // planes [NP][BM][BK]
-        u16* Wb = Ab + NP * BM * BK;               // planes [NP][BN][BK]
+        u16* Wb = Ab + NP * BM * BK;               // planes [NW][BN][BK]
 #pragma unroll
         for (int i = 0; i < ALD; ++i) {
             const int row = lr + RPA * i;
@@ -658,7 +661,7 @@ __device__ __forceinline__ void igemm_tile_x3(const IgemmP& p, float* lds, int t
             if (row < BN) {
                 const int off = row * BK + ((wc ^ x3_swz<BK>(row)) << 3);
 #pragma unroll
-                for (int pl = 0; pl < NP; ++pl) *(u32x4*)(Wb + pl * BN * BK + off) = w_reg[pl * WLD + j];
+                for (int pl = 0; pl < NW; ++pl) *(u32x4*)(Wb + pl * BN * BK + off) = w_reg[pl * WLD + j];
             }
         }
     };
@@ -681,21 +684,25 @@ __device__ __forceinline__ void igemm_tile_x3(const IgemmP& p, float* lds, int t
             // this lane's 8 k values of sub-step ks: chunk 2*ks + fh, swizzled (tile row offsets are
             // multiples of 32, so the swizzle depends on fr only)
             const int fch = ((2 * ks + fh) ^ x3_swz<BK>(fr)) << 3;
-            u32x4 af[TM][NP], wf[TN][NP];
+            u32x4 af[TM][NP], wf[TN][NW];
 #pragma unroll
-            for (int pl = 0; pl < NP; ++pl) {
+            for (int pl = 0; pl < NP; ++pl)
 #pragma unroll
                 for (int i = 0; i < TM; ++i) af[i][pl] = *(const u32x4*)(Ab + pl * BM * BK + (wm0 + i * 32 + fr) * BK + fch);
 #pragma unroll
+            for (int pl = 0; pl < NW; ++pl)
+#pragma unroll
                 for (int j = 0; j < TN; ++j) wf[j][pl] = *(const u32x4*)(Wb + pl * BN * BK + (wn0 + j * 32 + fr) * BK + fch);
-            }
-            // smallest partial products first: bf16 (h,l) (l,h) (m,m) (h,m) (m,h) (h,h); fp16 (h,l) (l,h) (h,h)
-            constexpr int NQ = NP == 3 ? 6 : 3;
+            // smallest partial products first: bf16 (h,l) (l,h) (m,m) (h,m) (m,h) (h,h); fp16 (h,l) (l,h) (h,h);
+            // fp16 with W exact in one plane: (l,w) (h,w)
+            constexpr int NQ = NP == 3 ? 6 : (NW == 2 ? 3 : 2);
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
                 constexpr int PA3[6] = {0, 2, 1, 0, 1, 0}, PB3[6] = {2, 0, 1, 1, 0, 0};
                 constexpr int PA2[3] = {0, 1, 0}, PB2[3] = {1, 0, 0};
-                const int pa = NP == 3 ? PA3[q] : PA2[q], pb = NP == 3 ? PB3[q] : PB2[q];
+                constexpr int PA1[2] = {1, 0}, PB1[2] = {0, 0};
+                const int pa = NP == 3 ? PA3[q] : (NW == 2 ? PA2[q] : PA1[q]);
+                const int pb = NP == 3 ? PB3[q] : (NW == 2 ? PB2[q] : PB1[q]);
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -746,14 +753,14 @@ __device__ __forceinline__ void igemm_tile_x3(const IgemmP& p, float* lds, int t
     }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int AMODE, int MINB, int SK, int NP, int BK>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int AMODE, int MINB, int SK, int NP, int NW, int BK>
 __global__ __launch_bounds__(256, MINB) void igemm_x3_kernel(const IgemmP p) {
     using G = Geo<BM, BN, WAVES_M, WAVES_N, BK>;
-    constexpr int LDSF = GeoX3<BM, BN, NP, BK>::TILE_FLOATS > G::EPI_FLOATS ? GeoX3<BM, BN, NP, BK>::TILE_FLOATS : G::EPI_FLOATS;
+    constexpr int LDSF = GeoX3<BM, BN, NP, NW, BK>::TILE_FLOATS > G::EPI_FLOATS ? GeoX3<BM, BN, NP, NW, BK>::TILE_FLOATS : G::EPI_FLOATS;
     __shared__ __attribute__((aligned(16))) float lds[LDSF];
     const int nk = p.K / BK;
     if constexpr (!SK) {
-        igemm_tile_x3<BM, BN, WAVES_M, WAVES_N, AMODE, NP, BK>(p, lds, xcd_remap(blockIdx.x, p.n_tiles), 0, nk, nullptr);
+        igemm_tile_x3<BM, BN, WAVES_M, WAVES_N, AMODE, NP, NW, BK>(p, lds, xcd_remap(blockIdx.x, p.n_tiles), 0, nk, nullptr);
     } else {
         const long long U = (long long)p.n_tiles * nk;
         long long u = U * blockIdx.x / p.sk_blocks;
@@ -764,7 +771,7 @@ __global__ __launch_bounds__(256, MINB) void igemm_x3_kernel(const IgemmP p) {
             float* partial = (kb == 0 && ke == nk)
                                  ? nullptr
                                  : p.sk_ws + ((size_t)blockIdx.x * 2 + (seg ? 1 : 0)) * (size_t)(BM * BN);
-            igemm_tile_x3<BM, BN, WAVES_M, WAVES_N, AMODE, NP, BK>(p, lds, tile, kb, ke, partial);
+            igemm_tile_x3<BM, BN, WAVES_M, WAVES_N, AMODE, NP, NW, BK>(p, lds, tile, kb, ke, partial);
             u += ke - kb;
         }
     }
@@ -860,7 +867,9 @@ constexpr int NUM_CUS = 256;
 // name the exact instantiation rocprofv3 reports); not used by any compute path
 thread_local int g_last_cfg[11] = {0};
 
-constexpr int X2_MINB(int BN) { return BN == 128 ? 2 : 3; }   // registers (128x128) / LDS (narrower tiles)
+// resident workgroups per CU of the fp16-pair kernels: the 128x128 tile with two W planes is held
+// to 2 by its 64 KB of LDS; with one W plane (48 KB, <= 168 VGPRs) and for the narrower tiles it is 3
+constexpr int X2_MINB(int BN, int NW) { return (BN == 128 && NW == 2) ? 2 : 3; }
 
 template <int BM, int BN, int WM, int WN, int AMODE, int WMODE, int BK, int MINB>
 int launch_cfg(IgemmP& p, hipStream_t s, int nbatch, void* ws, size_t ws_bytes) {
@@ -892,30 +901,36 @@ int launch_cfg(IgemmP& p, hipStream_t s, int nbatch, void* ws, size_t ws_bytes) 
         static const int x3_allow = [] { const char* e = getenv("DBMM_IGEMM_X3"); return e ? atoi(e) : 1; }();
         static const int x2_allow = [] { const char* e = getenv("DBMM_IGEMM_X2"); return e ? atoi(e) : 1; }();
         static const int x2_bk = [] { const char* e = getenv("DBMM_IGEMM_X2_BK"); return e ? atoi(e) : 32; }();
-        if (x2_allow && p.wh && p.a_absmax && nbatch == 1 && fast_ok<AMODE, WMODE, BK>(p)) {
-            constexpr int MB = X2_MINB(BN);
-            // 32-deep K chunks (half the barriers) when a chunk never straddles a filter tap
-            const bool bk32 = x2_bk == 32 && (p.K % 32) == 0 &&
-                              (AMODE == 0 || ((p.Cin % 32) == 0 && p.wl == DBMM_WL_TAP_MAJOR));
+        // 32-deep K chunks (half the barriers) when a chunk never straddles a filter tap
+        const bool bk32 = x2_bk == 32 && (p.K % 32) == 0 &&
+                          (AMODE == 0 || ((p.Cin % 32) == 0 && p.wl == DBMM_WL_TAP_MAJOR));
+        if (x2_allow && p.wh && p.a_absmax && nbatch == 1 && fast_ok<AMODE, WMODE, BK>(p) && (p.nw == 2 || bk32)) {
+            constexpr int MB2 = X2_MINB(BN, 2), MB1 = X2_MINB(BN, 1);
+            const int MB = p.nw == 1 ? MB1 : MB2;
             const int nkx = p.K / (bk32 ? 32 : 16);
             if (p.sk_blocks) {
                 p.sk_blocks = NUM_CUS * MB;
                 if ((long long)p.n_tiles * nkx < 4LL * p.sk_blocks || nkx < 8) p.sk_blocks = 0;
             }
             const dim3 g3(p.sk_blocks ? p.sk_blocks : p.n_tiles, 1);
-            if (bk32) {
+            if (p.nw == 1) {          // W exact in one fp16 plane: two partial products (bk32 guaranteed above)
                 if (p.sk_blocks)
-                    hipLaunchKernelGGL((igemm_x3_kernel<BM, BN, WM, WN, AMODE, MB, 1, 2, 32>), g3, dim3(256), 0, s, p);
+                    hipLaunchKernelGGL((igemm_x3_kernel<BM, BN, WM, WN, AMODE, MB1, 1, 2, 1, 32>), g3, dim3(256), 0, s, p);
                 else
-                    hipLaunchKernelGGL((igemm_x3_kernel<BM, BN, WM, WN, AMODE, MB, 0, 2, 32>), g3, dim3(256), 0, s, p);
+                    hipLaunchKernelGGL((igemm_x3_kernel<BM, BN, WM, WN, AMODE, MB1, 0, 2, 1, 32>), g3, dim3(256), 0, s, p);
+            } else if (bk32) {
+                if (p.sk_blocks)
+                    hipLaunchKernelGGL((igemm_x3_kernel<BM, BN, WM, WN, AMODE, MB2, 1, 2, 2, 32>), g3, dim3(256), 0, s, p);
+                else
+                    hipLaunchKernelGGL((igemm_x3_kernel<BM, BN, WM, WN, AMODE, MB2, 0, 2, 2, 32>), g3, dim3(256), 0, s, p);
             } else {
                 if (p.sk_blocks)
-                    hipLaunchKernelGGL((igemm_x3_kernel<BM, BN, WM, WN, AMODE, MB, 1, 2, 16>), g3, dim3(256), 0, s, p);
+                    hipLaunchKernelGGL((igemm_x3_kernel<BM, BN, WM, WN, AMODE, MB2, 1, 2, 2, 16>), g3, dim3(256), 0, s, p);
                 else
-                    hipLaunchKernelGGL((igemm_x3_kernel<BM, BN, WM, WN, AMODE, MB, 0, 2, 16>), g3, dim3(256), 0, s, p);
+                    hipLaunchKernelGGL((igemm_x3_kernel<BM, BN, WM, WN, AMODE, MB2, 0, 2, 2, 16>), g3, dim3(256), 0, s, p);
             }
             g_last_cfg[6] = bk32 ? 32 : 16; g_last_cfg[7] = MB; g_last_cfg[8] = 2; g_last_cfg[9] = p.sk_blocks ? 1 : 0;
-            g_last_cfg[10] = 0;
+            g_last_cfg[10] = p.nw;
             DBMM_CHECK_LAUNCH();
             if (p.sk_blocks) {   // the fix-up needs a_absmax / w_exp too: its epilogue rescales the sums
                 if (bk32)
@@ -936,10 +951,10 @@ int launch_cfg(IgemmP& p, hipStream_t s, int nbatch, void* ws, size_t ws_bytes) 
             }
             const dim3 g3(p.sk_blocks ? p.sk_blocks : p.n_tiles, 1);
             if (p.sk_blocks)
-                hipLaunchKernelGGL((igemm_x3_kernel<BM, BN, WM, WN, AMODE, MB, 1, 3, 16>), g3, dim3(256), 0, s, p);
+                hipLaunchKernelGGL((igemm_x3_kernel<BM, BN, WM, WN, AMODE, MB, 1, 3, 3, 16>), g3, dim3(256), 0, s, p);
             else
-                hipLaunchKernelGGL((igemm_x3_kernel<BM, BN, WM, WN, AMODE, MB, 0, 3, 16>), g3, dim3(256), 0, s, p);
-            g_last_cfg[7] = MB; g_last_cfg[8] = 3; g_last_cfg[9] = p.sk_blocks ? 1 : 0; g_last_cfg[10] = 0;
+                hipLaunchKernelGGL((igemm_x3_kernel<BM, BN, WM, WN, AMODE, MB, 0, 3, 3, 16>), g3, dim3(256), 0, s, p);
+            g_last_cfg[7] = MB; g_last_cfg[8] = 3; g_last_cfg[9] = p.sk_blocks ? 1 : 0; g_last_cfg[10] = 3;
             DBMM_CHECK_LAUNCH();
             if (p.sk_blocks) {
                 hipLaunchKernelGGL((igemm_fixup_kernel<BM, BN, WM, WN, BK>), dim3(p.sk_blocks - 1), dim3(256), 0, s, p);
@@ -1024,18 +1039,22 @@ struct SplitArgs {
     const void* w3 = nullptr;
     const void* wh = nullptr;
     int w_exp = 0;
+    int nw = 2;                        // planes in wh: 2 = hi + lo, 1 = the scaled weight is exact in fp16
     const float* a_absmax = nullptr;
     float* absmax_out = nullptr;
+    const float* oscale = nullptr;     // per-output-channel scale of the accumulator (BatchNorm kept out of the weights)
 };
 
 inline void set_planes(IgemmP& p, const SplitArgs& sx, long long N, long long ldw) {
-    const long long b3 = 3 * N * ldw * 2, b2 = 2 * N * ldw * 2;
+    const long long b3 = 3 * N * ldw * 2, b2 = (long long)sx.nw * N * ldw * 2;
     p.w3 = (sx.w3 && b3 < 0x7FFFFFF0LL && dbmm_aligned16(sx.w3)) ? (const unsigned short*)sx.w3 : nullptr;
     p.w3_bytes = p.w3 ? (unsigned)b3 : 0u;
-    const bool h_ok = sx.wh && sx.a_absmax && b2 < 0x7FFFFFF0LL && dbmm_aligned16(sx.wh) && sx.w_exp >= -40 && sx.w_exp <= 40;
+    const bool h_ok = sx.wh && sx.a_absmax && (sx.nw == 1 || sx.nw == 2) && b2 < 0x7FFFFFF0LL && dbmm_aligned16(sx.wh) &&
+                      sx.w_exp >= -40 && sx.w_exp <= 40;
     p.wh = h_ok ? (const unsigned short*)sx.wh : nullptr;
     p.wh_bytes = h_ok ? (unsigned)b2 : 0u;
     p.w_exp = h_ok ? sx.w_exp : 0;
+    p.nw = h_ok ? sx.nw : 2;
     p.a_absmax = h_ok ? sx.a_absmax : nullptr;   // launch_cfg clears it again when another kernel runs
 }
 
@@ -1057,7 +1076,7 @@ int gemm_impl(const float* a, int64_t lda, int trans_a, const float* w, int64_t 
     p.M = (int)M; p.N = (int)N; p.K = (int)K; p.act = act; p.alpha = alpha;
     set_extents(p, trans_a ? 0 : ((M - 1) * lda + K) * 4, trans_w ? 0 : ((N - 1) * ldw + K) * 4);
     if (!trans_a && !trans_w) set_planes(p, sx, N, ldw);
-    p.absmax_out = sx.absmax_out;
+    p.absmax_out = sx.absmax_out; p.oscale = sx.oscale;
     hipStream_t s = (hipStream_t)stream;
     if (!trans_a && !trans_w) return launch_modes<0, 0>(p, s, 1, ws, wsb);
     if (!trans_a && trans_w) return launch_modes<0, 1>(p, s, 1, ws, wsb);
@@ -1088,7 +1107,7 @@ int conv_impl(const float* x, const float* w, const float* bias, const float* re
     p.KH = (int)KH; p.KW = (int)KW; p.stride = (int)stride; p.pad = (int)pad; p.wl = w_layout;
     set_extents(p, B * H * W * Cin * 4, Cout * K * 4);
     set_planes(p, sx, Cout, K);   // planes carry the same K order as `w`
-    p.absmax_out = sx.absmax_out;
+    p.absmax_out = sx.absmax_out; p.oscale = sx.oscale;
     hipStream_t s = (hipStream_t)stream;
     if (KH == 1 && KW == 1 && stride == 1 && pad == 0) return launch_modes<0, 0>(p, s, 1, ws, wsb);  // plain GEMM
     return launch_modes<1, 0>(p, s, 1, ws, wsb);
@@ -1198,11 +1217,14 @@ extern "C" int dbmm_split_weight_planes_f16(const float* w, void* planes, int64_
 }
 
 extern "C" int dbmm_conv_bn_act_x2(const float* x, const float* x_absmax, const float* w, const void* w_planes_f16,
-                                   int w_exp, const float* bias, const float* residual, float* y, float* y_absmax,
+                                   int w_planes, int w_exp, const float* out_scale, const float* bias,
+                                   const float* residual, float* y, float* y_absmax,
                                    int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int64_t KH, int64_t KW,
                                    int64_t stride, int64_t pad, int act, int w_layout, void* workspace,
                                    size_t workspace_bytes, void* stream) {
-    SplitArgs sx; sx.wh = w_planes_f16; sx.w_exp = w_exp; sx.a_absmax = x_absmax; sx.absmax_out = y_absmax;
+    if (w_planes_f16 && w_planes != 1 && w_planes != 2) return DBMM_E_ARG;
+    SplitArgs sx; sx.wh = w_planes_f16; sx.nw = w_planes_f16 ? w_planes : 2; sx.w_exp = w_exp; sx.a_absmax = x_absmax;
+    sx.absmax_out = y_absmax; sx.oscale = out_scale;
     return conv_impl(x, w, bias, residual, y, B, H, W, Cin, Cout, KH, KW, stride, pad, act, w_layout, workspace,
                      workspace_bytes, stream, sx);
 }

@@ -38,8 +38,9 @@ def _last_igemm_tag():
     """exact instantiation of the igemm launch just issued, spelled like rocprofv3's kernel name"""
     cfg = (ctypes.c_int * 11)()
     _lib.lib().dbmm_debug_last_igemm(cfg)
-    if cfg[8] in (2, 3):   # split-precision kernels: <BM, BN, WAVES_M, WAVES_N, AMODE, MINB, SK, NP, BK>
-        return f"igemm_x3_kernel<{cfg[0]}, {cfg[1]}, {cfg[2]}, {cfg[3]}, {cfg[4]}, {cfg[7]}, {cfg[9]}, {cfg[8]}, {cfg[6]}>"
+    if cfg[8] in (2, 3):   # split-precision kernels: <BM, BN, WAVES_M, WAVES_N, AMODE, MINB, SK, NP, NW, BK>
+        return (f"igemm_x3_kernel<{cfg[0]}, {cfg[1]}, {cfg[2]}, {cfg[3]}, {cfg[4]}, {cfg[7]}, {cfg[9]}, {cfg[8]}, "
+                f"{cfg[10]}, {cfg[6]}>")
     return "igemm_f32_kernel<" + ", ".join(str(v) for v in cfg) + ">"
 
 
@@ -90,17 +91,25 @@ def split_planes(w):
     return planes
 
 
-def split_planes_f16(w):
-    """fp32 [N][K] weight -> (two fp16 planes [2][N][K] of w * 2^w_exp, w_exp) for the fp16-pair
-    kernel; w_exp puts max|w| just below 2^14 (one host read of the maximum, at plan time)"""
+def split_planes_f16(w, allow_single=False):
+    """fp32 [N][K] weight -> (fp16 planes [n][N][K] of w * 2^w_exp, w_exp, n) for the fp16-pair
+    kernel; w_exp puts max|w| just below 2^14 (one host read of the maximum, at plan time).
+    n = 2 (hi, lo) in general.  With allow_single, n = 1 when the scaled weight is exactly
+    representable in fp16 -- the case for every conv / linear weight that went through the
+    reference's build_model, which stores them in fp16 -- and K is a multiple of 32."""
     require_cuda(w)
     _f32c(w)
     N, K = w.shape[0], w.numel() // w.shape[0]
     m = float(w.abs().max())
     w_exp = 0 if not (m > 0.0 and math.isfinite(m)) else max(-40, min(40, 13 - math.frexp(m)[1] + 1))
+    if allow_single and K % 32 == 0:
+        ws = w.reshape(N, K) * (2.0 ** w_exp)
+        h = ws.half()
+        if torch.equal(h.float(), ws):
+            return h.reshape(1, N, K).contiguous(), w_exp, 1
     planes = torch.empty((2, N, K), device=w.device, dtype=torch.float16)
     check(_lib.lib().dbmm_split_weight_planes_f16(ptr(w), ptr(planes), N, K, w_exp, stream()), "split_weight_planes_f16")
-    return planes, w_exp
+    return planes, w_exp, 2
 
 
 def gemm(a, w, bias=None, residual=None, act=ACT_NONE, alpha=1.0, trans_a=False, trans_w=False,
@@ -155,12 +164,13 @@ def pack_conv_weight(w_oihw, chunk_major=False):
 
 
 def conv_bn_act(x, w, bias, residual, kh, kw, stride, pad, act, w_layout=WL_TAP_MAJOR, w_planes=None,
-                w_planes_f16=None, w_exp=0, x_absmax=None, y_absmax=None):
+                w_planes_f16=None, w_exp=0, x_absmax=None, y_absmax=None, out_scale=None):
     """x NHWC [B,H,W,Cin]; w packed [Cout][K] (BN folded) in `w_layout` order (default
     [Cout][kh][kw][Cin]; see pack_conv_weight); returns NHWC.
     w_planes: bf16 triple (split_planes) -> split-precision kernel.
     w_planes_f16 / w_exp (split_planes_f16) + x_absmax (1-element device tensor >= max|x|) ->
-    fp16-pair kernel; y_absmax (1-element device tensor, zeroed by the caller) receives max|y|."""
+    fp16-pair kernel; y_absmax (1-element device tensor, zeroed by the caller) receives max|y|.
+    out_scale ([Cout], x2 entry only): per-channel scale of the accumulator before the bias."""
     require_cuda(x, w)
     _f32c(x); _f32c(w)
     B, H, W, Cin = x.shape
@@ -171,11 +181,12 @@ def conv_bn_act(x, w, bias, residual, kh, kw, stride, pad, act, w_layout=WL_TAP_
     plain = kh == 1 and kw == 1 and stride == 1 and pad == 0
     with _Timed(B * Ho * Wo, Cout, kh * kw * Cin, 0 if plain else 1, 0):
         ws = igemm_workspace(x.device)
-        if w_planes_f16 is not None or y_absmax is not None:
-            check(_lib.lib().dbmm_conv_bn_act_x2(ptr(x), ptr(x_absmax), ptr(w), ptr(w_planes_f16), int(w_exp), ptr(bias),
-                                                 ptr(residual), ptr(y), ptr(y_absmax), B, H, W, Cin, Cout, kh, kw, stride,
-                                                 pad, act, int(w_layout), ptr(ws), ws.numel() * 4, stream()),
-                  "conv_bn_act_x2")
+        if w_planes_f16 is not None or y_absmax is not None or out_scale is not None:
+            nw = 2 if w_planes_f16 is None else int(w_planes_f16.shape[0])
+            check(_lib.lib().dbmm_conv_bn_act_x2(ptr(x), ptr(x_absmax), ptr(w), ptr(w_planes_f16), nw, int(w_exp),
+                                                 ptr(out_scale), ptr(bias), ptr(residual), ptr(y), ptr(y_absmax), B, H, W,
+                                                 Cin, Cout, kh, kw, stride, pad, act, int(w_layout), ptr(ws),
+                                                 ws.numel() * 4, stream()), "conv_bn_act_x2")
             return y
         if w_planes is not None:
             check(_lib.lib().dbmm_conv_bn_act_x3(ptr(x), ptr(w), ptr(w_planes), ptr(bias), ptr(residual), ptr(y), B, H, W,

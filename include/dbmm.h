@@ -117,11 +117,19 @@ int dbmm_gemm_bias_act_x3(const float* a, int64_t lda, const float* w, const voi
  * an average pool may reuse its input's scalar: any upper bound works, a bound 2^k too large
  * costs k bits of the 2^-39 absolute floor).  w_planes_f16 = w * 2^w_exp split by
  * dbmm_split_weight_planes_f16 ([2][N][K] fp16); choose w_exp so that max|w| * 2^w_exp < 2^15.
- * x_absmax or w_planes_f16 may be NULL (fp32-MFMA kernel, y_absmax still honoured). */
+ * x_absmax or w_planes_f16 may be NULL (fp32-MFMA kernel, y_absmax still honoured).
+ * w_planes = 2: hi and lo plane.  w_planes = 1: the scaled weight is EXACTLY representable in
+ * fp16 (true for every conv / linear weight the reference's build_model loads: it stores them
+ * in fp16, clip/model.py:375-396,433) and only that plane is given -> two partial products; the
+ * 32-deep K chunk is required (K % 32 == 0, and Cin % 32 == 0 for KxK convs), otherwise the
+ * fp32-MFMA kernel runs.  out_scale (optional, [Cout]) multiplies the accumulator per output
+ * channel before the bias: y = act((acc * out_scale + bias) + residual) -- it carries the
+ * BatchNorm scale so that the weights themselves can stay the stored fp16 values. */
 size_t dbmm_split_planes_f16_bytes(int64_t N, int64_t K);
 int dbmm_split_weight_planes_f16(const float* w, void* planes, int64_t N, int64_t K, int w_exp, void* stream);
 int dbmm_conv_bn_act_x2(const float* x, const float* x_absmax, const float* w, const void* w_planes_f16,
-                        int w_exp, const float* bias, const float* residual, float* y, float* y_absmax,
+                        int w_planes, int w_exp, const float* out_scale, const float* bias,
+                        const float* residual, float* y, float* y_absmax,
                         int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int64_t KH, int64_t KW,
                         int64_t stride, int64_t pad, int act, int w_layout, void* workspace,
                         size_t workspace_bytes, void* stream);

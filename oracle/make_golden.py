@@ -317,9 +317,38 @@ def gen_checkpoint_contract():
     print(f"[ckpt] {len(sd)} tensors")
 
 
+def gen_fp16_keys(M):
+    """Which state-dict entries the reference's build_model rounds to fp16 on load
+    (convert_weights before load_state_dict, clip/model.py:375-396,433): feed it weights that are
+    NOT fp16-representable and record, per key, whether the loaded (then .float()-ed) parameter
+    equals the fp16-rounded or the original value."""
+    out = {}
+    for arch in ("tiny-RN", "tiny-ViT"):
+        sd = {k: (v * 1.0001 + 1e-5 if v.is_floating_point() else v) for k, v in synth.clip_state_dict(2, arch).items()}
+        model = M.build_model({k: v.clone() for k, v in sd.items()}).float()
+        got = model.state_dict()
+        cls = {}
+        for k, v in sd.items():
+            if not v.is_floating_point():
+                continue
+            if torch.equal(got[k], v.half().float()) and not torch.equal(v.half().float(), v):
+                cls[k] = "fp16"
+            elif torch.equal(got[k], v):
+                cls[k] = "fp32"
+            else:
+                raise SystemExit(f"{arch} {k}: neither fp16-rounded nor kept")
+        out[arch] = cls
+        print(f"[fp16 keys] {arch}: {sum(c == 'fp16' for c in cls.values())} rounded, "
+              f"{sum(c == 'fp32' for c in cls.values())} kept")
+    with open(os.path.join(GOLD, "build_model_fp16_keys.json"), "w") as f:
+        json.dump(out, f, indent=0, sort_keys=True)
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ["clip", "tokens", "adapter", "indices", "ckpt"]
+    which = sys.argv[1:] or ["clip", "tokens", "adapter", "indices", "ckpt", "fp16keys"]
+    if "fp16keys" in which:
+        gen_fp16_keys(ref_model_module())
     if "clip" in which:
         gen_clip(ref_model_module())
     if "tokens" in which:

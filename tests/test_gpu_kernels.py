@@ -363,7 +363,7 @@ def test_split_precision_falls_back_when_ineligible():
 
 
 def _x2_conv(xd, wp, wl, bd, rd, k, act, x_bound):
-    ph, we = ops.split_planes_f16(wp)
+    ph, we, _ = ops.split_planes_f16(wp)
     yam = torch.zeros(1, device=DEV)
     out = ops.conv_bn_act(xd, wp, bd, rd, k, k, 1, k // 2, act, wl, w_planes_f16=ph, w_exp=we,
                           x_absmax=x_bound, y_absmax=yam)
@@ -430,12 +430,12 @@ def test_conv_fp16_pair_stream_k():
         x = synth.normal(1, "x", (128, 256, 14, 14)); w = synth.normal(2, "w", (256, 256, 3, 3), 2304 ** -0.5)
         ref = torch.relu(F.conv2d(x.double(), w.double(), None, padding=1)).permute(0, 2, 3, 1)
         xd = x.permute(0, 2, 3, 1).contiguous().cuda(); wp, wl = ops.pack_conv_weight(w.cuda())
-        ph, we = ops.split_planes_f16(wp); yam = torch.zeros(1, device="cuda")
+        ph, we, _ = ops.split_planes_f16(wp); yam = torch.zeros(1, device="cuda")
         o = ops.conv_bn_act(xd, wp, None, None, 3, 3, 1, 1, ops.ACT_RELU, wl, w_planes_f16=ph, w_exp=we,
                             x_absmax=xd.abs().max().reshape(1), y_absmax=yam)
         tag = ops._last_igemm_tag()
         e = ((o.cpu().double() - ref).abs().max() / ref.abs().max()).item()
-        assert tag.startswith("igemm_x3_kernel<") and tag.endswith(", 1, 2, 32>"), tag   # SK = 1, NP = 2, BK = 32
+        assert tag.startswith("igemm_x3_kernel<") and tag.endswith(", 1, 2, 2, 32>"), tag   # SK = 1, NP = 2, NW = 2, BK = 32
         assert e < 5e-6, e
         assert yam.item() == o.abs().max().item()
         print("ok")
@@ -450,9 +450,52 @@ def test_conv_fp16_pair_without_bound_uses_fp32_kernel():
     B, H, Cin, Cout, k = 2, 10, 32, 64, 3
     x = rnd(1, "x", (B, Cin, H, H)); w = rnd(2, "w", (Cout, Cin, k, k), 0.05)
     xd = x.permute(0, 2, 3, 1).contiguous().to(DEV); wp, wl = ops.pack_conv_weight(w.to(DEV))
-    ph, we = ops.split_planes_f16(wp); yam = torch.zeros(1, device=DEV)
+    ph, we, _ = ops.split_planes_f16(wp); yam = torch.zeros(1, device=DEV)
     o = ops.conv_bn_act(xd, wp, None, None, k, k, 1, 1, ops.ACT_NONE, wl, w_planes_f16=ph, w_exp=we, y_absmax=yam)
     assert ops._last_igemm_tag().startswith("igemm_f32_kernel<")
     ref = F.conv2d(x, w, None, padding=1).permute(0, 2, 3, 1)
     assert relerr(o.cpu(), ref) < 2e-5
     assert yam.item() == o.abs().max().item()
+
+
+@pytest.mark.parametrize("B,H,Cin,Cout,k,res,x2", [(4, 14, 64, 128, 3, True, False), (128, 14, 256, 256, 3, False, True),
+                                                   (2, 12, 64, 256, 1, True, False), (8, 28, 128, 64, 3, False, True),
+                                                   (4, 20, 32, 32, 3, False, True), (64, 7, 512, 512, 3, False, False),
+                                                   (256, 14, 256, 256, 1, True, True), (256, 14, 128, 384, 3, True, True)])
+def test_conv_fp16_single_plane_with_out_scale(B, H, Cin, Cout, k, res, x2):
+    """weights that are exact in fp16 (what the reference's build_model holds): one weight plane,
+    two partial products, BatchNorm scale applied to the accumulator per output channel.
+    Reference: fp64 conv with the fp16 weights, times the scale, plus bias."""
+    x = rnd(1, "x", (B, Cin, H, H)); w = rnd(2, "w", (Cout, Cin, k, k), (Cin * k * k) ** -0.5).half().float()
+    b = rnd(3, "b", (Cout,), 0.1); sc = 0.5 + synth.uniform(4, "sc", (Cout,))
+    r = rnd(5, "r", (B, Cout, H, H)) if res else None
+    ref = F.conv2d(x.double(), w.double(), None, padding=k // 2) * sc.double().view(1, -1, 1, 1) + b.double().view(1, -1, 1, 1)
+    if res:
+        ref = ref + r.double()
+    ref = torch.relu(ref).permute(0, 2, 3, 1)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    rd = r.permute(0, 2, 3, 1).contiguous().to(DEV) if res else None
+    wp, wl = ops.pack_conv_weight(w.to(DEV))
+    ph, we, n = ops.split_planes_f16(wp, allow_single=True)
+    assert n == 1 and ph.shape == (1, Cout, Cin * k * k)
+    assert torch.equal(ph[0].float() * 2.0 ** -we, wp)                      # the plane IS the weight
+    yam = torch.zeros(1, device=DEV)
+    o = ops.conv_bn_act(xd, wp, b.to(DEV), rd, k, k, 1, k // 2, ops.ACT_RELU, wl, w_planes_f16=ph, w_exp=we,
+                        x_absmax=xd.abs().max().reshape(1), y_absmax=yam, out_scale=sc.to(DEV))
+    tag = ops._last_igemm_tag()
+    if x2:       # (small problems take the 64x64 fp32-MFMA tile, which also honours out_scale)
+        assert tag.startswith("igemm_x3_kernel<") and tag.endswith(", 2, 1, 32>"), tag   # NP = 2, NW = 1, BK = 32
+    # same op on the fp32-MFMA kernel (no planes): identical semantics of out_scale
+    o32 = ops.conv_bn_act(xd, wp, b.to(DEV), rd, k, k, 1, k // 2, ops.ACT_RELU, wl, out_scale=sc.to(DEV))
+    assert ops._last_igemm_tag().startswith("igemm_f32_kernel<")
+    e1, e32 = relerr(o.cpu().double(), ref), relerr(o32.cpu().double(), ref)
+    assert e1 < 5e-6 and e1 < 5 * e32 + 5e-7, (e1, e32)
+    assert yam.item() == o.abs().max().item()
+
+
+def test_split_planes_f16_single_only_when_exact():
+    w = rnd(1, "w", (64, 96)).to(DEV)                                       # not fp16-representable
+    assert ops.split_planes_f16(w, allow_single=True)[2] == 2
+    assert ops.split_planes_f16(w.half().float(), allow_single=True)[2] == 1
+    assert ops.split_planes_f16(w.half().float()[:, :80].contiguous(), allow_single=True)[2] == 2   # K % 32 != 0
+    assert ops.split_planes_f16(w.half().float())[2] == 2                   # not asked for

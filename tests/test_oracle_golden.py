@@ -132,3 +132,22 @@ def test_checkpoint_contract():
     keys = json.load(open(os.path.join(GOLDEN, "multiple_adapter_keys.json")))
     assert len(keys) == 18
     assert keys["new_adapter.layers.0.weight"][0] == [128, 1024]
+
+
+def test_build_model_rounds_the_same_keys_to_fp16_as_the_reference():
+    """fixture = which parameters the REFERENCE's build_model left fp16-rounded / untouched when
+    fed non-representable weights (oracle/make_golden.py fp16keys); our loader must classify
+    every key the same way (and then do the rounding: checked on the values)."""
+    import json, os
+    import torch
+    from conftest import ROOT
+    from dbmm_amd import synth
+    from dbmm_amd.clip.model import _as_loaded
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "build_model_fp16_keys.json")))
+    for arch, cls in gold.items():
+        sd = {k: (v * 1.0001 + 1e-5 if v.is_floating_point() else v) for k, v in synth.clip_state_dict(2, arch).items()}
+        assert set(cls) == {k for k, v in sd.items() if v.is_floating_point()}
+        for k, c in cls.items():
+            got = _as_loaded(k, sd[k])
+            want = sd[k].half().float() if c == "fp16" else sd[k].float()
+            assert torch.equal(got, want), (arch, k, c)

@@ -56,7 +56,7 @@ def main():
             if mode == "bf16":
                 kw = dict(w_planes=ops.split_planes(w))
             elif mode == "f16":
-                ph, we = ops.split_planes_f16(w)
+                ph, we, _ = ops.split_planes_f16(w)
                 kw = dict(w_planes_f16=ph, w_exp=we, x_absmax=x.abs().max().reshape(1),
                           y_absmax=torch.zeros(1, device=dev))
             b = torch.randn(Cout, device=dev)

@@ -33,7 +33,7 @@ for (B, H, Cin, Cout) in [(2, 16, 32, 128), (3, 14, 64, 128), (2, 9, 16, 64), (4
     xd = x.permute(0, 2, 3, 1).contiguous().cuda(); wp, wl = ops.pack_conv_weight(w.cuda()); pl = ops.split_planes(wp)
     o32 = ops.conv_bn_act(xd, wp, b.cuda(), None, 3, 3, 1, 1, ops.ACT_RELU, wl)
     o3 = ops.conv_bn_act(xd, wp, b.cuda(), None, 3, 3, 1, 1, ops.ACT_RELU, wl, w_planes=pl)
-    ph, we = ops.split_planes_f16(wp); xam = xd.abs().max().reshape(1); yam = torch.zeros(1, device="cuda")
+    ph, we, _ = ops.split_planes_f16(wp); xam = xd.abs().max().reshape(1); yam = torch.zeros(1, device="cuda")
     o2 = ops.conv_bn_act(xd, wp, b.cuda(), None, 3, 3, 1, 1, ops.ACT_RELU, wl, w_planes_f16=ph, w_exp=we, x_absmax=xam, y_absmax=yam)
     print(f"conv B{B} H{H} {Cin}->{Cout}: fp32-mfma err {rel(o32.cpu(), ref):.2e}  x3 err {rel(o3.cpu(), ref):.2e}  "
           f"x2 err {rel(o2.cpu(), ref):.2e} [{ops._last_igemm_tag()}] absmax {yam.item():.6f} vs {o2.abs().max().item():.6f}")
@@ -46,7 +46,7 @@ for name, H, Cin, Cout, k in [("l2.0.c2", 56, 128, 128, 3), ("l2.1.c2", 28, 128,
     bb = torch.randn(Cout, device="cuda"); pl = ops.split_planes(w); pad = 1 if k == 3 else 0
     t32 = t(lambda: ops.conv_bn_act(x, w, bb, None, k, k, 1, pad, ops.ACT_RELU, wl))
     t3 = t(lambda: ops.conv_bn_act(x, w, bb, None, k, k, 1, pad, ops.ACT_RELU, wl, w_planes=pl))
-    ph, we = ops.split_planes_f16(w); xam = x.abs().max().reshape(1); yam = torch.zeros(1, device="cuda")
+    ph, we, _ = ops.split_planes_f16(w); xam = x.abs().max().reshape(1); yam = torch.zeros(1, device="cuda")
     t2 = t(lambda: ops.conv_bn_act(x, w, bb, None, k, k, 1, pad, ops.ACT_RELU, wl, w_planes_f16=ph, w_exp=we, x_absmax=xam, y_absmax=yam))
     fl = 2.0 * B * H * H * Cout * Cin * k * k
     print(f"{name}: fp32-mfma {t32:.3f} ms ({fl / t32 / 1e9:.0f} TF)   x3 {t3:.3f} ms ({fl / t3 / 1e9:.0f} TF-eq)   "
