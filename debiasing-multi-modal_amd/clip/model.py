@@ -214,24 +214,27 @@ class ModifiedResNet(nn.Module):
         slot = [1]
         x = ops.conv_stem_s2(x, *P["stem1"], y_absmax=amax[0:1])            # -> NHWC from here on
 
-        def conv(t, t_am, c, res, k, pad, act):
+        def conv(t, t_am, c, res, k, pad, act, pool=1):
             y_am = amax[slot[0]:slot[0] + 1]; slot[0] += 1
             y = ops.conv_bn_act(t, c["w"], c["b"], res, k, k, 1, pad, act, c["wl"], w_planes=c["p3"],
-                                w_planes_f16=c["ph"], w_exp=c["we"], x_absmax=t_am, y_absmax=y_am, out_scale=c["sc"])
+                                w_planes_f16=c["ph"], w_exp=c["we"], x_absmax=t_am, y_absmax=y_am, out_scale=c["sc"],
+                                pool=pool)
             return y, y_am
 
         x, am = conv(x, amax[0:1], P["stem2"], None, 3, 1, ops.ACT_RELU)
-        x, am = conv(x, am, P["stem3"], None, 3, 1, ops.ACT_RELU)
-        x = ops.avgpool2d(x, 2)
+        x, am = conv(x, am, P["stem3"], None, 3, 1, ops.ACT_RELU, pool=2)      # + the stem's AvgPool2d(2)
         stages = {"stem": x}
         bi = 0
         for li in (1, 2, 3, 4):
             for _ in getattr(self, f"layer{li}"):
                 e = P["blocks"][bi]; bi += 1
                 out, oam = conv(x, am, e["c1"], None, 1, 0, ops.ACT_RELU)
-                out, oam = conv(out, oam, e["c2"], None, 3, 1, ops.ACT_RELU)
-                if e["stride"] > 1:
-                    out = ops.avgpool2d(out, e["stride"])
+                if e["stride"] == 2:      # conv2 + bn2 + ReLU + AvgPool2d(2) in one epilogue
+                    out, oam = conv(out, oam, e["c2"], None, 3, 1, ops.ACT_RELU, pool=2)
+                else:
+                    out, oam = conv(out, oam, e["c2"], None, 3, 1, ops.ACT_RELU)
+                    if e["stride"] > 1:
+                        out = ops.avgpool2d(out, e["stride"])
                 identity = x
                 if "ds" in e:
                     if e["stride"] > 1:

@@ -628,6 +628,7 @@ extern "C" const char* dbmm_error_string(int code) {
         case DBMM_E_ALIGN: return "pointer or leading dimension not 16-byte aligned";
         case DBMM_E_WORKSPACE: return "workspace too small";
         case DBMM_E_ARG: return "null pointer or bad enum";
+        case DBMM_E_UNSUPPORTED: return "no kernel for this (valid) request; use the unfused calls";
         default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown dbmm error";
     }
 }

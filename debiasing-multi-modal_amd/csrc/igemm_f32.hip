@@ -69,6 +69,7 @@ struct IgemmP {
     const unsigned short* wh;           // fp16-pair path: W * 2^w_exp as two fp16 planes [2][N][ldw]
     unsigned wh_bytes;
     int w_exp;
+    int pool2;                          // epilogue averages 2x2 output windows (rows walked window-major)
     int nw;                             // fp16-pair path: W planes present (2 = hi + lo, 1 = W exact in fp16)
     const float* oscale;                // optional per-output-channel scale applied to the accumulator (unfolded BN)
     const float* a_absmax;              // fp16-pair path: device scalar >= max|A| (null: path not in use)
@@ -579,9 +580,18 @@ __device__ __forceinline__ void igemm_tile_x3(const IgemmP& p, float* lds, int t
             fa_off[i] = rv ? (unsigned)m * (unsigned)p.lda * 4u + lc * 16u : OOR;
             fa_mask[i] = 0;
         } else {
-            const int hw = p.Ho * p.Wo;
-            const int n = m / hw, rem = m - n * hw;
-            const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+            int n, ho, wo;
+            if (p.pool2) {       // rows in 2x2-window-major order: m = (pooled pixel) * 4 + (dy * 2 + dx)
+                const int q = m & 3, mp = m >> 2, wp2 = p.Wo >> 1, hwp = (p.Ho >> 1) * wp2;
+                n = mp / hwp;
+                const int rem = mp - n * hwp, hp = rem / wp2;
+                ho = 2 * hp + (q >> 1); wo = 2 * (rem - hp * wp2) + (q & 1);
+            } else {
+                const int hw = p.Ho * p.Wo;
+                n = m / hw;
+                const int rem = m - n * hw;
+                ho = rem / p.Wo; wo = rem - ho * p.Wo;
+            }
             const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
             fa_off[i] = ((unsigned)(n * p.H + hi0) * (unsigned)p.W + (unsigned)wi0) * (unsigned)p.Cin * 4u + lc * 16u;
             unsigned msk = 0;
@@ -904,7 +914,8 @@ int launch_cfg(IgemmP& p, hipStream_t s, int nbatch, void* ws, size_t ws_bytes) 
         // 32-deep K chunks (half the barriers) when a chunk never straddles a filter tap
         const bool bk32 = x2_bk == 32 && (p.K % 32) == 0 &&
                           (AMODE == 0 || ((p.Cin % 32) == 0 && p.wl == DBMM_WL_TAP_MAJOR));
-        if (x2_allow && p.wh && p.a_absmax && nbatch == 1 && fast_ok<AMODE, WMODE, BK>(p) && (p.nw == 2 || bk32)) {
+        const bool pool_ok = !p.pool2 || (AMODE == 1 && !p.res && (p.N & 3) == 0 && (p.ldc & 3) == 0);
+        if (x2_allow && p.wh && p.a_absmax && nbatch == 1 && fast_ok<AMODE, WMODE, BK>(p) && (p.nw == 2 || bk32) && pool_ok) {
             constexpr int MB2 = X2_MINB(BN, 2), MB1 = X2_MINB(BN, 1);
             const int MB = p.nw == 1 ? MB1 : MB2;
             const int nkx = p.K / (bk32 ? 32 : 16);
@@ -941,6 +952,7 @@ int launch_cfg(IgemmP& p, hipStream_t s, int nbatch, void* ws, size_t ws_bytes) 
             }
             return DBMM_OK;
         }
+        if (p.pool2) return DBMM_E_UNSUPPORTED;   // only the fp16-pair kernels walk rows window-major
         p.a_absmax = nullptr;   // every other kernel takes A unscaled
         if constexpr (BN != 32)
         if (x3_allow && p.w3 && nbatch == 1 && fast_ok<AMODE, WMODE, BK>(p)) {
@@ -964,6 +976,7 @@ int launch_cfg(IgemmP& p, hipStream_t s, int nbatch, void* ws, size_t ws_bytes) 
         }
     }
 
+    if (p.pool2) return DBMM_E_UNSUPPORTED;
     p.a_absmax = nullptr;
     if constexpr (AMODE != 2 && WMODE == 0) {
         if (fast_ok<AMODE, WMODE, BK>(p)) {
@@ -1043,6 +1056,7 @@ struct SplitArgs {
     const float* a_absmax = nullptr;
     float* absmax_out = nullptr;
     const float* oscale = nullptr;     // per-output-channel scale of the accumulator (BatchNorm kept out of the weights)
+    int pool = 0;                      // 2: average 2x2 output windows in the epilogue
 };
 
 inline void set_planes(IgemmP& p, const SplitArgs& sx, long long N, long long ldw) {
@@ -1108,6 +1122,11 @@ int conv_impl(const float* x, const float* w, const float* bias, const float* re
     set_extents(p, B * H * W * Cin * 4, Cout * K * 4);
     set_planes(p, sx, Cout, K);   // planes carry the same K order as `w`
     p.absmax_out = sx.absmax_out; p.oscale = sx.oscale;
+    if (sx.pool != 0 && sx.pool != 2) return DBMM_E_ARG;
+    if (sx.pool == 2) {
+        if ((Ho & 1) || (Wo & 1) || residual || (KH == 1 && KW == 1 && stride == 1 && pad == 0)) return DBMM_E_UNSUPPORTED;
+        p.pool2 = 1;
+    }
     hipStream_t s = (hipStream_t)stream;
     if (KH == 1 && KW == 1 && stride == 1 && pad == 0) return launch_modes<0, 0>(p, s, 1, ws, wsb);  // plain GEMM
     return launch_modes<1, 0>(p, s, 1, ws, wsb);
@@ -1220,11 +1239,11 @@ extern "C" int dbmm_conv_bn_act_x2(const float* x, const float* x_absmax, const 
                                    int w_planes, int w_exp, const float* out_scale, const float* bias,
                                    const float* residual, float* y, float* y_absmax,
                                    int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int64_t KH, int64_t KW,
-                                   int64_t stride, int64_t pad, int act, int w_layout, void* workspace,
+                                   int64_t stride, int64_t pad, int act, int pool, int w_layout, void* workspace,
                                    size_t workspace_bytes, void* stream) {
     if (w_planes_f16 && w_planes != 1 && w_planes != 2) return DBMM_E_ARG;
     SplitArgs sx; sx.wh = w_planes_f16; sx.nw = w_planes_f16 ? w_planes : 2; sx.w_exp = w_exp; sx.a_absmax = x_absmax;
-    sx.absmax_out = y_absmax; sx.oscale = out_scale;
+    sx.absmax_out = y_absmax; sx.oscale = out_scale; sx.pool = pool;
     return conv_impl(x, w, bias, residual, y, B, H, W, Cin, Cout, KH, KW, stride, pad, act, w_layout, workspace,
                      workspace_bytes, stream, sx);
 }

@@ -34,6 +34,7 @@ extern "C" {
 #define DBMM_E_ALIGN (-2)     /* pointer or leading dimension not 16-byte aligned */
 #define DBMM_E_WORKSPACE (-3) /* workspace too small                              */
 #define DBMM_E_ARG (-4)       /* null pointer / bad enum                          */
+#define DBMM_E_UNSUPPORTED (-5) /* valid request this build has no kernel for (caller falls back) */
 
 /* K order of a packed conv weight [Cout][K], K = KH*KW*Cin */
 #define DBMM_WL_TAP_MAJOR 0   /* (kh, kw, cin)                                              */
@@ -124,14 +125,20 @@ int dbmm_gemm_bias_act_x3(const float* a, int64_t lda, const float* w, const voi
  * 32-deep K chunk is required (K % 32 == 0, and Cin % 32 == 0 for KxK convs), otherwise the
  * fp32-MFMA kernel runs.  out_scale (optional, [Cout]) multiplies the accumulator per output
  * channel before the bias: y = act((acc * out_scale + bias) + residual) -- it carries the
- * BatchNorm scale so that the weights themselves can stay the stored fp16 values. */
+ * BatchNorm scale so that the weights themselves can stay the stored fp16 values.
+ * pool = 2 fuses the AvgPool2d(2) that follows the conv in the reference's stem and stride-2
+ * bottlenecks (clip/model.py:25,48,117,145) into the epilogue: the kernel walks the output
+ * pixels 2x2-window-major, averages each window after the activation and writes only the pooled
+ * tensor y[B][Ho/2][Wo/2][Cout] (same summation order as dbmm_avgpool2d: bit-identical result).
+ * Needs the fp16-pair kernel, a KxK conv, even Ho and Wo, no residual; otherwise
+ * DBMM_E_UNSUPPORTED is returned and nothing is launched (run the conv and the pool separately). */
 size_t dbmm_split_planes_f16_bytes(int64_t N, int64_t K);
 int dbmm_split_weight_planes_f16(const float* w, void* planes, int64_t N, int64_t K, int w_exp, void* stream);
 int dbmm_conv_bn_act_x2(const float* x, const float* x_absmax, const float* w, const void* w_planes_f16,
                         int w_planes, int w_exp, const float* out_scale, const float* bias,
                         const float* residual, float* y, float* y_absmax,
                         int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int64_t KH, int64_t KW,
-                        int64_t stride, int64_t pad, int act, int w_layout, void* workspace,
+                        int64_t stride, int64_t pad, int act, int pool, int w_layout, void* workspace,
                         size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------

@@ -499,3 +499,46 @@ def test_split_planes_f16_single_only_when_exact():
     assert ops.split_planes_f16(w.half().float(), allow_single=True)[2] == 1
     assert ops.split_planes_f16(w.half().float()[:, :80].contiguous(), allow_single=True)[2] == 2   # K % 32 != 0
     assert ops.split_planes_f16(w.half().float())[2] == 2                   # not asked for
+
+
+@pytest.mark.parametrize("B,H,Cin,Cout,single", [(8, 28, 128, 64, True), (4, 20, 32, 32, True), (64, 28, 128, 128, True),
+                                                 (64, 28, 128, 128, False), (256, 14, 64, 256, True), (3, 12, 48, 64, False)])
+def test_conv_pool2_fused_equals_conv_then_avgpool(B, H, Cin, Cout, single):
+    """conv + ReLU + AvgPool2d(2) in one epilogue (rows walked 2x2-window-major) is bit-identical
+    to the same conv followed by dbmm_avgpool2d, and agrees with an fp64 reference."""
+    x = rnd(1, "x", (B, Cin, H, H)); w = rnd(2, "w", (Cout, Cin, 3, 3), (Cin * 9) ** -0.5)
+    if single:
+        w = w.half().float()
+    b = rnd(3, "b", (Cout,), 0.1); sc = 0.5 + synth.uniform(4, "sc", (Cout,))
+    ref = F.conv2d(x.double(), w.double(), None, padding=1) * sc.double().view(1, -1, 1, 1) + b.double().view(1, -1, 1, 1)
+    ref = F.avg_pool2d(torch.relu(ref), 2).permute(0, 2, 3, 1)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    wp, wl = ops.pack_conv_weight(w.to(DEV))
+    ph, we, n = ops.split_planes_f16(wp, allow_single=single)
+    kw = dict(w_planes_f16=ph, w_exp=we, x_absmax=xd.abs().max().reshape(1), out_scale=sc.to(DEV))
+    am1, am2 = torch.zeros(1, device=DEV), torch.zeros(1, device=DEV)
+    fused = ops.conv_bn_act(xd, wp, b.to(DEV), None, 3, 3, 1, 1, ops.ACT_RELU, wl, y_absmax=am1, pool=2, **kw)
+    tag = ops._last_igemm_tag()
+    unf = ops.avgpool2d(ops.conv_bn_act(xd, wp, b.to(DEV), None, 3, 3, 1, 1, ops.ACT_RELU, wl, y_absmax=am2, **kw), 2)
+    assert fused.shape == (B, H // 2, H // 2, Cout)
+    stream_k = tag.startswith("igemm_x3_kernel<") and tag.split(", ")[6] == "1"
+    if stream_k:     # cut tiles differ between the two row orders: sums of K segments in another order
+        assert relerr(fused.cpu(), unf.cpu()) < 1e-6
+    else:
+        assert torch.equal(fused, unf)
+    assert relerr(fused.cpu().double(), ref) < 5e-6
+    if tag.startswith("igemm_x3_kernel<"):          # fused kernel ran: its scalar is the pooled maximum
+        assert am1.item() == fused.abs().max().item()
+    assert am1.item() <= am2.item()
+
+
+def test_conv_pool2_unsupported_shapes_compose():
+    """odd output size / no planes: the library reports DBMM_E_UNSUPPORTED and ops composes conv + pool"""
+    x = rnd(1, "x", (2, 32, 14, 14)); w = rnd(2, "w", (64, 32, 3, 3), 0.06)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(DEV); wp, wl = ops.pack_conv_weight(w.to(DEV))
+    ref = F.avg_pool2d(torch.relu(F.conv2d(x, w, None, padding=1)), 2).permute(0, 2, 3, 1)
+    am = torch.zeros(1, device=DEV)
+    out = ops.conv_bn_act(xd, wp, None, None, 3, 3, 1, 1, ops.ACT_RELU, wl, y_absmax=am, pool=2)   # no planes -> fp32 kernel
+    assert relerr(out.cpu(), ref) < 2e-5
+    out = ops.conv_bn_act(xd, wp, None, None, 3, 3, 1, 1, ops.ACT_RELU, wl, pool=2)                # plain entry point
+    assert relerr(out.cpu(), ref) < 2e-5

@@ -51,14 +51,18 @@ def main():
             x = torch.randn(a.batch, H, H, Cin, device=dev)
             w, wl = ops.pack_conv_weight(torch.randn(Cout, Cin, k, k, device=dev) * (Cin * k * k) ** -0.5,
                                          chunk_major=os.environ.get("BENCH_WL") == "1")
-            mode = os.environ.get("BENCH_SPLIT", "f16")          # f16 | bf16 | off
+            mode = os.environ.get("BENCH_SPLIT", "f16x1")        # f16x1 (exact fp16 weights, one plane) | f16 | bf16 | off
             kw = {}
             if mode == "bf16":
                 kw = dict(w_planes=ops.split_planes(w))
-            elif mode == "f16":
-                ph, we, _ = ops.split_planes_f16(w)
+            elif mode in ("f16", "f16x1"):
+                if mode == "f16x1":
+                    w = w.half().float()
+                ph, we, _ = ops.split_planes_f16(w, allow_single=mode == "f16x1")
                 kw = dict(w_planes_f16=ph, w_exp=we, x_absmax=x.abs().max().reshape(1),
                           y_absmax=torch.zeros(1, device=dev))
+                if mode == "f16x1":
+                    kw["out_scale"] = 0.5 + torch.rand(Cout, device=dev)
             b = torch.randn(Cout, device=dev)
             r = torch.randn(a.batch, H, H, Cout, device=dev) if res else None
             pad = 1 if k == 3 else 0
