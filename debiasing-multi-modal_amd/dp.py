@@ -52,9 +52,9 @@ class EmbedAdapterStep:
     optimizer:   dbmm_amd.optim.SGD over the classifier's trainable parameters
     """
 
-    def __init__(self, encode_fn, classifier, optimizer, n_groups=4, group=None):
+    def __init__(self, encode_fn, classifier, optimizer, n_groups=4, group=None, fused=True):
         self.encode_fn, self.classifier, self.optimizer = encode_fn, classifier, optimizer
-        self.n_groups, self.group = n_groups, group
+        self.n_groups, self.group, self.fused = n_groups, group, fused
         self.counts = None
 
     def gather(self, emb_local, y_local, g_local):
@@ -67,10 +67,15 @@ class EmbedAdapterStep:
         emb_local = self.encode_fn(images_local)
         emb, y, g = self.gather(emb_local, y_local, g_local)
         labels = g if use_group else y
-        loss, logits, loss_rows = self.classifier.loss(emb.detach(), labels, use_group)
-        self.optimizer.zero_grad()
-        loss.backward()
-        self.optimizer.step()
+        if self.fused and emb.is_cuda and hasattr(self.classifier, "train_step"):
+            # the whole step body as one C call (bit-identical to the autograd path below,
+            # tests/test_gpu_trainer.py); needs the optimiser to hold the adapter in one group
+            loss, logits, loss_rows = self.classifier.train_step(emb.detach(), labels, self.optimizer, use_group)
+        else:
+            loss, logits, loss_rows = self.classifier.loss(emb.detach(), labels, use_group)
+            self.optimizer.zero_grad()
+            loss.backward()
+            self.optimizer.step()
         # update_dict (final_main.py:473) without a host sync: counters stay on the device
         if not use_group:
             if self.counts is None:

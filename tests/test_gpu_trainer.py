@@ -105,3 +105,25 @@ def test_train_epoch_matches_oracle_loop(text_paths):
     assert vacc == ocnt[:, 1].sum() / ocnt[:, 0].sum()
     assert abs(vloss - torch.nn.functional.cross_entropy(oev, y).item()) < 2e-3 * max(1.0, vloss)
     assert set(vg) == set(trainer.NEW_ORDER_FOR_PRINT)
+
+
+def test_embed_adapter_step_fused_equals_autograd(text_paths):
+    """dp.EmbedAdapterStep: the one-call step body and the autograd path leave identical
+    parameters, BN statistics, momentum and group counters"""
+    from dbmm_amd import dp
+    B = 64
+    emb = synth.normal(7, "e", (B, D), 0.5).cuda()
+    y, c, g = (t.cuda() for t in synth.labels(8, B))
+
+    def run(fused):
+        ad = adapter.Adapter(D, H); ad.load_state_dict(synth.adapter_state_dict(3, D, H))
+        clf = adapter.CustomCLIP(ad, *text_paths).cuda().train()
+        opt = optim.set_optimizer(_ns(), clf)
+        st = dp.EmbedAdapterStep(lambda t: t, clf, opt, fused=fused)
+        for _ in range(3):
+            loss, logits, _ = st.step(emb, y, g)
+        return clf.state_dict(), loss, logits, st.counts
+    sa, la, ga, ca = run(True); sb, lb, gb, cb = run(False)
+    assert torch.equal(la.detach(), lb.detach()) and torch.equal(ga, gb) and torch.equal(ca, cb)
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), k
