@@ -69,13 +69,14 @@ _SIGS = {
     "dbmm_split_planes_f16_bytes": [_L, _L],
     "dbmm_split_weight_planes_f16": [_P, _P, _L, _L, _I, _P],
     "dbmm_conv_bn_act_x2": [_P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _L, _L, _L, _L, _L, _L, _L, _L, _L, _I, _I, _I, _P, _Z, _P],
+    "dbmm_gemm_bias_act_x2": [_P, _L, _P, _P, _P, _I, _I, _L, _P, _P, _P, _L, _P, _L, _P, _L, _L, _L, _F, _I, _P, _Z, _P],
     "dbmm_gemm_bias_act_x3": [_P, _L, _P, _P, _L, _P, _P, _L, _P, _L, _L, _L, _L, _F, _I, _P, _Z, _P],
     "dbmm_gemm_batched": [_P, _L, _L, _I, _P, _L, _L, _I, _P, _L, _P, _L, _L, _L, _L, _L, _L, _F, _I, _P],
     "dbmm_conv_stem_s2": [_P, _P, _P, _P, _P, _L, _L, _L, _L, _P],
     "dbmm_avgpool2d": [_P, _P, _L, _L, _L, _L, _L, _P],
     "dbmm_workspace_bytes_attnpool": [_L, _L, _L],
     "dbmm_attnpool": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _L, _L, _L, _L, _P, _Z, _P],
-    "dbmm_layernorm": [_P, _L, _P, _P, _P, _L, _L, _L, _F, _P],
+    "dbmm_layernorm": [_P, _L, _P, _P, _P, _L, _L, _L, _F, _P, _P],
     "dbmm_mha_core": [_P, _P, _L, _L, _L, _L, _I, _P],
     "dbmm_embed_gather": [_P, _P, _P, _P, _L, _L, _L, _L, _P],
     "dbmm_im2col_patch": [_P, _P, _L, _L, _L, _P],

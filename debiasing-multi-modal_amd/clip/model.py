@@ -282,26 +282,42 @@ class Transformer(nn.Module):
 
     @torch.no_grad()
     def _split_planes(self):
-        """bf16 planes of the four projection weights of every block (split-precision GEMMs)"""
-        self._planes = [tuple(ops.split_planes(w.detach().contiguous()) for w in
-                              (b.attn.in_proj_weight, b.attn.out_proj.weight, b.mlp.c_fc.weight, b.mlp.c_proj.weight))
-                        for b in self.resblocks]
+        """pre-split planes of the four projection weights of every block for the split-precision
+        GEMMs: fp16 (one plane when the weight is exact in fp16, as after build_model; else hi + lo)
+        or, with DBMM_CONV_SPLIT=bf16, the bf16 triple; "off" = fp32-input MFMA."""
+        def one(w):
+            w = w.detach().contiguous()
+            if CONV_SPLIT == "f16" and w.shape[1] % 16 == 0:
+                ph, we, _ = ops.split_planes_f16(w, allow_single=True)
+                return dict(w_planes_f16=ph, w_exp=we)
+            if CONV_SPLIT == "bf16":
+                return dict(w_planes=ops.split_planes(w))
+            return {}
+        self._planes = [tuple(one(w) for w in (b.attn.in_proj_weight, b.attn.out_proj.weight, b.mlp.c_fc.weight,
+                                                b.mlp.c_proj.weight)) for b in self.resblocks]
         return self._planes
 
     @torch.no_grad()
     def run(self, x, B, L):
         """x [B*L, E] batch-first rows.  Pre-LN blocks (clip/model.py:189-192): the residual
-        adds and QuickGELU are GEMM epilogues."""
+        adds and QuickGELU are GEMM epilogues.  Every GEMM input carries a device scalar with (a
+        bound of) its maximum for the fp16-pair kernel: written by the LayerNorm kernel and the
+        GEMM epilogues; the attention core's output is a convex combination of V rows, so the
+        qkv GEMM's scalar bounds it."""
         E = self.width
         planes = getattr(self, "_planes", None) or self._split_planes()
-        for blk, (p_in, p_out, p_fc, p_proj) in zip(self.resblocks, planes):
-            h = ops.layernorm(x, blk.ln_1.weight, blk.ln_1.bias)
-            qkv = ops.gemm(h, blk.attn.in_proj_weight, blk.attn.in_proj_bias, w_planes=p_in)
+        amax = torch.zeros(4 * len(self.resblocks), device=x.device, dtype=torch.float32)
+        f16 = CONV_SPLIT == "f16"
+        for i, (blk, (p_in, p_out, p_fc, p_proj)) in enumerate(zip(self.resblocks, planes)):
+            a = [amax[4 * i + j:4 * i + j + 1] if f16 else None for j in range(4)]
+            sc = (lambda am: dict(a_absmax=am)) if f16 else (lambda am: {})
+            h = ops.layernorm(x, blk.ln_1.weight, blk.ln_1.bias, y_absmax=a[0])
+            qkv = ops.gemm(h, blk.attn.in_proj_weight, blk.attn.in_proj_bias, c_absmax=a[1], **sc(a[0]), **p_in)
             o = ops.mha_core(qkv, B, L, E, self.heads, self.causal)
-            x = ops.gemm(o, blk.attn.out_proj.weight, blk.attn.out_proj.bias, residual=x, w_planes=p_out)
-            h = ops.layernorm(x, blk.ln_2.weight, blk.ln_2.bias)
-            h = ops.gemm(h, blk.mlp.c_fc.weight, blk.mlp.c_fc.bias, act=ops.ACT_QUICKGELU, w_planes=p_fc)
-            x = ops.gemm(h, blk.mlp.c_proj.weight, blk.mlp.c_proj.bias, residual=x, w_planes=p_proj)
+            x = ops.gemm(o, blk.attn.out_proj.weight, blk.attn.out_proj.bias, residual=x, **sc(a[1]), **p_out)
+            h = ops.layernorm(x, blk.ln_2.weight, blk.ln_2.bias, y_absmax=a[2])
+            h = ops.gemm(h, blk.mlp.c_fc.weight, blk.mlp.c_fc.bias, act=ops.ACT_QUICKGELU, c_absmax=a[3], **sc(a[2]), **p_fc)
+            x = ops.gemm(h, blk.mlp.c_proj.weight, blk.mlp.c_proj.bias, residual=x, **sc(a[3]), **p_proj)
         return x
 
 

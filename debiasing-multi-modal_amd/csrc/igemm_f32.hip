@@ -1257,6 +1257,18 @@ extern "C" int dbmm_gemm_bias_act_x3(const float* a, int64_t lda, const float* w
                      stream, sx);
 }
 
+extern "C" int dbmm_gemm_bias_act_x2(const float* a, int64_t lda, const float* a_absmax, const float* w,
+                                     const void* w_planes_f16, int w_planes, int w_exp, int64_t ldw,
+                                     const float* out_scale, const float* bias, const float* residual, int64_t ldr,
+                                     float* c, int64_t ldc, float* c_absmax, int64_t M, int64_t N, int64_t K,
+                                     float alpha, int act, void* workspace, size_t workspace_bytes, void* stream) {
+    if (w_planes_f16 && w_planes != 1 && w_planes != 2) return DBMM_E_ARG;
+    SplitArgs sx; sx.wh = w_planes_f16; sx.nw = w_planes_f16 ? w_planes : 2; sx.w_exp = w_exp; sx.a_absmax = a_absmax;
+    sx.absmax_out = c_absmax; sx.oscale = out_scale;
+    return gemm_impl(a, lda, 0, w, ldw, 0, bias, residual, ldr, c, ldc, M, N, K, alpha, act, workspace, workspace_bytes,
+                     stream, sx);
+}
+
 extern "C" int dbmm_conv1x1_bn_act(const float* x, const float* w, const float* bias, const float* residual,
                                    float* y, int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t Cout,
                                    int act, void* stream) {

@@ -14,7 +14,8 @@ namespace {
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, long long ldx,
                                                         const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float* __restrict__ y,
-                                                        long long ldy, int rows, int E4, float eps) {
+                                                        long long ldy, int rows, int E4, float eps,
+                                                        float* __restrict__ y_absmax) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= rows) return;
     const f32x4* xr = (const f32x4*)(x + (long long)row * ldx);
@@ -29,8 +30,16 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     }
     const float rstd = rsqrtf(wave_sum(q) * invE + eps);
     f32x4* yr = (f32x4*)(y + (long long)row * ldy);
-    for (int i = lane; i < E4; i += 64)
-        yr[i] = (xr[i] - mean) * rstd * ((const f32x4*)gamma)[i] + ((const f32x4*)beta)[i];
+    float amax = 0.f;
+    for (int i = lane; i < E4; i += 64) {
+        const f32x4 v = (xr[i] - mean) * rstd * ((const f32x4*)gamma)[i] + ((const f32x4*)beta)[i];
+        yr[i] = v;
+        amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    }
+    if (y_absmax) {          // scale source of the fp16-pair GEMM that consumes y
+        amax = wave_max(amax);
+        if (lane == 0 && amax > *(volatile const float*)y_absmax) atomicMax((unsigned*)y_absmax, __float_as_uint(amax));
+    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -202,14 +211,14 @@ inline unsigned grid_for(long long total) {
 }  // namespace
 
 extern "C" int dbmm_layernorm(const float* x, int64_t ldx, const float* gamma, const float* beta, float* y,
-                              int64_t ldy, int64_t rows, int64_t E, float eps, void* stream) {
+                              int64_t ldy, int64_t rows, int64_t E, float eps, float* y_absmax, void* stream) {
     if (!x || !gamma || !beta || !y) return DBMM_E_ARG;
     if (rows <= 0 || E <= 0 || (E & 3) || rows > INT32_MAX) return DBMM_E_SHAPE;
     if ((ldx & 3) || (ldy & 3) || !dbmm_aligned16(x) || !dbmm_aligned16(y) || !dbmm_aligned16(gamma) ||
         !dbmm_aligned16(beta))
         return DBMM_E_ALIGN;
     hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x,
-                       (long long)ldx, gamma, beta, y, (long long)ldy, (int)rows, (int)(E / 4), eps);
+                       (long long)ldx, gamma, beta, y, (long long)ldy, (int)rows, (int)(E / 4), eps, y_absmax);
     DBMM_CHECK_LAUNCH();
     return DBMM_OK;
 }

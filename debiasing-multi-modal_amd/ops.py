@@ -113,8 +113,11 @@ def split_planes_f16(w, allow_single=False):
 
 
 def gemm(a, w, bias=None, residual=None, act=ACT_NONE, alpha=1.0, trans_a=False, trans_w=False,
-         M=None, N=None, K=None, lda=None, out=None, w_planes=None):
-    """c = act(alpha * (op(a) @ op(w)^T + bias) + residual); see dbmm_gemm_bias_act."""
+         M=None, N=None, K=None, lda=None, out=None, w_planes=None, w_planes_f16=None, w_exp=0, a_absmax=None,
+         c_absmax=None):
+    """c = act(alpha * (op(a) @ op(w)^T + bias) + residual); see dbmm_gemm_bias_act.
+    w_planes: bf16 triple; w_planes_f16 / w_exp + a_absmax: fp16-pair kernel (split_planes_f16);
+    c_absmax (1-element device tensor, zeroed by the caller) receives max|c|."""
     require_cuda(a, w)
     _f32c(w)
     if a.dtype != torch.float32:
@@ -132,6 +135,14 @@ def gemm(a, w, bias=None, residual=None, act=ACT_NONE, alpha=1.0, trans_a=False,
         out = torch.empty((M, N), device=a.device, dtype=torch.float32)
     ldr = residual.shape[-1] if residual is not None else 0
     ws = igemm_workspace(a.device)
+    if (w_planes_f16 is not None or c_absmax is not None) and not trans_a and not trans_w:
+        nw = 2 if w_planes_f16 is None else int(w_planes_f16.shape[0])
+        with _Timed(M, N, K, 0, 0):
+            check(_lib.lib().dbmm_gemm_bias_act_x2(ptr(a), lda, ptr(a_absmax), ptr(w), ptr(w_planes_f16), nw, int(w_exp),
+                                                   w.shape[-1], None, ptr(bias), ptr(residual), ldr, ptr(out),
+                                                   out.shape[-1], ptr(c_absmax), M, N, K, float(alpha), act, ptr(ws),
+                                                   ws.numel() * 4, stream()), "gemm_bias_act_x2")
+        return out
     if w_planes is not None and not trans_a and not trans_w:
         with _Timed(M, N, K, 0, 0):
             check(_lib.lib().dbmm_gemm_bias_act_x3(ptr(a), lda, ptr(w), ptr(w_planes), w.shape[-1], ptr(bias),
@@ -258,7 +269,7 @@ def attnpool(x, pos, wq, bq, wkv, bkv, wc, bc, heads):
     return out
 
 
-def layernorm(x, gamma, beta, rows=None, ldx=None, eps=1e-5):
+def layernorm(x, gamma, beta, rows=None, ldx=None, eps=1e-5, y_absmax=None):
     require_cuda(x)
     E = gamma.numel()
     if rows is None:
@@ -266,7 +277,8 @@ def layernorm(x, gamma, beta, rows=None, ldx=None, eps=1e-5):
     if ldx is None:
         ldx = E
     y = torch.empty((rows, E), device=x.device, dtype=torch.float32)
-    check(_lib.lib().dbmm_layernorm(ptr(x), ldx, ptr(gamma), ptr(beta), ptr(y), E, rows, E, eps, stream()), "layernorm")
+    check(_lib.lib().dbmm_layernorm(ptr(x), ldx, ptr(gamma), ptr(beta), ptr(y), E, rows, E, eps, ptr(y_absmax), stream()),
+          "layernorm")
     return y
 
 

@@ -141,6 +141,18 @@ int dbmm_conv_bn_act_x2(const float* x, const float* x_absmax, const float* w, c
                         int64_t stride, int64_t pad, int act, int pool, int w_layout, void* workspace,
                         size_t workspace_bytes, void* stream);
 
+/* GEMM on the fp16-pair path (see dbmm_conv_bn_act_x2 for the operands): c = act(alpha *
+ * (a @ w^T * out_scale + bias) + residual), a row-major [M][K] with a device scalar a_absmax >=
+ * max|a|, w [N][K] plus its fp16 planes (w_planes = 1 when w * 2^w_exp is exact in fp16 -- every
+ * nn.Linear / attention projection weight of a model loaded like the reference does; needs
+ * K % 32 == 0), c_absmax (optional) receives max|c|.  The attention core's output is a convex
+ * combination of V rows, so the qkv GEMM's c_absmax also bounds it. */
+int dbmm_gemm_bias_act_x2(const float* a, int64_t lda, const float* a_absmax, const float* w,
+                          const void* w_planes_f16, int w_planes, int w_exp, int64_t ldw,
+                          const float* out_scale, const float* bias, const float* residual, int64_t ldr,
+                          float* c, int64_t ldc, float* c_absmax, int64_t M, int64_t N, int64_t K, float alpha,
+                          int act, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * Device-side preprocessing (clip/clip.py:79-86: Resize(BICUBIC) -> CenterCrop -> ToTensor ->
  * Normalize) of one decoded RGB uint8 image [H][W][3] resident on the device.  Integer
@@ -200,9 +212,10 @@ int dbmm_attnpool(const float* x, const float* pos, const float* wq, const float
  * ------------------------------------------------------------------------------------ */
 
 /* LayerNorm over the last dim, fp32 statistics (clip/model.py:157-163).
- * x rows start at x + r*ldx (lets ln_post read only token 0 of every image). */
+ * x rows start at x + r*ldx (lets ln_post read only token 0 of every image).  y_absmax
+ * (optional, zeroed by the caller) receives max|y| for a following dbmm_gemm_bias_act_x2. */
 int dbmm_layernorm(const float* x, int64_t ldx, const float* gamma, const float* beta, float* y,
-                   int64_t ldy, int64_t rows, int64_t E, float eps, void* stream);
+                   int64_t ldy, int64_t rows, int64_t E, float eps, float* y_absmax, void* stream);
 
 /* softmax(q k^T * hd^-0.5 [+ causal mask]) v for packed qkv[B*L][3E] (batch-first rows),
  * head h uses columns [h*64, h*64+64) of each third.  head_dim must be 64 (all CLIP models).

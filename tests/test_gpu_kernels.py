@@ -542,3 +542,36 @@ def test_conv_pool2_unsupported_shapes_compose():
     assert relerr(out.cpu(), ref) < 2e-5
     out = ops.conv_bn_act(xd, wp, None, None, 3, 3, 1, 1, ops.ACT_RELU, wl, pool=2)                # plain entry point
     assert relerr(out.cpu(), ref) < 2e-5
+
+
+@pytest.mark.parametrize("M,N,K,single,res,act", [(25600, 768, 768, True, True, 0), (25600, 2304, 768, True, False, 0),
+                                                  (25600, 3072, 768, True, False, 2), (1000, 256, 64, True, True, 0),
+                                                  (4096, 512, 2048, False, True, 0), (616, 192, 96, False, False, 2)])
+def test_gemm_fp16_pair(M, N, K, single, res, act):
+    """transformer GEMMs on the fp16-pair kernel (one exact weight plane or hi + lo), QuickGELU /
+    residual epilogues, output-maximum scalar, LayerNorm as the producer of the input scalar"""
+    xin = rnd(1, "x", (M, K), 2.0); g = 1.0 + rnd(2, "g", (K,), 0.1); be = rnd(3, "be", (K,), 0.1)
+    w = rnd(4, "w", (N, K), K ** -0.5); b = rnd(5, "b", (N,), 0.1)
+    if single:
+        w = w.half().float()
+    r = rnd(6, "r", (M, N)) if res else None
+    a_am = torch.zeros(1, device=DEV)
+    a = ops.layernorm(xin.to(DEV), g.to(DEV), be.to(DEV), y_absmax=a_am)
+    assert a_am.item() == a.abs().max().item()
+    ref = a.cpu().double() @ w.double().t() + b.double()
+    if act == 2:
+        ref = ref * torch.sigmoid(1.702 * ref)
+    if res:
+        ref = ref + r.double()
+    ph, we, n = ops.split_planes_f16(w.to(DEV), allow_single=True)
+    assert n == (1 if single and K % 32 == 0 else 2)
+    c_am = torch.zeros(1, device=DEV)
+    out = ops.gemm(a, w.to(DEV), b.to(DEV), residual=None if r is None else r.to(DEV), act=act, w_planes_f16=ph, w_exp=we,
+                   a_absmax=a_am, c_absmax=c_am)
+    tag = ops._last_igemm_tag()
+    o32 = ops.gemm(a, w.to(DEV), b.to(DEV), residual=None if r is None else r.to(DEV), act=act)
+    e2, e32 = relerr(out.cpu().double(), ref), relerr(o32.cpu().double(), ref)
+    assert e2 < 5e-6 and e2 < 5 * e32 + 5e-7, (e2, e32, tag)
+    assert c_am.item() == out.abs().max().item()
+    if (M // 128) * (N // 128) >= 192:     # enough 128x128 tiles for the big-tile kernels
+        assert tag.startswith("igemm_x3_kernel<"), tag
