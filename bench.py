@@ -45,7 +45,8 @@ FP32_MFMA_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md, chip table (v_mfma
 F16_MFMA_PEAK_TFLOPS = 2500.0          # dense fp16 MFMA, same table (same rate as bf16)
 # 16-bit partial products a split-precision kernel issues per fp32 product, by plane count
 SPLIT_PRODUCTS = {(2, 1): 2, (2, 2): 3, (3, 3): 6}
-RN50_GFLOP_PER_IMG = 11.59             # SURVEY.md section 8d (conv 5.367 + attn-pool 0.426 GMAC)
+# algorithmic GFLOP per image, SURVEY.md section 8d (RN50: conv 5.367 + attn-pool 0.426 GMAC)
+GFLOP_PER_IMG = {"RN50": 11.59, "ViT-B/32": 8.82, "ViT-L/14@336px": 381.9}
 # dominant kernel: 3x3 implicit-GEMM conv, 128x128 tile, one tile per workgroup
 # (template arguments <BM, BN, WAVES_M, WAVES_N, AMODE=1 (conv), MINB, SK=0, NP, NW, BK>; NP / NW = 16-bit planes
 #  of the activations / weights: 2, 1 = fp16 pair x exact fp16 weight; 2, 2 = fp16 pair x pair; 3, 3 = bf16 triple)
@@ -183,8 +184,10 @@ def main():
 
     if rank == 0:
         value = B * args.steps / dt
-        DOMINANT = next((k for k in DOMINANT_SPLIT if k in prof), DOMINANT_F32)
-        split = DOMINANT in DOMINANT_SPLIT
+        DOMINANT = next((k for k in DOMINANT_SPLIT + (DOMINANT_F32,) if k in prof), None)
+        if DOMINANT is None:     # other towers (ViT): the MFMA kernel instantiation with the most time
+            DOMINANT = max(prof, key=lambda k: prof[k][2]) if prof else DOMINANT_F32
+        split = DOMINANT.startswith("igemm_x3_kernel<")
         n_prod = SPLIT_PRODUCTS[tuple(int(v) for v in DOMINANT.rstrip(">").split(",")[-3:-1])] if split else 1
         peak = F16_MFMA_PEAK_TFLOPS / n_prod if split else FP32_MFMA_PEAK_TFLOPS
         n, fl, ms = prof.get(DOMINANT, (0, 0.0, 0.0))
@@ -198,7 +201,7 @@ def main():
             pass
         all_fl = sum(v[1] for v in prof.values()); all_ms = sum(v[2] for v in prof.values())
         line = {
-            "metric": "images/sec (embed+adapter step), CLIP-RN50 224px", "value": round(value, 2),
+            "metric": f"images/sec (embed+adapter step), CLIP-{args.arch} {R}px", "value": round(value, 2),
             "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -218,7 +221,7 @@ def main():
                          "all_mfma_kernels": {"achieved": round(all_fl / (all_ms * 1e-3) / 1e12, 2) if all_ms else 0.0,
                                               "ms_per_step": round(all_ms / args.steps, 3),
                                               "share_of_step": round(all_ms / (dt * 1e3), 4)},
-                         "end_to_end_over_fp32_mfma_peak": round(value / world * RN50_GFLOP_PER_IMG * 1e9 / (FP32_MFMA_PEAK_TFLOPS * 1e12), 4)},
+                         "end_to_end_over_fp32_mfma_peak": round(value / world * GFLOP_PER_IMG.get(args.arch, float("nan")) * 1e9 / (FP32_MFMA_PEAK_TFLOPS * 1e12), 4)},
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(sd, D, paths)
