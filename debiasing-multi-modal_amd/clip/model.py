@@ -214,20 +214,22 @@ class ModifiedResNet(nn.Module):
         slot = [1]
         x = ops.conv_stem_s2(x, *P["stem1"], y_absmax=amax[0:1])            # -> NHWC from here on
 
-        def conv(t, t_am, c, res, k, pad, act, pool=1):
+        def conv(t, t_am, c, res, k, pad, act, pool=1, keep_full=False):
             y_am = amax[slot[0]:slot[0] + 1]; slot[0] += 1
             y = ops.conv_bn_act(t, c["w"], c["b"], res, k, k, 1, pad, act, c["wl"], w_planes=c["p3"],
                                 w_planes_f16=c["ph"], w_exp=c["we"], x_absmax=t_am, y_absmax=y_am, out_scale=c["sc"],
-                                pool=pool)
+                                pool=pool, keep_full=keep_full)
             return y, y_am
 
         x, am = conv(x, amax[0:1], P["stem2"], None, 3, 1, ops.ACT_RELU)
         x, am = conv(x, am, P["stem3"], None, 3, 1, ops.ACT_RELU, pool=2)      # + the stem's AvgPool2d(2)
         stages = {"stem": x}
+        blocks = P["blocks"]
+        x_pooled = None          # AvgPool2d(2) of x when the previous conv3 already produced it
         bi = 0
         for li in (1, 2, 3, 4):
             for _ in getattr(self, f"layer{li}"):
-                e = P["blocks"][bi]; bi += 1
+                e = blocks[bi]; bi += 1
                 out, oam = conv(x, am, e["c1"], None, 1, 0, ops.ACT_RELU)
                 if e["stride"] == 2:      # conv2 + bn2 + ReLU + AvgPool2d(2) in one epilogue
                     out, oam = conv(out, oam, e["c2"], None, 3, 1, ops.ACT_RELU, pool=2)
@@ -238,10 +240,18 @@ class ModifiedResNet(nn.Module):
                 identity = x
                 if "ds" in e:
                     if e["stride"] > 1:
-                        identity = ops.avgpool2d(x, e["stride"])
+                        identity = x_pooled if (x_pooled is not None and e["stride"] == 2) else ops.avgpool2d(x, e["stride"])
                     identity, _ = conv(identity, am, e["ds"], None, 1, 0, ops.ACT_NONE)
-                # conv3 + bn3, residual add and the final ReLU fused into one epilogue
-                x, am = conv(out, oam, e["c3"], identity, 1, 0, ops.ACT_RELU)
+                # conv3 + bn3, residual add and the final ReLU fused into one epilogue; when the next
+                # block downsamples, the same launch also writes AvgPool2d(2) of its output for that
+                # block's downsample branch
+                nxt = blocks[bi] if bi < len(blocks) else None
+                if nxt is not None and nxt["stride"] == 2 and "ds" in nxt and x.shape[1] % 2 == 0 and x.shape[2] % 2 == 0 \
+                        and identity.shape[1] % 2 == 0 and identity.shape[2] % 2 == 0:
+                    (x_pooled, x), am = conv(out, oam, e["c3"], identity, 1, 0, ops.ACT_RELU, pool=2, keep_full=True)
+                else:
+                    x_pooled = None
+                    x, am = conv(out, oam, e["c3"], identity, 1, 0, ops.ACT_RELU)
             stages[f"layer{li}"] = x
         a = P["attn"]
         out = ops.attnpool(x, a["pos"], a["wq"], a["bq"], a["wkv"], a["bkv"], a["wc"], a["bc"], self.attnpool.num_heads)

@@ -70,6 +70,7 @@ struct IgemmP {
     unsigned wh_bytes;
     int w_exp;
     int pool2;                          // epilogue averages 2x2 output windows (rows walked window-major)
+    float* c_full;                      // pool2 only, optional: the un-pooled output [M][ldc], standard row order
     int nw;                             // fp16-pair path: W planes present (2 = hi + lo, 1 = W exact in fp16)
     const float* oscale;                // optional per-output-channel scale applied to the accumulator (unfolded BN)
     const float* a_absmax;              // fp16-pair path: device scalar >= max|A| (null: path not in use)
@@ -85,6 +86,14 @@ __device__ __forceinline__ int a_scale_exp(const float* a_absmax) {
     return s < -60 ? -60 : (s > 60 ? 60 : s);
 }
 __device__ __forceinline__ float pow2f(int e) { return __uint_as_float((unsigned)(e + 127) << 23); }
+// pool2 row order: row m = 4 * (pooled pixel, standard order) + (dy * 2 + dx).  Returns the
+// standard-order pixel index of the window's top-left corner (q = 0); q adds (q >> 1) * Wo + (q & 1).
+__device__ __forceinline__ int pool2_base_pixel(const IgemmP& p, int mp) {
+    const int wp2 = p.Wo >> 1, hwp = (p.Ho >> 1) * wp2;
+    const int n = mp / hwp, rem = mp - n * hwp, hp = rem / wp2;
+    return (n * p.Ho + 2 * hp) * p.Wo + 2 * (rem - hp * wp2);
+}
+
 __device__ __forceinline__ float igemm_acc_scale(const IgemmP& p) {
     return p.a_absmax ? pow2f(-a_scale_exp(p.a_absmax) - p.w_exp) : 1.f;
 }
@@ -577,7 +586,8 @@ __device__ __forceinline__ void igemm_tile_x3(const IgemmP& p, float* lds, int t
         const int m = m0 + lr + RPA * i;
         const bool rv = m < p.M;
         if constexpr (AMODE == 0) {
-            fa_off[i] = rv ? (unsigned)m * (unsigned)p.lda * 4u + lc * 16u : OOR;
+            const int row = p.pool2 ? pool2_base_pixel(p, m >> 2) + ((m & 3) >> 1) * p.Wo + (m & 1) : m;
+            fa_off[i] = rv ? (unsigned)row * (unsigned)p.lda * 4u + lc * 16u : OOR;
             fa_mask[i] = 0;
         } else {
             int n, ho, wo;
@@ -914,7 +924,7 @@ int launch_cfg(IgemmP& p, hipStream_t s, int nbatch, void* ws, size_t ws_bytes) 
         // 32-deep K chunks (half the barriers) when a chunk never straddles a filter tap
         const bool bk32 = x2_bk == 32 && (p.K % 32) == 0 &&
                           (AMODE == 0 || ((p.Cin % 32) == 0 && p.wl == DBMM_WL_TAP_MAJOR));
-        const bool pool_ok = !p.pool2 || (AMODE == 1 && !p.res && (p.N & 3) == 0 && (p.ldc & 3) == 0);
+        const bool pool_ok = !p.pool2 || ((p.N & 3) == 0 && (p.ldc & 3) == 0 && (!p.res || (p.ldr & 3) == 0));
         if (x2_allow && p.wh && p.a_absmax && nbatch == 1 && fast_ok<AMODE, WMODE, BK>(p) && (p.nw == 2 || bk32) && pool_ok) {
             constexpr int MB2 = X2_MINB(BN, 2), MB1 = X2_MINB(BN, 1);
             const int MB = p.nw == 1 ? MB1 : MB2;
@@ -1057,6 +1067,7 @@ struct SplitArgs {
     float* absmax_out = nullptr;
     const float* oscale = nullptr;     // per-output-channel scale of the accumulator (BatchNorm kept out of the weights)
     int pool = 0;                      // 2: average 2x2 output windows in the epilogue
+    float* c_full = nullptr;           // pool == 2: also store the un-pooled output here
 };
 
 inline void set_planes(IgemmP& p, const SplitArgs& sx, long long N, long long ldw) {
@@ -1124,8 +1135,11 @@ int conv_impl(const float* x, const float* w, const float* bias, const float* re
     p.absmax_out = sx.absmax_out; p.oscale = sx.oscale;
     if (sx.pool != 0 && sx.pool != 2) return DBMM_E_ARG;
     if (sx.pool == 2) {
-        if ((Ho & 1) || (Wo & 1) || residual || (KH == 1 && KW == 1 && stride == 1 && pad == 0)) return DBMM_E_UNSUPPORTED;
-        p.pool2 = 1;
+        if ((Ho & 1) || (Wo & 1) || M > (INT32_MAX >> 1)) return DBMM_E_UNSUPPORTED;
+        if (sx.c_full && !dbmm_aligned16(sx.c_full)) return DBMM_E_ALIGN;
+        p.pool2 = 1; p.c_full = sx.c_full;
+    } else if (sx.c_full) {
+        return DBMM_E_ARG;
     }
     hipStream_t s = (hipStream_t)stream;
     if (KH == 1 && KW == 1 && stride == 1 && pad == 0) return launch_modes<0, 0>(p, s, 1, ws, wsb);  // plain GEMM
@@ -1237,13 +1251,13 @@ extern "C" int dbmm_split_weight_planes_f16(const float* w, void* planes, int64_
 
 extern "C" int dbmm_conv_bn_act_x2(const float* x, const float* x_absmax, const float* w, const void* w_planes_f16,
                                    int w_planes, int w_exp, const float* out_scale, const float* bias,
-                                   const float* residual, float* y, float* y_absmax,
+                                   const float* residual, float* y, float* y_full, float* y_absmax,
                                    int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int64_t KH, int64_t KW,
                                    int64_t stride, int64_t pad, int act, int pool, int w_layout, void* workspace,
                                    size_t workspace_bytes, void* stream) {
     if (w_planes_f16 && w_planes != 1 && w_planes != 2) return DBMM_E_ARG;
     SplitArgs sx; sx.wh = w_planes_f16; sx.nw = w_planes_f16 ? w_planes : 2; sx.w_exp = w_exp; sx.a_absmax = x_absmax;
-    sx.absmax_out = y_absmax; sx.oscale = out_scale; sx.pool = pool;
+    sx.absmax_out = y_absmax; sx.oscale = out_scale; sx.pool = pool; sx.c_full = y_full;
     return conv_impl(x, w, bias, residual, y, B, H, W, Cin, Cout, KH, KW, stride, pad, act, w_layout, workspace,
                      workspace_bytes, stream, sx);
 }

@@ -175,7 +175,7 @@ def pack_conv_weight(w_oihw, chunk_major=False):
 
 
 def conv_bn_act(x, w, bias, residual, kh, kw, stride, pad, act, w_layout=WL_TAP_MAJOR, w_planes=None,
-                w_planes_f16=None, w_exp=0, x_absmax=None, y_absmax=None, out_scale=None, pool=1):
+                w_planes_f16=None, w_exp=0, x_absmax=None, y_absmax=None, out_scale=None, pool=1, keep_full=False):
     """x NHWC [B,H,W,Cin]; w packed [Cout][K] (BN folded) in `w_layout` order (default
     [Cout][kh][kw][Cin]; see pack_conv_weight); returns NHWC.
     w_planes: bf16 triple (split_planes) -> split-precision kernel.
@@ -183,7 +183,8 @@ def conv_bn_act(x, w, bias, residual, kh, kw, stride, pad, act, w_layout=WL_TAP_
     fp16-pair kernel; y_absmax (1-element device tensor, zeroed by the caller) receives max|y|.
     out_scale ([Cout], x2 entry only): per-channel scale of the accumulator before the bias.
     pool = 2: followed by AvgPool2d(2) (returns the pooled tensor); fused into the conv epilogue
-    when the library has a kernel for it, otherwise the two calls are composed here."""
+    when the library has a kernel for it, otherwise the two calls are composed here.
+    keep_full (with pool = 2): returns (pooled, un-pooled) -- both written by the one launch."""
     require_cuda(x, w)
     _f32c(x); _f32c(w)
     B, H, W, Cin = x.shape
@@ -194,15 +195,16 @@ def conv_bn_act(x, w, bias, residual, kh, kw, stride, pad, act, w_layout=WL_TAP_
         raise _lib.DbmmError("conv_bn_act: pool must be 1 or 2")
     plain = kh == 1 and kw == 1 and stride == 1 and pad == 0
     split = w_planes_f16 is not None or y_absmax is not None or out_scale is not None
-    if pool == 2 and split and Ho % 2 == 0 and Wo % 2 == 0 and residual is None and not plain:
+    if pool == 2 and split and Ho % 2 == 0 and Wo % 2 == 0:
         y = torch.empty((B, Ho // 2, Wo // 2, Cout), device=x.device, dtype=torch.float32)
-        t = _Timed(B * Ho * Wo, Cout, kh * kw * Cin, 1, 0)
+        yf = torch.empty((B, Ho, Wo, Cout), device=x.device, dtype=torch.float32) if keep_full else None
+        t = _Timed(B * Ho * Wo, Cout, kh * kw * Cin, 0 if plain else 1, 0)
         t.__enter__()
-        rc = _conv_x2(x, w, bias, None, y, kh, kw, stride, pad, act, w_layout, w_planes_f16, w_exp, x_absmax,
-                      y_absmax, out_scale, 2)
+        rc = _conv_x2(x, w, bias, residual, y, kh, kw, stride, pad, act, w_layout, w_planes_f16, w_exp, x_absmax,
+                      y_absmax, out_scale, 2, yf)
         if rc == 0:
             t.__exit__(None, None, None)
-            return y
+            return (y, yf) if keep_full else y
         if rc != _lib.E_UNSUPPORTED:
             check(rc, "conv_bn_act_x2(pool)")
     y = torch.empty((B, Ho, Wo, Cout), device=x.device, dtype=torch.float32)
@@ -210,7 +212,7 @@ def conv_bn_act(x, w, bias, residual, kh, kw, stride, pad, act, w_layout=WL_TAP_
         ws = igemm_workspace(x.device)
         if split:
             check(_conv_x2(x, w, bias, residual, y, kh, kw, stride, pad, act, w_layout, w_planes_f16, w_exp, x_absmax,
-                           y_absmax, out_scale, 0), "conv_bn_act_x2")
+                           y_absmax, out_scale, 0, None), "conv_bn_act_x2")
         elif w_planes is not None:
             check(_lib.lib().dbmm_conv_bn_act_x3(ptr(x), ptr(w), ptr(w_planes), ptr(bias), ptr(residual), ptr(y), B, H, W,
                                                  Cin, Cout, kh, kw, stride, pad, act, int(w_layout), ptr(ws),
@@ -219,16 +221,19 @@ def conv_bn_act(x, w, bias, residual, kh, kw, stride, pad, act, w_layout=WL_TAP_
             check(_lib.lib().dbmm_conv_bn_act_ws(ptr(x), ptr(w), ptr(bias), ptr(residual), ptr(y), B, H, W, Cin, Cout, kh,
                                                  kw, stride, pad, act, int(w_layout), ptr(ws), ws.numel() * 4, stream()),
                   "conv_bn_act")
-    return avgpool2d(y, 2) if pool == 2 else y     # (y_absmax of the unpooled map bounds the pooled one)
+    if pool == 2:      # (y_absmax of the unpooled map bounds the pooled one)
+        return (avgpool2d(y, 2), y) if keep_full else avgpool2d(y, 2)
+    return y
 
 
 def _conv_x2(x, w, bias, residual, y, kh, kw, stride, pad, act, w_layout, w_planes_f16, w_exp, x_absmax, y_absmax,
-             out_scale, pool):
+             out_scale, pool, y_full):
     B, H, W, Cin = x.shape
     ws = igemm_workspace(x.device)
     nw = 2 if w_planes_f16 is None else int(w_planes_f16.shape[0])
     return _lib.lib().dbmm_conv_bn_act_x2(ptr(x), ptr(x_absmax), ptr(w), ptr(w_planes_f16), nw, int(w_exp), ptr(out_scale),
-                                          ptr(bias), ptr(residual), ptr(y), ptr(y_absmax), B, H, W, Cin, w.shape[0], kh,
+                                          ptr(bias), ptr(residual), ptr(y), ptr(y_full), ptr(y_absmax), B, H, W, Cin,
+                                          w.shape[0], kh,
                                           kw, stride, pad, act, pool, int(w_layout), ptr(ws), ws.numel() * 4, stream())
 
 

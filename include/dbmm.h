@@ -130,13 +130,16 @@ int dbmm_gemm_bias_act_x3(const float* a, int64_t lda, const float* w, const voi
  * bottlenecks (clip/model.py:25,48,117,145) into the epilogue: the kernel walks the output
  * pixels 2x2-window-major, averages each window after the activation and writes only the pooled
  * tensor y[B][Ho/2][Wo/2][Cout] (same summation order as dbmm_avgpool2d: bit-identical result).
- * Needs the fp16-pair kernel, a KxK conv, even Ho and Wo, no residual; otherwise
- * DBMM_E_UNSUPPORTED is returned and nothing is launched (run the conv and the pool separately). */
+ * With pool = 2, y_full (optional, [B][Ho][Wo][Cout]) additionally receives the un-pooled output:
+ * the last conv3 of a stage needs both -- the next block's conv1 reads the full map, its
+ * downsample branch the pooled one (clip/model.py:36-38).  The residual, if any, is un-pooled.
+ * Needs the fp16-pair kernel and even Ho and Wo; otherwise DBMM_E_UNSUPPORTED is returned and
+ * nothing is launched (run the conv and the pool separately).  y_full must be NULL when pool = 0. */
 size_t dbmm_split_planes_f16_bytes(int64_t N, int64_t K);
 int dbmm_split_weight_planes_f16(const float* w, void* planes, int64_t N, int64_t K, int w_exp, void* stream);
 int dbmm_conv_bn_act_x2(const float* x, const float* x_absmax, const float* w, const void* w_planes_f16,
                         int w_planes, int w_exp, const float* out_scale, const float* bias,
-                        const float* residual, float* y, float* y_absmax,
+                        const float* residual, float* y, float* y_full, float* y_absmax,
                         int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int64_t KH, int64_t KW,
                         int64_t stride, int64_t pad, int act, int pool, int w_layout, void* workspace,
                         size_t workspace_bytes, void* stream);

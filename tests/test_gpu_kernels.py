@@ -575,3 +575,35 @@ def test_gemm_fp16_pair(M, N, K, single, res, act):
     assert c_am.item() == out.abs().max().item()
     if (M // 128) * (N // 128) >= 192:     # enough 128x128 tiles for the big-tile kernels
         assert tag.startswith("igemm_x3_kernel<"), tag
+
+
+@pytest.mark.parametrize("B,H,Cin,Cout,k,single", [(64, 28, 128, 256, 1, True), (256, 14, 256, 512, 1, True),
+                                                   (16, 56, 64, 256, 1, True), (64, 28, 128, 128, 3, False),
+                                                   (6, 10, 32, 64, 1, True)])
+def test_conv_pool2_dual_output_with_residual(B, H, Cin, Cout, k, single):
+    """conv3-style launch (1x1 or 3x3) + residual + ReLU that writes BOTH the un-pooled map and its
+    AvgPool2d(2): equal to the plain launch followed by the pool kernel (bit for bit without
+    stream-K), and to an fp64 reference."""
+    x = rnd(1, "x", (B, Cin, H, H)); w = rnd(2, "w", (Cout, Cin, k, k), (Cin * k * k) ** -0.5)
+    if single:
+        w = w.half().float()
+    b = rnd(3, "b", (Cout,), 0.1); sc = 0.5 + synth.uniform(4, "sc", (Cout,)); r = rnd(5, "r", (B, Cout, H, H))
+    ref = torch.relu(F.conv2d(x.double(), w.double(), None, padding=k // 2) * sc.double().view(1, -1, 1, 1)
+                     + b.double().view(1, -1, 1, 1) + r.double())
+    ref_p = F.avg_pool2d(ref, 2).permute(0, 2, 3, 1); ref = ref.permute(0, 2, 3, 1)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(DEV); rd = r.permute(0, 2, 3, 1).contiguous().to(DEV)
+    wp, wl = ops.pack_conv_weight(w.to(DEV))
+    ph, we, n = ops.split_planes_f16(wp, allow_single=single)
+    kw = dict(w_planes_f16=ph, w_exp=we, x_absmax=xd.abs().max().reshape(1), out_scale=sc.to(DEV))
+    am1, am2 = torch.zeros(1, device=DEV), torch.zeros(1, device=DEV)
+    pooled, full = ops.conv_bn_act(xd, wp, b.to(DEV), rd, k, k, 1, k // 2, ops.ACT_RELU, wl, y_absmax=am1, pool=2,
+                                   keep_full=True, **kw)
+    tag = ops._last_igemm_tag()
+    plain = ops.conv_bn_act(xd, wp, b.to(DEV), rd, k, k, 1, k // 2, ops.ACT_RELU, wl, y_absmax=am2, **kw)
+    stream_k = tag.startswith("igemm_x3_kernel<") and tag.split(", ")[6] == "1"
+    if stream_k:
+        assert relerr(full.cpu(), plain.cpu()) < 1e-6 and relerr(pooled.cpu(), ops.avgpool2d(plain, 2).cpu()) < 1e-6
+    else:
+        assert torch.equal(full, plain) and torch.equal(pooled, ops.avgpool2d(plain, 2))
+    assert relerr(full.cpu().double(), ref) < 5e-6 and relerr(pooled.cpu().double(), ref_p) < 5e-6
+    assert am1.item() == full.abs().max().item()
