@@ -212,16 +212,17 @@ class ModifiedResNet(nn.Module):
         n_slots = 3 + 4 * len(P["blocks"])
         amax = torch.zeros(n_slots, device=x.device, dtype=torch.float32)
         slot = [1]
-        x = ops.conv_stem_s2(x, *P["stem1"], y_absmax=amax[0:1])            # -> NHWC from here on
+        track = CONV_SPLIT == "f16"          # the maxima are only needed by the fp16-pair kernels
+        x = ops.conv_stem_s2(x, *P["stem1"], y_absmax=amax[0:1] if track else None)   # -> NHWC from here on
 
         def conv(t, t_am, c, res, k, pad, act, pool=1, keep_full=False):
-            y_am = amax[slot[0]:slot[0] + 1]; slot[0] += 1
+            y_am = amax[slot[0]:slot[0] + 1] if track else None; slot[0] += 1
             y = ops.conv_bn_act(t, c["w"], c["b"], res, k, k, 1, pad, act, c["wl"], w_planes=c["p3"],
                                 w_planes_f16=c["ph"], w_exp=c["we"], x_absmax=t_am, y_absmax=y_am, out_scale=c["sc"],
                                 pool=pool, keep_full=keep_full)
             return y, y_am
 
-        x, am = conv(x, amax[0:1], P["stem2"], None, 3, 1, ops.ACT_RELU)
+        x, am = conv(x, amax[0:1] if track else None, P["stem2"], None, 3, 1, ops.ACT_RELU)
         x, am = conv(x, am, P["stem3"], None, 3, 1, ops.ACT_RELU, pool=2)      # + the stem's AvgPool2d(2)
         stages = {"stem": x}
         blocks = P["blocks"]
