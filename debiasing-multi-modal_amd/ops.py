@@ -14,12 +14,15 @@ ACT_NONE, ACT_RELU, ACT_QUICKGELU = 0, 1, 2
 
 # ---- optional per-launch timing of the MFMA kernel family (bench.py roofline leg) ----------
 _prof = None
+_prof_conv_only = False
 
 
-def profile_begin():
-    """start collecting (kernel tag, flops, start event, end event) for every igemm launch."""
-    global _prof
-    _prof = []
+def profile_begin(conv_only=False):
+    """start collecting (kernel tag, flops, start event, end event) for every igemm launch --
+    with conv_only, just the KxK convolutions (the event pairs are stream work themselves, ~4 us
+    per launch, so a bench that only needs the dominant kernel should not pay for all)."""
+    global _prof, _prof_conv_only
+    _prof, _prof_conv_only = [], bool(conv_only)
 
 
 def profile_end():
@@ -49,12 +52,13 @@ class _Timed:
         self.args = (M, N, K, amode, wmode)
 
     def __enter__(self):
-        if _prof is not None:
+        self.on = _prof is not None and (self.args[3] == 1 or not _prof_conv_only)
+        if self.on:
             self.e0 = torch.cuda.Event(enable_timing=True)
             self.e0.record()
 
     def __exit__(self, *exc):
-        if _prof is not None and exc[0] is None:
+        if self.on and _prof is not None and exc[0] is None:
             M, N, K, amode, wmode = self.args
             e1 = torch.cuda.Event(enable_timing=True)
             e1.record()
