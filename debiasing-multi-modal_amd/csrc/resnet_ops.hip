@@ -62,10 +62,15 @@ __global__ __launch_bounds__(256) void stem_s2_kernel(const float* __restrict__ 
         for (int j = 0; j < 4; ++j) omax = fmaxf(omax, fmaxf(o0[j], o1[j]));
     }
     }
-    if (y_absmax) {
+    if (y_absmax) {       // one (filtered) atomic per workgroup: every workgroup targets the same address
+        __shared__ float wmax[4];
         omax = wave_max(omax);
-        if ((threadIdx.x & 63) == 0 && omax > *(volatile const float*)y_absmax)
-            atomicMax((unsigned*)y_absmax, __float_as_uint(omax));
+        if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = omax;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            omax = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+            if (omax > *(volatile const float*)y_absmax) atomicMax((unsigned*)y_absmax, __float_as_uint(omax));
+        }
     }
 }
 

@@ -2,6 +2,8 @@
 // the attention core, token-embedding gather, patch im2col, class-token assembly and the
 // EOT-row gather.  All fp32; the projections (QKV / out / MLP) go through
 // dbmm_gemm_bias_act with bias / QuickGELU / residual epilogues.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -11,34 +13,77 @@ namespace {
 // exactly the reference's LayerNorm subclass (fp32 compute) -- HBM-bound: 1 read + 1 write
 // per element, re-reads hit L1/L2.
 // ---------------------------------------------------------------------------------------
+// NV = float4s per lane held in registers (E <= 256 * NV): the row is read from memory once.
+// NV = 0: generic fallback that re-reads the row (L1/L2 hits) for any E.
+template <int NV>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, long long ldx,
                                                         const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float* __restrict__ y,
                                                         long long ldy, int rows, int E4, float eps,
                                                         float* __restrict__ y_absmax) {
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (row >= rows) return;
-    const f32x4* xr = (const f32x4*)(x + (long long)row * ldx);
+    const int lane = threadIdx.x & 63;
     const float invE = 1.f / (float)(E4 * 4);
-    float s = 0.f;
-    for (int i = lane; i < E4; i += 64) { const f32x4 v = xr[i]; s += (v[0] + v[1]) + (v[2] + v[3]); }
-    const float mean = wave_sum(s) * invE;
-    float q = 0.f;
-    for (int i = lane; i < E4; i += 64) {
-        const f32x4 v = xr[i] - mean;
-        q += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
-    }
-    const float rstd = rsqrtf(wave_sum(q) * invE + eps);
-    f32x4* yr = (f32x4*)(y + (long long)row * ldy);
     float amax = 0.f;
-    for (int i = lane; i < E4; i += 64) {
-        const f32x4 v = (xr[i] - mean) * rstd * ((const f32x4*)gamma)[i] + ((const f32x4*)beta)[i];
-        yr[i] = v;
-        amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    // grid-stride over groups of 4 rows: the grid is capped so that the single-address atomic of
+    // the output maximum is issued once per workgroup and a few hundred times per launch (one
+    // per wave and row was 25,600 same-address atomics = 3x the kernel's own run time)
+    for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += gridDim.x * 4) {
+    const f32x4* xr = (const f32x4*)(x + (long long)row * ldx);
+    f32x4* yr = (f32x4*)(y + (long long)row * ldy);
+    if constexpr (NV > 0) {
+        f32x4 v[NV];
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int i = lane + 64 * j;
+            v[j] = i < E4 ? xr[i] : (f32x4){0.f, 0.f, 0.f, 0.f};
+            s += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
+        }
+        const float mean = wave_sum(s) * invE;
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            if (lane + 64 * j < E4) {
+                const f32x4 d = v[j] - mean;
+                q += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+            }
+        }
+        const float rstd = rsqrtf(wave_sum(q) * invE + eps);
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int i = lane + 64 * j;
+            if (i < E4) {
+                const f32x4 o = (v[j] - mean) * rstd * ((const f32x4*)gamma)[i] + ((const f32x4*)beta)[i];
+                yr[i] = o;
+                amax = fmaxf(fmaxf(amax, fmaxf(fabsf(o[0]), fabsf(o[1]))), fmaxf(fabsf(o[2]), fabsf(o[3])));
+            }
+        }
+    } else {
+        float s = 0.f;
+        for (int i = lane; i < E4; i += 64) { const f32x4 v = xr[i]; s += (v[0] + v[1]) + (v[2] + v[3]); }
+        const float mean = wave_sum(s) * invE;
+        float q = 0.f;
+        for (int i = lane; i < E4; i += 64) {
+            const f32x4 v = xr[i] - mean;
+            q += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+        }
+        const float rstd = rsqrtf(wave_sum(q) * invE + eps);
+        for (int i = lane; i < E4; i += 64) {
+            const f32x4 v = (xr[i] - mean) * rstd * ((const f32x4*)gamma)[i] + ((const f32x4*)beta)[i];
+            yr[i] = v;
+            amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+        }
+    }
     }
     if (y_absmax) {          // scale source of the fp16-pair GEMM that consumes y
+        __shared__ float wmax[4];
         amax = wave_max(amax);
-        if (lane == 0 && amax > *(volatile const float*)y_absmax) atomicMax((unsigned*)y_absmax, __float_as_uint(amax));
+        if (lane == 0) wmax[threadIdx.x >> 6] = amax;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            amax = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+            if (amax > *(volatile const float*)y_absmax) atomicMax((unsigned*)y_absmax, __float_as_uint(amax));
+        }
     }
 }
 
@@ -140,6 +185,166 @@ __global__ __launch_bounds__(64) void mha_core_kernel(const float* __restrict__ 
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// Attention core on the fp32-input matrix cores (v_mfma_f32_32x32x2_f32), head_dim 64.
+// One wave per (64-query tile, head, image), key blocks of 64, online softmax.
+// Both products are computed TRANSPOSED so that a query is an MFMA *column* = a lane:
+//   S^T[key][q] = sum_d K[key][d] Q[q][d]         A = K rows (LDS), B = Q (registers, loop-invariant)
+//   O^T[d][q]  += sum_key V[key][d] P^T[key][q]   A = V^T (LDS), B = P^T
+// In the 32x32 C layout lane l holds column l & 31 and rows (r & 3) + 8 (r >> 2) + 4 (l >> 5):
+// the softmax statistics of a query are a reduction over the lane's own registers plus one
+// exchange with lane l ^ 32, the rescale of O^T is lane-local, and P^T is already in the B-operand
+// layout of the second product (k index = l >> 5 selects which of the step's two keys this lane
+// half supplies; the K order of that product is simply chosen to match: step r uses keys
+// (r & 3) + 8 (r >> 2) and that + 4).  The d order of the first product is permuted the same way
+// for K and Q so that one 16-B LDS read feeds four MFMA k-steps (as in the igemm).
+// K rows are stored with the 16-B chunk index XOR (row & 15): the 16 lanes of a ds_read_b128
+// group read the same chunk of 16 different rows.
+// ---------------------------------------------------------------------------------------
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__global__ __launch_bounds__(64) void mha_mfma_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+                                                      int L, int E, int causal) {
+    __shared__ __attribute__((aligned(16))) float Ks[64 * 64];   // K block (first: the Q tile), swizzled chunks
+    __shared__ __attribute__((aligned(16))) float Vs[64 * 64];   // V block, plain row-major
+    const int lane = threadIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const int q0 = blockIdx.x * 64;
+    const int fr = lane & 31, fh = lane >> 5;
+    const long long ld = 3LL * E;
+    const float* base = qkv + (long long)b * L * ld + h * 64;
+
+    // Q tile -> LDS (swizzled) -> B-operand fragments in registers, pre-scaled by head_dim^-0.5
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int idx = i * 64 + lane, r = idx >> 4, c4 = idx & 15;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (q0 + r < L) v = *(const f32x4*)(base + (long long)(q0 + r) * ld + c4 * 4);
+        *(f32x4*)(Ks + r * 64 + ((c4 ^ (r & 15)) << 2)) = v * 0.125f;
+    }
+    __syncthreads();
+    f32x4 qf[2][8];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int r = 32 * t + fr;
+            qf[t][j] = *(const f32x4*)(Ks + r * 64 + (((2 * j + fh) ^ (r & 15)) << 2));
+        }
+
+    f32x16 o[2][2];                       // O^T tiles [d tile][query tile]
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[a][c][r] = 0.f;
+    float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};   // per query tile; l is this half's partial sum
+
+    const int kend = causal ? min(L, q0 + 64) : L;   // keys beyond the tile's last query are masked
+    for (int k0 = 0; k0 < kend; k0 += 64) {
+        __syncthreads();                  // previous block's (or the Q tile's) LDS reads are done
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int idx = i * 64 + lane, r = idx >> 4, c4 = idx & 15;
+            f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
+            if (k0 + r < L) {
+                kv = *(const f32x4*)(base + (long long)(k0 + r) * ld + E + c4 * 4);
+                vv = *(const f32x4*)(base + (long long)(k0 + r) * ld + 2 * E + c4 * 4);
+            }
+            *(f32x4*)(Ks + r * 64 + ((c4 ^ (r & 15)) << 2)) = kv;
+            *(f32x4*)(Vs + r * 64 + c4 * 4) = vv;
+        }
+        __syncthreads();
+
+        // S^T = K Q^T
+        f32x16 sT[2][2];                  // [key tile][query tile]
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sT[a][c][r] = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const int kr = 32 * mt + fr;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const f32x4 kf = *(const f32x4*)(Ks + kr * 64 + (((2 * j + fh) ^ (kr & 15)) << 2));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    sT[mt][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[e], qf[0][j][e], sT[mt][0], 0, 0, 0);
+                    sT[mt][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[e], qf[1][j][e], sT[mt][1], 0, 0, 0);
+                }
+            }
+        }
+
+        // masks + online softmax, one query per lane column
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int qg = q0 + 32 * nt + fr;
+            float bm = -INFINITY;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int kg = k0 + 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                    const bool ok = kg < L && (!causal || kg <= qg);
+                    sT[mt][nt][r] = ok ? sT[mt][nt][r] : -INFINITY;
+                    bm = fmaxf(bm, sT[mt][nt][r]);
+                }
+            bm = fmaxf(bm, __shfl_xor(bm, 32));
+            const float mn = fmaxf(m_run[nt], bm);
+            // (mn is finite: key 0 is valid for every query in the first block)
+            const float sc = expf(m_run[nt] - mn);
+            m_run[nt] = mn;
+            float ps = 0.f;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float pv = expf(sT[mt][nt][r] - mn);
+                    sT[mt][nt][r] = pv;
+                    ps += pv;
+                }
+            l_run[nt] = l_run[nt] * sc + ps;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[dt][nt][r] *= sc;
+        }
+
+        // O^T += V^T P^T : step r of key tile mt consumes keys 32 mt + (r & 3) + 8 (r >> 2) (+ 4 for the upper lane half)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                const float v0 = Vs[key * 64 + fr], v1 = Vs[key * 64 + 32 + fr];
+                o[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(v0, sT[mt][0][r], o[0][0], 0, 0, 0);
+                o[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(v0, sT[mt][1][r], o[0][1], 0, 0, 0);
+                o[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(v1, sT[mt][0][r], o[1][0], 0, 0, 0);
+                o[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(v1, sT[mt][1][r], o[1][1], 0, 0, 0);
+            }
+    }
+
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int qg = q0 + 32 * nt + fr;
+        const float inv = 1.f / (l_run[nt] + __shfl_xor(l_run[nt], 32));
+        if (qg < L) {
+            float* op = out + ((long long)b * L + qg) * E + h * 64;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 v = {o[dt][nt][4 * g] * inv, o[dt][nt][4 * g + 1] * inv, o[dt][nt][4 * g + 2] * inv,
+                                     o[dt][nt][4 * g + 3] * inv};
+                    *(f32x4*)(op + 32 * dt + 8 * g + 4 * fh) = v;
+                }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void embed_gather_kernel(const int32_t* __restrict__ tokens,
                                                            const float* __restrict__ table,
                                                            const float* __restrict__ pos, float* __restrict__ out,
@@ -217,8 +422,19 @@ extern "C" int dbmm_layernorm(const float* x, int64_t ldx, const float* gamma, c
     if ((ldx & 3) || (ldy & 3) || !dbmm_aligned16(x) || !dbmm_aligned16(y) || !dbmm_aligned16(gamma) ||
         !dbmm_aligned16(beta))
         return DBMM_E_ALIGN;
-    hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x,
-                       (long long)ldx, gamma, beta, y, (long long)ldy, (int)rows, (int)(E / 4), eps, y_absmax);
+    const long long groups = (rows + 3) / 4;
+    const dim3 grid((unsigned)(groups < 2048 ? groups : 2048));
+    const int E4 = (int)(E / 4);
+#define DBMM_LN(NV)                                                                                                  \
+    hipLaunchKernelGGL(layernorm_kernel<NV>, grid, dim3(256), 0, (hipStream_t)stream, x, (long long)ldx, gamma, beta, y, \
+                       (long long)ldy, (int)rows, E4, eps, y_absmax)
+    if (E4 <= 64) DBMM_LN(1);
+    else if (E4 <= 128) DBMM_LN(2);
+    else if (E4 <= 192) DBMM_LN(3);
+    else if (E4 <= 256) DBMM_LN(4);
+    else if (E4 <= 512) DBMM_LN(8);
+    else DBMM_LN(0);
+#undef DBMM_LN
     DBMM_CHECK_LAUNCH();
     return DBMM_OK;
 }
@@ -228,8 +444,13 @@ extern "C" int dbmm_mha_core(const float* qkv, float* out, int64_t B, int64_t L,
     if (!qkv || !out) return DBMM_E_ARG;
     if (B <= 0 || L <= 0 || heads <= 0 || E != heads * 64 || B > 65535 || heads > 65535) return DBMM_E_SHAPE;
     if (!dbmm_aligned16(qkv) || !dbmm_aligned16(out)) return DBMM_E_ALIGN;
-    hipLaunchKernelGGL(mha_core_kernel, dim3((unsigned)((L + 63) / 64), (unsigned)heads, (unsigned)B), dim3(64), 0,
-                       (hipStream_t)stream, qkv, out, (int)L, (int)E, causal);
+    // matrix-core kernel by default; DBMM_MHA_VALU=1 selects the lane-per-query VALU kernel (ablation)
+    static const int valu = [] { const char* e = getenv("DBMM_MHA_VALU"); return e ? atoi(e) : 0; }();
+    const dim3 grid((unsigned)((L + 63) / 64), (unsigned)heads, (unsigned)B);
+    if (valu)
+        hipLaunchKernelGGL(mha_core_kernel, grid, dim3(64), 0, (hipStream_t)stream, qkv, out, (int)L, (int)E, causal);
+    else
+        hipLaunchKernelGGL(mha_mfma_kernel, grid, dim3(64), 0, (hipStream_t)stream, qkv, out, (int)L, (int)E, causal);
     DBMM_CHECK_LAUNCH();
     return DBMM_OK;
 }

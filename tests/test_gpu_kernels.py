@@ -144,8 +144,19 @@ def test_layernorm(rows, E):
     x = rnd(1, "x", (rows, E), 2.0) + 0.5
     g = synth.uniform(2, "g", (E,), 0.5, 1.5); b = rnd(3, "b", (E,), 0.1)
     ref = F.layer_norm(x, (E,), g, b, 1e-5)
-    out = ops.layernorm(x.to(DEV), g.to(DEV), b.to(DEV))
+    am = torch.zeros(1, device=DEV)
+    out = ops.layernorm(x.to(DEV), g.to(DEV), b.to(DEV), y_absmax=am)
     assert relerr(out.cpu(), ref) < 1e-5
+    assert am.item() == out.abs().max().item()
+
+
+@pytest.mark.parametrize("E", [64, 320, 768, 1024, 1280, 2052, 4096])
+def test_layernorm_widths(E):
+    """register-resident variants (E <= 2048) and the generic fallback"""
+    x = rnd(1, "x", (37, E), 3.0) - 1.0
+    g = synth.uniform(2, "g", (E,), 0.5, 1.5); b = rnd(3, "b", (E,), 0.1)
+    out = ops.layernorm(x.to(DEV), g.to(DEV), b.to(DEV))
+    assert relerr(out.cpu(), F.layer_norm(x, (E,), g, b, 1e-5)) < 1e-5
 
 
 def test_layernorm_strided_rows():
@@ -159,6 +170,7 @@ def test_layernorm_strided_rows():
 @pytest.mark.parametrize("B,L,heads,causal", [(3, 50, 2, False), (2, 77, 8, True), (2, 130, 1, False),
                                               (1, 130, 2, True), (2, 5, 1, False), (1, 577, 1, False)])
 def test_mha_core(B, L, heads, causal):
+    """matrix-core attention kernel (default) against torch softmax attention"""
     E = heads * 64
     qkv = rnd(1, "qkv", (B, L, 3 * E))
     q, k, v = qkv.split(E, dim=-1)
@@ -181,6 +193,30 @@ def test_mha_core_spiked_scores():
     ref = torch.softmax((q * 0.125) @ k.transpose(-1, -2), -1) @ v
     out = ops.mha_core(qkv.to(DEV).view(L, 3 * E), B, L, E, 1, False)
     assert relerr(out.cpu(), ref.reshape(L, E)) < 1e-5
+
+
+def test_mha_core_valu_kernel_agrees():
+    """DBMM_MHA_VALU=1 (lane-per-query VALU kernel, kept for ablation) gives the same result"""
+    import os, subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import sys, torch
+        sys.path.insert(0, %r)
+        import dbmm_amd
+        from dbmm_amd import ops, synth
+        B, L, heads = 2, 77, 3
+        E = heads * 64
+        qkv = synth.normal(1, "qkv", (B, L, 3 * E))
+        q, k, v = qkv.split(E, dim=-1)
+        sh = lambda t: t.reshape(B, L, heads, 64).transpose(1, 2)
+        s = (sh(q) * 0.125) @ sh(k).transpose(-1, -2) + torch.full((L, L), float("-inf")).triu_(1)
+        ref = (torch.softmax(s, -1) @ sh(v)).transpose(1, 2).reshape(B * L, E)
+        out = ops.mha_core(qkv.cuda().view(B * L, 3 * E), B, L, E, heads, True).cpu()
+        assert ((out - ref).abs().max() / ref.abs().max()).item() < 1e-5
+        print("ok")
+    """ % ROOT)
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, DBMM_MHA_VALU="1"), capture_output=True,
+                         text=True, timeout=600)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
 
 
 def test_embed_gather_and_eot():
