@@ -533,6 +533,18 @@ __device__ __forceinline__ void split2h(float xs, u16& hi, u16& lo) {
     hi = __builtin_bit_cast(u16, h); lo = __builtin_bit_cast(u16, l);
 }
 
+// (hi, lo) fp16 pairs of x0 * sc and x1 * sc, packed {x0 | x1 << 16}, on v_fma_mix{lo,hi}_f16
+__device__ __forceinline__ void split2h_pair(float x0, float x1, float sc, unsigned& hi, unsigned& lo) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(hi) : "v"(x0), "v"(sc));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(hi) : "v"(x1), "v"(sc));
+    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(lo) : "v"(x0), "v"(sc), "v"(hi));
+    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(lo) : "v"(x1), "v"(sc), "v"(hi));
+#else
+    (void)x0; (void)x1; (void)sc; hi = lo = 0;
+#endif
+}
+
 template <int BM, int BN, int NP, int NW, int BK>
 struct GeoX3 {   // LDS floats for the split path (NP / NW 16-bit planes of A / W, two stages) vs the epilogue staging
     static constexpr int STAGE_U16 = (NP * BM + NW * BN) * BK;
@@ -663,17 +675,25 @@ __device__ __forceinline__ void igemm_tile_x3(const IgemmP& p, float* lds, int t
 #pragma unroll
         for (int i = 0; i < ALD; ++i) {
             const int row = lr + RPA * i;
-            u16 h[4], m[4], l[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if constexpr (NP == 3) split3(a_reg[i][j], h[j], m[j], l[j]);
-                else split2h(a_reg[i][j] * a_sc, h[j], m[j]);
-            }
             const int off = row * BK + ((((lc >> 1) ^ x3_swz<BK>(row))) << 3) + ((lc & 1) << 2);
-            *(u32x2*)(Ab + 0 * BM * BK + off) = (u32x2){(unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16)};
-            *(u32x2*)(Ab + 1 * BM * BK + off) = (u32x2){(unsigned)m[0] | ((unsigned)m[1] << 16), (unsigned)m[2] | ((unsigned)m[3] << 16)};
-            if constexpr (NP == 3)
+            if constexpr (NP == 3) {
+                u16 h[4], m[4], l[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) split3(a_reg[i][j], h[j], m[j], l[j]);
+                *(u32x2*)(Ab + 0 * BM * BK + off) = (u32x2){(unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16)};
+                *(u32x2*)(Ab + 1 * BM * BK + off) = (u32x2){(unsigned)m[0] | ((unsigned)m[1] << 16), (unsigned)m[2] | ((unsigned)m[3] << 16)};
                 *(u32x2*)(Ab + 2 * BM * BK + off) = (u32x2){(unsigned)l[0] | ((unsigned)l[1] << 16), (unsigned)l[2] | ((unsigned)l[3] << 16)};
+            } else {
+                // two packed fp16 results per pair of elements, one mixed-precision FMA each:
+                // hi = f16(x * sc), lo = f16(x * sc - hi) (the fp32 difference is exact), written
+                // straight into the low / high half of the packed register.  What the compiler made
+                // of the same arithmetic in C was 4.4 VALU per element; this is 2.
+                unsigned hp[2], lp[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) split2h_pair(a_reg[i][2 * j], a_reg[i][2 * j + 1], a_sc, hp[j], lp[j]);
+                *(u32x2*)(Ab + 0 * BM * BK + off) = (u32x2){hp[0], hp[1]};
+                *(u32x2*)(Ab + 1 * BM * BK + off) = (u32x2){lp[0], lp[1]};
+            }
         }
 #pragma unroll
         for (int j = 0; j < WLD; ++j) {
