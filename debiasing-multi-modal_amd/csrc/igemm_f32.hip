@@ -57,6 +57,7 @@ struct IgemmP {
     int M, N, K;
     int H, W, Cin, Ho, Wo, KH, KW, stride, pad;  // AMODE 1 only
     int wl;                             // AMODE 1: K order of the packed weights (DBMM_WL_*)
+    int slab;                           // AMODE 1: 0 = tap-major K, else channels per slab of a chunk-major K (16 / 32)
     int act;
     float alpha;
     int tiles_n, n_tiles;
@@ -238,10 +239,10 @@ __device__ __forceinline__ void igemm_tile(const IgemmP& p, float* lds, int tile
             }
         }
         if constexpr (AMODE == 1) {   // position of chunk kb along K
-            if (p.wl == DBMM_WL_CHUNK_MAJOR) {       // K = (cin/16, kh, kw, 16): taps cycle fastest
-                const int taps = p.KH * p.KW, cpc = 16 / BK > 0 ? 16 / BK : 1;   // chunks per (16-ch, tap) cell
+            if (p.slab) {                             // K = (cin/slab, kh, kw, slab): taps cycle fastest
+                const int taps = p.KH * p.KW, cpc = p.slab / BK > 0 ? p.slab / BK : 1;   // chunks per (slab, tap) cell
                 const int cell = kb / cpc;
-                f_tap = cell % taps; f_ci0 = (cell / taps) * 16 + (kb % cpc) * BK;
+                f_tap = cell % taps; f_ci0 = (cell / taps) * p.slab + (kb % cpc) * BK;
             } else {                                  // K = (kh, kw, cin)
                 const int k = kb * BK;
                 f_tap = k / p.Cin; f_ci0 = k - f_tap * p.Cin;
@@ -278,12 +279,12 @@ __device__ __forceinline__ void igemm_tile(const IgemmP& p, float* lds, int tile
                 if (wrow0 + RPP * i < BN)
                     buf_load16_lds(rsW, Wb + (wrow0 + RPP * i) * BK, fw_off[i], (unsigned)k0 * 4u);
             if constexpr (AMODE == 1) {
-                if (p.wl == DBMM_WL_CHUNK_MAJOR) {
+                if (p.slab) {
                     f_ci0 += BK;
-                    if ((f_ci0 & 15) == 0) {
-                        f_ci0 -= 16; ++f_tap;
+                    if ((f_ci0 & (p.slab - 1)) == 0) {
+                        f_ci0 -= p.slab; ++f_tap;
                         if (++f_kw == p.KW) { f_kw = 0; ++f_kh; }
-                        if (f_tap == p.KH * p.KW) { f_tap = 0; f_kh = 0; f_kw = 0; f_ci0 += 16; }
+                        if (f_tap == p.KH * p.KW) { f_tap = 0; f_kh = 0; f_kw = 0; f_ci0 += p.slab; }
                     }
                 } else {
                     f_ci0 += BK;
@@ -307,14 +308,14 @@ __device__ __forceinline__ void igemm_tile(const IgemmP& p, float* lds, int tile
 #pragma unroll
             for (int i = 0; i < ALD; ++i)
                 a_reg[i] = buf_load16(rsA, (fa_mask[i] & bit) ? fa_off[i] + delta : OOR, 0u);
-            if (p.wl == DBMM_WL_CHUNK_MAJOR) {
-                // the KH*KW taps of one 16-channel slab are consecutive K chunks: the 9 re-reads of
+            if (p.slab) {
+                // the KH*KW taps of one channel slab are consecutive K chunks: the 9 re-reads of
                 // an input pixel happen back to back and are served by L1/L2 instead of the fabric
                 f_ci0 += BK;
-                if ((f_ci0 & 15) == 0) {
-                    f_ci0 -= 16; ++f_tap;
+                if ((f_ci0 & (p.slab - 1)) == 0) {
+                    f_ci0 -= p.slab; ++f_tap;
                     if (++f_kw == p.KW) { f_kw = 0; ++f_kh; }
-                    if (f_tap == p.KH * p.KW) { f_tap = 0; f_kh = 0; f_kw = 0; f_ci0 += 16; }
+                    if (f_tap == p.KH * p.KW) { f_tap = 0; f_kh = 0; f_kw = 0; f_ci0 += p.slab; }
                 }
             } else {
                 f_ci0 += BK;
@@ -333,9 +334,9 @@ __device__ __forceinline__ void igemm_tile(const IgemmP& p, float* lds, int tile
         } else if constexpr (AMODE == 1) {
             const int k = k0 + lc * 4;
             int tap, ci;
-            if (p.wl == DBMM_WL_CHUNK_MAJOR) {
-                const int cell = k >> 4, taps = p.KH * p.KW;
-                tap = cell % taps; ci = (cell / taps) * 16 + (k & 15);
+            if (p.slab) {
+                const int cell = k / p.slab, taps = p.KH * p.KW;
+                tap = cell % taps; ci = (cell / taps) * p.slab + (k & (p.slab - 1));
             } else {
                 tap = k / p.Cin; ci = k - tap * p.Cin;
             }
@@ -625,9 +626,9 @@ __device__ __forceinline__ void igemm_tile_x3(const IgemmP& p, float* lds, int t
         }
     }
     if constexpr (AMODE == 1) {
-        if (BK == 16 && p.wl == DBMM_WL_CHUNK_MAJOR) {       // K = (cin/16, kh, kw, 16): taps cycle fastest
+        if (p.slab == BK) {                                   // K = (cin/BK, kh, kw, BK): taps cycle fastest
             const int taps = p.KH * p.KW;
-            f_tap = kb % taps; f_ci0 = (kb / taps) * 16;
+            f_tap = kb % taps; f_ci0 = (kb / taps) * BK;
         } else {
             const int k = kb * BK;
             f_tap = k / p.Cin; f_ci0 = k - f_tap * p.Cin;
@@ -651,10 +652,10 @@ __device__ __forceinline__ void igemm_tile_x3(const IgemmP& p, float* lds, int t
 #pragma unroll
             for (int i = 0; i < ALD; ++i)
                 a_reg[i] = buf_load16(ra, (fa_mask[i] & bit) ? fa_off[i] + delta : OOR, 0u);
-            if (BK == 16 && p.wl == DBMM_WL_CHUNK_MAJOR) {
+            if (p.slab == BK) {
                 ++f_tap;
                 if (++f_kw == p.KW) { f_kw = 0; ++f_kh; }
-                if (f_tap == p.KH * p.KW) { f_tap = 0; f_kh = 0; f_kw = 0; f_ci0 += 16; }
+                if (f_tap == p.KH * p.KW) { f_tap = 0; f_kh = 0; f_kw = 0; f_ci0 += BK; }
             } else {
                 f_ci0 += BK;
                 if (f_ci0 == p.Cin) {
@@ -897,7 +898,7 @@ bool fast_ok(const IgemmP& p) {
     static const int allow = [] { const char* e = getenv("DBMM_IGEMM_FAST"); return e ? atoi(e) : 1; }();
     if (!allow || AMODE == 2 || WMODE != 0 || (p.K % BK) != 0) return false;
     if (AMODE == 1 && ((p.Cin % BK) != 0 || p.KH * p.KW > 32)) return false;
-    if (AMODE == 1 && p.wl == DBMM_WL_CHUNK_MAJOR && BK > 16) return false;   // one tap per chunk needed
+    if (AMODE == 1 && p.slab && BK > p.slab) return false;   // a chunk must not straddle taps
     return p.a_bytes != 0 && p.w_bytes != 0;
 }
 
@@ -943,9 +944,10 @@ int launch_cfg(IgemmP& p, hipStream_t s, int nbatch, void* ws, size_t ws_bytes) 
         static const int x2_bk = [] { const char* e = getenv("DBMM_IGEMM_X2_BK"); return e ? atoi(e) : 32; }();
         // 32-deep K chunks (half the barriers) when a chunk never straddles a filter tap
         const bool bk32 = x2_bk == 32 && (p.K % 32) == 0 &&
-                          (AMODE == 0 || ((p.Cin % 32) == 0 && p.wl == DBMM_WL_TAP_MAJOR));
+                          (AMODE == 0 || ((p.Cin % 32) == 0 && (p.slab == 0 || p.slab == 32)));
+        const bool slab_ok16 = AMODE == 0 || p.slab == 0 || p.slab == 16;     // the 16-deep split kernels: one tap per chunk
         const bool pool_ok = !p.pool2 || ((p.N & 3) == 0 && (p.ldc & 3) == 0 && (!p.res || (p.ldr & 3) == 0));
-        if (x2_allow && p.wh && p.a_absmax && nbatch == 1 && fast_ok<AMODE, WMODE, BK>(p) && (p.nw == 2 || bk32) && pool_ok) {
+        if (x2_allow && p.wh && p.a_absmax && nbatch == 1 && fast_ok<AMODE, WMODE, BK>(p) && (p.nw == 2 || bk32) && (bk32 || slab_ok16) && pool_ok) {
             constexpr int MB2 = X2_MINB(BN, 2), MB1 = X2_MINB(BN, 1);
             const int MB = p.nw == 1 ? MB1 : MB2;
             const int nkx = p.K / (bk32 ? 32 : 16);
@@ -985,7 +987,7 @@ int launch_cfg(IgemmP& p, hipStream_t s, int nbatch, void* ws, size_t ws_bytes) 
         if (p.pool2) return DBMM_E_UNSUPPORTED;   // only the fp16-pair kernels walk rows window-major
         p.a_absmax = nullptr;   // every other kernel takes A unscaled
         if constexpr (BN != 32)
-        if (x3_allow && p.w3 && nbatch == 1 && fast_ok<AMODE, WMODE, BK>(p)) {
+        if (x3_allow && p.w3 && nbatch == 1 && fast_ok<AMODE, WMODE, BK>(p) && slab_ok16) {
             constexpr int MB = BN == 128 ? 2 : 3;   // register budget for the two prefetch sets (no spills)
             if (p.sk_blocks) {   // the resident grid is sized for this kernel's occupancy
                 p.sk_blocks = NUM_CUS * MB;
@@ -1132,8 +1134,10 @@ int gemm_impl(const float* a, int64_t lda, int trans_a, const float* w, int64_t 
 int conv_impl(const float* x, const float* w, const float* bias, const float* residual, float* y, int64_t B, int64_t H,
               int64_t W, int64_t Cin, int64_t Cout, int64_t KH, int64_t KW, int64_t stride, int64_t pad, int act,
               int w_layout, void* ws, size_t wsb, void* stream, const SplitArgs& sx = SplitArgs()) {
-    if (w_layout != DBMM_WL_TAP_MAJOR && w_layout != DBMM_WL_CHUNK_MAJOR) return DBMM_E_ARG;
+    if (w_layout != DBMM_WL_TAP_MAJOR && w_layout != DBMM_WL_CHUNK_MAJOR && w_layout != DBMM_WL_CHUNK32_MAJOR)
+        return DBMM_E_ARG;
     if (w_layout == DBMM_WL_CHUNK_MAJOR && (Cin & 15)) return DBMM_E_SHAPE;
+    if (w_layout == DBMM_WL_CHUNK32_MAJOR && (Cin & 31)) return DBMM_E_SHAPE;
     if (!x || !w || !y) return DBMM_E_ARG;
     if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || KH <= 0 || KW <= 0 || stride <= 0 || pad < 0)
         return DBMM_E_SHAPE;
@@ -1150,6 +1154,7 @@ int conv_impl(const float* x, const float* w, const float* bias, const float* re
     p.M = (int)M; p.N = (int)Cout; p.K = (int)K; p.act = act; p.alpha = 1.f;
     p.H = (int)H; p.W = (int)W; p.Cin = (int)Cin; p.Ho = (int)Ho; p.Wo = (int)Wo;
     p.KH = (int)KH; p.KW = (int)KW; p.stride = (int)stride; p.pad = (int)pad; p.wl = w_layout;
+    p.slab = w_layout == DBMM_WL_CHUNK_MAJOR ? 16 : (w_layout == DBMM_WL_CHUNK32_MAJOR ? 32 : 0);
     set_extents(p, B * H * W * Cin * 4, Cout * K * 4);
     set_planes(p, sx, Cout, K);   // planes carry the same K order as `w`
     p.absmax_out = sx.absmax_out; p.oscale = sx.oscale;

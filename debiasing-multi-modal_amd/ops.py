@@ -160,21 +160,23 @@ def gemm(a, w, bias=None, residual=None, act=ACT_NONE, alpha=1.0, trans_a=False,
     return out
 
 
-WL_TAP_MAJOR, WL_CHUNK_MAJOR = 0, 1
+WL_TAP_MAJOR, WL_CHUNK_MAJOR, WL_CHUNK32_MAJOR = 0, 1, 2
 
 
 def pack_conv_weight(w_oihw, chunk_major=False):
     """[Cout][Cin][kh][kw] -> (packed fp32 [Cout][K], layout id).
 
-    Default K order (kh, kw, cin).  chunk_major=True packs (cin/16, kh, kw, 16) -- the taps of a
-    16-channel slab adjacent along K -- which cuts the fabric re-reads of the 3x3 gather (each
+    Default K order (kh, kw, cin).  chunk_major=True packs (cin/16, kh, kw, 16), chunk_major=32
+    packs (cin/32, kh, kw, 32) -- the taps of a
+    channel slab adjacent along K -- which cuts the fabric re-reads of the 3x3 gather (each
     input pixel is read by 9 taps) but measured 1-5 % *slower* on MI355X at B = 512: the
     Infinity Cache already absorbs the re-reads and tap-major uses both halves of every 128-B
     line back to back.  Kept as an option (needs Cin % 16 == 0)."""
     Cout, Cin, kh, kw = w_oihw.shape
-    if chunk_major and kh * kw > 1 and Cin % 16 == 0:
-        w = w_oihw.reshape(Cout, Cin // 16, 16, kh, kw).permute(0, 1, 3, 4, 2)
-        return w.contiguous().float().reshape(Cout, kh * kw * Cin), WL_CHUNK_MAJOR
+    slab = 32 if chunk_major == 32 else 16
+    if chunk_major and kh * kw > 1 and Cin % slab == 0:
+        w = w_oihw.reshape(Cout, Cin // slab, slab, kh, kw).permute(0, 1, 3, 4, 2)
+        return w.contiguous().float().reshape(Cout, kh * kw * Cin), (WL_CHUNK32_MAJOR if slab == 32 else WL_CHUNK_MAJOR)
     return w_oihw.permute(0, 2, 3, 1).contiguous().float().reshape(Cout, kh * kw * Cin), WL_TAP_MAJOR
 
 

@@ -41,6 +41,8 @@ extern "C" {
 #define DBMM_WL_CHUNK_MAJOR 1 /* (cin/16, kh, kw, 16): needs Cin % 16 == 0; the taps of one
                                  16-channel slab are adjacent along K, so the KH*KW re-reads
                                  of an input pixel hit L1/L2 instead of HBM                  */
+#define DBMM_WL_CHUNK32_MAJOR 2 /* (cin/32, kh, kw, 32): the same with 32-channel slabs (Cin % 32
+                                 == 0) -- the order the 32-deep fp16-pair kernels can step     */
 
 #define DBMM_ACT_NONE 0
 #define DBMM_ACT_RELU 1

@@ -643,3 +643,30 @@ def test_conv_pool2_dual_output_with_residual(B, H, Cin, Cout, k, single):
         assert torch.equal(full, plain) and torch.equal(pooled, ops.avgpool2d(plain, 2))
     assert relerr(full.cpu().double(), ref) < 5e-6 and relerr(pooled.cpu().double(), ref_p) < 5e-6
     assert am1.item() == full.abs().max().item()
+
+
+@pytest.mark.parametrize("B,H,Cin,Cout,single,pool", [(64, 28, 128, 128, True, 1), (8, 28, 64, 64, True, 2),
+                                                      (128, 14, 256, 256, False, 1), (3, 10, 32, 48, True, 1)])
+def test_conv_chunk32_major_layout(B, H, Cin, Cout, single, pool):
+    """K packed (cin/32, kh, kw, 32) -- the nine taps of a 32-channel slab adjacent along K -- gives
+    the same convolution on every kernel family (fp16-pair 32-deep, fp32-MFMA fallback)."""
+    x = rnd(1, "x", (B, Cin, H, H)); w = rnd(2, "w", (Cout, Cin, 3, 3), (Cin * 9) ** -0.5)
+    if single:
+        w = w.half().float()
+    b = rnd(3, "b", (Cout,), 0.1)
+    ref = torch.relu(F.conv2d(x.double(), w.double(), b.double(), padding=1))
+    if pool == 2:
+        ref = F.avg_pool2d(ref, 2)
+    ref = ref.permute(0, 2, 3, 1)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    wp, wl = ops.pack_conv_weight(w.to(DEV), chunk_major=32)
+    assert wl == ops.WL_CHUNK32_MAJOR
+    wt, _ = ops.pack_conv_weight(w.to(DEV))
+    assert torch.equal(wp.reshape(Cout, Cin // 32, 9, 32).permute(0, 2, 1, 3).reshape(Cout, -1), wt)
+    ph, we, n = ops.split_planes_f16(wp, allow_single=single)
+    am = torch.zeros(1, device=DEV)
+    o2 = ops.conv_bn_act(xd, wp, b.to(DEV), None, 3, 3, 1, 1, ops.ACT_RELU, wl, w_planes_f16=ph, w_exp=we,
+                         x_absmax=xd.abs().max().reshape(1), y_absmax=am, pool=pool)
+    o32 = ops.conv_bn_act(xd, wp, b.to(DEV), None, 3, 3, 1, 1, ops.ACT_RELU, wl, pool=pool)     # fp32-MFMA kernel
+    e2, e32 = relerr(o2.cpu().double(), ref), relerr(o32.cpu().double(), ref)
+    assert e32 < 2e-5 and e2 < 5e-6 and e2 < 5 * e32 + 5e-7, (e2, e32)

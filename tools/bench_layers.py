@@ -50,7 +50,7 @@ def main():
         else:
             x = torch.randn(a.batch, H, H, Cin, device=dev)
             w, wl = ops.pack_conv_weight(torch.randn(Cout, Cin, k, k, device=dev) * (Cin * k * k) ** -0.5,
-                                         chunk_major=os.environ.get("BENCH_WL") == "1")
+                                         chunk_major={"1": True, "32": 32}.get(os.environ.get("BENCH_WL"), False))
             mode = os.environ.get("BENCH_SPLIT", "f16x1")        # f16x1 (exact fp16 weights, one plane) | f16 | bf16 | off
             kw = {}
             if mode == "bf16":
