@@ -65,6 +65,7 @@ struct IgemmP {
     unsigned a_bytes, w_bytes;          // FAST loader: buffer extents (< 2 GiB)
     int sk_blocks;                      // stream-K: resident grid size (0 = one tile per block)
     float* sk_ws;                       // stream-K: [sk_blocks][2][BM*BN] partial accumulators
+    int sk_nk;                          // stream-K: work units per tile when they are not K / BK chunks (0 = chunks)
     const unsigned short* w3;           // split path: W as three bf16 planes [3][N][ldw]
     unsigned w3_bytes;
     const unsigned short* wh;           // fp16-pair path: W * 2^w_exp as two fp16 planes [2][N][ldw]
@@ -427,7 +428,7 @@ __device__ __forceinline__ void igemm_tile(const IgemmP& p, float* lds, int tile
     const int fr = lane & 31, fh = lane >> 5, fsw = lds_swz<BK>(fr);
 
     if constexpr (FIXUP) {
-        const int nk = (p.K + BK - 1) / BK;
+        const int nk = p.sk_nk ? p.sk_nk : (p.K + BK - 1) / BK;
         const long long U = (long long)p.n_tiles * nk, t = tile;
         for (int c = fix_c0; c < p.sk_blocks; ++c) {
             const long long bc = U * c / p.sk_blocks;
@@ -818,6 +819,269 @@ __global__ __launch_bounds__(256, MINB) void igemm_x3_kernel(const IgemmP p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// 3x3 / stride 1 / pad 1 convolution with the activation tile REUSED across the three kw taps
+// ("halo" variant of the fp16-pair kernel with one exact weight plane; K order (cin/32, kh, kw, 32)).
+// Ablation of igemm_tile_x3 showed the operand loads through the CU's vector-memory path to be the
+// bound (16 KB of fp32 activations + 8 KB of weights per 128x128x32 chunk).  With the standard row
+// order consecutive tile rows are consecutive pixels, so for one (32-channel slab, kh) the three
+// kw taps read the SAME 130 pixels [m0 - 1, m0 + 128] shifted by 0 / 1 / 2 rows: they are fetched,
+// split and stored to LDS once per group of three K steps instead of three times.  What a tap may
+// not use (image borders: left / right column wrap, top / bottom rows, rows past M) is masked when
+// the A fragment is READ: the lane's LDS address is redirected to a zero row.
+// A work unit is 6 K steps (two (slab, kh) groups): two A stages alternate per group, two W stages
+// per step, all indices static, no branches in the loop.  Needs Cin % 64 == 0.
+// ---------------------------------------------------------------------------------------------
+template <int BN>
+struct GeoHalo {
+    static constexpr int AR = 132;                        // LDS rows per A plane: 130 used + zero rows 130, 131
+    static constexpr int A_STAGE = 2 * AR * 32;           // u16: [2 planes][AR][32]
+    static constexpr int W_STAGE = BN * 32;               // u16: [BN][32]
+    static constexpr int TILE_FLOATS = (2 * A_STAGE + 2 * W_STAGE) / 2;
+};
+
+template <int BN, int WAVES_M, int WAVES_N>
+__device__ __forceinline__ void igemm_tile_halo(const IgemmP& p, float* lds, int tile, int ub, int ue, float* partial) {
+    constexpr int BM = 128, BK = 32;
+    using G = Geo<BM, BN, WAVES_M, WAVES_N, BK>;
+    using H = GeoHalo<BN>;
+    constexpr int TM = G::TM, TN = G::TN, WTN = G::WTN, LROW = G::LROW;
+    constexpr int AR = H::AR, ZR = 131;
+    constexpr int ALD = 5;                                // 130 rows x 8 k-quads / 256 threads, passes of 32 rows
+    constexpr int RPW = 64, WLD = (BN + RPW - 1) / RPW;   // W: 4 chunks per row, 64 rows per pass
+    u16* As = (u16*)lds;                                  // [2 stages][2 planes][AR][32]
+    u16* Ws = As + 2 * H::A_STAGE;                        // [2 stages][BN][32]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = (tile / p.tiles_n) * BM, n0 = (tile % p.tiles_n) * BN;
+    const int wm0 = (wave / WAVES_N) * (TM * 32), wn0 = (wave % WAVES_N) * (TN * 32);
+    const int lc = tid & 7, lr = tid >> 3;                // A: k-quad lc of LDS rows lr + 32 i
+    const int wc = tid & 3, wr = tid >> 2;                // W: chunk wc of rows wr + 64 j
+    const int fr = lane & 31, fh = lane >> 5;
+
+    __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.a, 0, (int)p.a_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.wh, 0, (int)p.wh_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rsA0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.a, 0, 0, 0x00020000);
+    __amdgpu_buffer_rsrc_t rsW0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.wh, 0, 0, 0x00020000);
+    const float a_sc = pow2f(a_scale_exp(p.a_absmax));
+
+    // A: LDS row j holds pixel (m0 - 1 + j) + (kh - 1) * W of the current slab.  Byte offset of the
+    // kh = 1 pixel; a negative pixel index wraps to >= 2^31 and is out of range = zeros.
+    unsigned fa_off[ALD];
+#pragma unroll
+    for (int i = 0; i < ALD; ++i) {
+        const int j = lr + 32 * i;
+        fa_off[i] = j < 130 ? (unsigned)((m0 - 1 + j) * p.Cin) * 4u + lc * 16u : OOR;
+    }
+    unsigned fw_off[WLD];
+#pragma unroll
+    for (int j = 0; j < WLD; ++j) {
+        const int row = wr + RPW * j;
+        fw_off[j] = (row < BN && n0 + row < p.N) ? ((unsigned)(n0 + row) * (unsigned)p.ldw + wc * 8u) * 2u : OOR;
+    }
+    // tap-validity masks of this lane's two FRAGMENT rows (output pixels), bit kh * 3 + kw
+    unsigned fmask[TM];
+    int faddr[TM][3][2];                                  // u16 index of (row + kw, k sub-step) in plane 0
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int r = wm0 + i * 32 + fr, m = m0 + r;
+        unsigned msk = 0;
+        if (m < p.M) {
+            const int hw = p.Ho * p.Wo, n = m / hw, rem = m - n * hw, ho = rem / p.Wo, wo = rem - ho * p.Wo;
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw)
+                    if (ho + kh - 1 >= 0 && ho + kh - 1 < p.H && wo + kw - 1 >= 0 && wo + kw - 1 < p.W)
+                        msk |= 1u << (kh * 3 + kw);
+        }
+        fmask[i] = msk;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                faddr[i][kw][ks] = (r + kw) * 32 + (((2 * ks + fh) ^ x3_swz<32>(r + kw)) << 3);
+    }
+    int wfaddr[TN][2];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int r = wn0 + j * 32 + fr;
+            wfaddr[j][ks] = r * 32 + (((2 * ks + fh) ^ x3_swz<32>(r)) << 3);
+        }
+
+    f32x4 a_r[ALD];
+    u32x4 w_r0[WLD], w_r1[WLD];
+    // group g = (slab, kh): pixel shift (kh - 1) * W, channel offset slab * 32
+    auto load_a = [&](int g, bool valid) {
+        const int slab = g / 3, kh = g - slab * 3;
+        const unsigned delta = (unsigned)(((kh - 1) * p.W * p.Cin + slab * 32) * 4);
+        const __amdgpu_buffer_rsrc_t ra = valid ? rsA : rsA0;
+#pragma unroll
+        for (int i = 0; i < ALD; ++i) a_r[i] = buf_load16(ra, fa_off[i] == OOR ? OOR : fa_off[i] + delta, 0u);
+    };
+    auto store_a = [&](int stage) {
+        u16* Ab = As + stage * H::A_STAGE;
+#pragma unroll
+        for (int i = 0; i < ALD; ++i) {
+            const int row = lr + 32 * i;
+            if (row < 130) {
+                unsigned hp[2], lp[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) split2h_pair(a_r[i][2 * j], a_r[i][2 * j + 1], a_sc, hp[j], lp[j]);
+                const int off = row * 32 + ((((lc >> 1) ^ x3_swz<32>(row))) << 3) + ((lc & 1) << 2);
+                *(u32x2*)(Ab + off) = (u32x2){hp[0], hp[1]};
+                *(u32x2*)(Ab + AR * 32 + off) = (u32x2){lp[0], lp[1]};
+            }
+        }
+    };
+    auto load_w = [&](int t, u32x4 (&w_reg)[WLD], bool valid) {
+        const __amdgpu_buffer_rsrc_t rw = valid ? rsW : rsW0;
+#pragma unroll
+        for (int j = 0; j < WLD; ++j) w_reg[j] = __builtin_amdgcn_raw_buffer_load_b128(rw, fw_off[j], (unsigned)t * 64u, 0);
+    };
+    auto store_w = [&](int stage, const u32x4 (&w_reg)[WLD]) {
+        u16* Wb = Ws + stage * H::W_STAGE;
+#pragma unroll
+        for (int j = 0; j < WLD; ++j) {
+            const int row = wr + RPW * j;
+            if (row < BN) *(u32x4*)(Wb + row * 32 + ((wc ^ x3_swz<32>(row)) << 3)) = w_reg[j];
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // tap = kh * 3 + kw of the step (bit of fmask); astage / wstage / kw are compile-time at every call
+    auto compute = [&](int astage, int wstage, int kw, int tap) {
+        const u16* Ab = As + astage * H::A_STAGE;
+        const u16* Wb = Ws + wstage * H::W_STAGE;
+        int aoff[TM][2];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const bool ok = (fmask[i] >> tap) & 1u;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) aoff[i][ks] = ok ? faddr[i][kw][ks] : ZR * 32;
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            u32x4 af[TM][2], wf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                af[i][0] = *(const u32x4*)(Ab + aoff[i][ks]);
+                af[i][1] = *(const u32x4*)(Ab + AR * 32 + aoff[i][ks]);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) wf[j] = *(const u32x4*)(Wb + wfaddr[j][ks]);
+#pragma unroll
+            for (int pl = 1; pl >= 0; --pl)              // (lo, w) first, then (hi, w)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[i][pl]),
+                                                                           __builtin_bit_cast(f16x8, wf[j]), acc[i][j], 0, 0, 0);
+        }
+    };
+
+    const int t_end = ue * 6, g_end = ue * 2;
+    __syncthreads();                                      // a previous tile of this workgroup may still use the LDS
+    // zero rows 130, 131 of both planes of both A stages (never written by the loader)
+    if (tid < 2 * 2 * 2 * 4) {                            // 2 stages x 2 planes x 2 rows x 4 chunks of 16 B
+        const int ch = tid & 3, row = 130 + ((tid >> 2) & 1), pl = (tid >> 3) & 1, st = tid >> 4;
+        *(u32x4*)(As + st * H::A_STAGE + pl * AR * 32 + row * 32 + ch * 8) = (u32x4){0u, 0u, 0u, 0u};
+    }
+    load_a(2 * ub, true);
+    load_w(6 * ub, w_r0, true);
+    load_w(6 * ub + 1, w_r1, true);
+    store_a(0);
+    store_w(0, w_r0);
+    load_a(2 * ub + 1, true);
+    __syncthreads();
+
+    for (int u = ub; u < ue; ++u) {
+        const int t = 6 * u, g = 2 * u;
+        const int tap0 = (g % 3) * 3, tap1 = ((g + 1) % 3) * 3;      // kh * 3 of the unit's two groups
+        // step 0: group g, kw 0
+        load_w(t + 2, w_r0, t + 2 < t_end);
+        compute(0, 0, 0, tap0);
+        store_w(1, w_r1);
+        __syncthreads();
+        // step 1: kw 1; the other A stage (last read in the previous unit) receives group g + 1
+        load_w(t + 3, w_r1, t + 3 < t_end);
+        compute(0, 1, 1, tap0 + 1);
+        store_w(0, w_r0);
+        store_a(1);
+        load_a(g + 2, g + 2 < g_end);
+        __syncthreads();
+        // step 2: kw 2
+        load_w(t + 4, w_r0, t + 4 < t_end);
+        compute(0, 0, 2, tap0 + 2);
+        store_w(1, w_r1);
+        __syncthreads();
+        // step 3: group g + 1, kw 0
+        load_w(t + 5, w_r1, t + 5 < t_end);
+        compute(1, 1, 0, tap1);
+        store_w(0, w_r0);
+        __syncthreads();
+        // step 4: kw 1; A stage 0 (last read at step 2) receives group g + 2
+        load_w(t + 6, w_r0, t + 6 < t_end);
+        compute(1, 0, 1, tap1 + 1);
+        store_w(1, w_r1);
+        store_a(0);
+        load_a(g + 3, g + 3 < g_end);
+        __syncthreads();
+        // step 5: kw 2
+        load_w(t + 7, w_r1, t + 7 < t_end);
+        compute(1, 1, 2, tap1 + 2);
+        store_w(0, w_r0);
+        __syncthreads();
+    }
+
+    if (partial) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) partial[((i * TN + j) * 16 + r) * 256 + tid] = acc[i][j][r];
+        return;
+    }
+    const float acc_scale = igemm_acc_scale(p);
+    {
+#include "igemm_epilogue.inc"
+    }
+}
+
+template <int BN, int WAVES_M, int WAVES_N, int MINB, int SK>
+__global__ __launch_bounds__(256, MINB) void igemm_halo_kernel(const IgemmP p) {
+    using G = Geo<128, BN, WAVES_M, WAVES_N, 32>;
+    constexpr int LDSF = GeoHalo<BN>::TILE_FLOATS > G::EPI_FLOATS ? GeoHalo<BN>::TILE_FLOATS : G::EPI_FLOATS;
+    __shared__ __attribute__((aligned(16))) float lds[LDSF];
+    const int nu = p.K / 192;                             // units of 6 K steps per tile
+    if constexpr (!SK) {
+        igemm_tile_halo<BN, WAVES_M, WAVES_N>(p, lds, xcd_remap(blockIdx.x, p.n_tiles), 0, nu, nullptr);
+    } else {
+        const long long U = (long long)p.n_tiles * nu;
+        long long u = U * blockIdx.x / p.sk_blocks;
+        const long long u1 = U * (blockIdx.x + 1) / p.sk_blocks;
+        for (int seg = 0; u < u1; ++seg) {
+            const int tile = (int)(u / nu), ub = (int)(u - (long long)tile * nu);
+            const int ue = (int)((u1 - u < nu - ub) ? ub + (u1 - u) : nu);
+            float* partial = (ub == 0 && ue == nu)
+                                 ? nullptr
+                                 : p.sk_ws + ((size_t)blockIdx.x * 2 + (seg ? 1 : 0)) * (size_t)(128 * BN);
+            igemm_tile_halo<BN, WAVES_M, WAVES_N>(p, lds, tile, ub, ue, partial);
+            u += ue - ub;
+        }
+    }
+}
+
 // fp32 [N][K] -> three bf16 planes [3][N][K] (hi, mid, lo)
 __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ w, u16* __restrict__ out,
                                                            long long n) {
@@ -881,7 +1145,7 @@ template <int BM, int BN, int WAVES_M, int WAVES_N, int BK>
 __global__ __launch_bounds__(256) void igemm_fixup_kernel(const IgemmP p) {
     using G = Geo<BM, BN, WAVES_M, WAVES_N, BK>;
     __shared__ __attribute__((aligned(16))) float lds[G::EPI_FLOATS];
-    const int nk = (p.K + BK - 1) / BK;
+    const int nk = p.sk_nk ? p.sk_nk : (p.K + BK - 1) / BK;
     const long long U = (long long)p.n_tiles * nk;
     const int g = blockIdx.x + 1, nb = p.sk_blocks;
     const long long b = U * g / nb;
@@ -1048,11 +1312,58 @@ inline int forced_bk() {
     return v;
 }
 
+// 3x3 / stride 1 / pad 1 convs on the halo kernel (see igemm_tile_halo).  Returns 1 when it launched.
+template <int BN>
+int launch_halo(IgemmP& p, hipStream_t s, void* ws, size_t ws_bytes, int* rc) {
+    constexpr int BM = 128, MB = 3;
+    const int tiles_m = (p.M + BM - 1) / BM;
+    p.tiles_n = (p.N + BN - 1) / BN;
+    p.n_tiles = tiles_m * p.tiles_n;
+    if (p.n_tiles < 192) return 0;                  // small problems: the 64x64 tiles fill the chip better
+    const int nu = p.K / 192;
+    p.sk_blocks = 0; p.sk_ws = nullptr; p.sk_nk = 0;
+    static const int sk_mode = [] { const char* e = getenv("DBMM_IGEMM_STREAMK"); return e ? atoi(e) : 1; }();
+    const int grid_sk = NUM_CUS * MB;
+    const size_t need = (size_t)grid_sk * 2 * BM * BN * sizeof(float);
+    if (sk_mode && ws && ws_bytes >= need && dbmm_aligned16(ws) && nu >= 4) {
+        const double per_slot = (double)p.n_tiles / NUM_CUS;
+        const double eff = per_slot / (double)((p.n_tiles + NUM_CUS - 1) / NUM_CUS);
+        if (sk_mode == 2 || (eff < 0.93 && (long long)p.n_tiles * nu >= 4LL * grid_sk)) {
+            p.sk_blocks = grid_sk; p.sk_ws = (float*)ws; p.sk_nk = nu;
+        }
+    }
+    const dim3 g(p.sk_blocks ? p.sk_blocks : p.n_tiles, 1);
+    if (p.sk_blocks)
+        hipLaunchKernelGGL((igemm_halo_kernel<BN, 2, 2, MB, 1>), g, dim3(256), 0, s, p);
+    else
+        hipLaunchKernelGGL((igemm_halo_kernel<BN, 2, 2, MB, 0>), g, dim3(256), 0, s, p);
+    {
+        const int c[11] = {BM, BN, 2, 2, 1, 0, 32, MB, 4, p.sk_blocks ? 1 : 0, 1};   // [8] = 4: halo kernel
+        for (int i = 0; i < 11; ++i) g_last_cfg[i] = c[i];
+    }
+    *rc = (int)hipGetLastError();
+    if (*rc == 0 && p.sk_blocks) {
+        hipLaunchKernelGGL((igemm_fixup_kernel<BM, BN, 2, 2, 32>), dim3(p.sk_blocks - 1), dim3(256), 0, s, p);
+        *rc = (int)hipGetLastError();
+    }
+    return 1;
+}
+
 template <int AMODE, int WMODE>
 int launch_modes(IgemmP& p, hipStream_t s, int nbatch = 1, void* ws = nullptr, size_t wsb = 0) {
     // tile choice: widest N tile that N fills; drop to 64x64 when the 128-wide grid would
     // leave most of the 256 CUs idle (small-M projections).
     const long long t128 = (long long)((p.M + 127) / 128) * ((p.N + 127) / 128) * nbatch;
+    if constexpr (AMODE == 1 && WMODE == 0) {
+        // DBMM_IGEMM_HALO=0 selects the per-tap kernel (read on every call: tests compare both in one process)
+        const char* e = getenv("DBMM_IGEMM_HALO");
+        if ((e ? atoi(e) : 1) && nbatch == 1 && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && p.slab == 32 &&
+            p.wh && p.nw == 1 && p.a_absmax && !p.pool2 && (p.Cin % 64) == 0 && p.N > 32 && p.a_bytes && p.wh_bytes &&
+            (p.N & 3) == 0) {
+            int rc = 0;
+            if (p.N <= 64 ? launch_halo<64>(p, s, ws, wsb, &rc) : launch_halo<128>(p, s, ws, wsb, &rc)) return rc;
+        }
+    }
     if (forced_bk() == 32) {
         if (p.N <= 32) return launch_cfg<128, 32, 4, 1, AMODE, WMODE, 32, 3>(p, s, nbatch, ws, wsb);
         if (p.N <= 64) return launch_cfg<128, 64, 2, 2, AMODE, WMODE, 32, 3>(p, s, nbatch, ws, wsb);

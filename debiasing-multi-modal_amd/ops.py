@@ -41,6 +41,8 @@ def _last_igemm_tag():
     """exact instantiation of the igemm launch just issued, spelled like rocprofv3's kernel name"""
     cfg = (ctypes.c_int * 11)()
     _lib.lib().dbmm_debug_last_igemm(cfg)
+    if cfg[8] == 4:        # 3x3 halo kernel: <BN, WAVES_M, WAVES_N, MINB, SK>
+        return f"igemm_halo_kernel<{cfg[1]}, {cfg[2]}, {cfg[3]}, {cfg[7]}, {cfg[9]}>"
     if cfg[8] in (2, 3):   # split-precision kernels: <BM, BN, WAVES_M, WAVES_N, AMODE, MINB, SK, NP, NW, BK>
         return (f"igemm_x3_kernel<{cfg[0]}, {cfg[1]}, {cfg[2]}, {cfg[3]}, {cfg[4]}, {cfg[7]}, {cfg[9]}, {cfg[8]}, "
                 f"{cfg[10]}, {cfg[6]}>")

@@ -670,3 +670,37 @@ def test_conv_chunk32_major_layout(B, H, Cin, Cout, single, pool):
     o32 = ops.conv_bn_act(xd, wp, b.to(DEV), None, 3, 3, 1, 1, ops.ACT_RELU, wl, pool=pool)     # fp32-MFMA kernel
     e2, e32 = relerr(o2.cpu().double(), ref), relerr(o32.cpu().double(), ref)
     assert e32 < 2e-5 and e2 < 5e-6 and e2 < 5 * e32 + 5e-7, (e2, e32)
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,res", [(8, 56, 56, 64, 64, False), (128, 14, 14, 256, 256, False),
+                                                (512, 7, 7, 512, 512, False), (33, 28, 28, 128, 128, False),
+                                                (9, 40, 72, 64, 192, False), (70, 19, 19, 128, 128, True)])
+def test_conv3x3_halo_kernel(B, H, W, Cin, Cout, res, monkeypatch):
+    """3x3 conv with the activation tile reused across the kw taps (LDS rows shifted, border taps
+    redirected to a zero row): equal to the per-tap kernel up to summation order, and to fp64.
+    Shapes cover every image-border case (7x7 ... 56x56, non-square, M not a multiple of 128,
+    stream-K and plain grids, residual)."""
+    x = rnd(1, "x", (B, Cin, H, W)); w = rnd(2, "w", (Cout, Cin, 3, 3), (Cin * 9) ** -0.5).half().float()
+    b = rnd(3, "b", (Cout,), 0.1); sc = 0.5 + synth.uniform(4, "sc", (Cout,))
+    r = rnd(5, "r", (B, Cout, H, W)) if res else None
+    ref = F.conv2d(x.double(), w.double(), None, padding=1) * sc.double().view(1, -1, 1, 1) + b.double().view(1, -1, 1, 1)
+    if res:
+        ref = ref + r.double()
+    ref = torch.relu(ref).permute(0, 2, 3, 1)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    rd = r.permute(0, 2, 3, 1).contiguous().to(DEV) if res else None
+    wp, wl = ops.pack_conv_weight(w.to(DEV), chunk_major=32)
+    ph, we, n = ops.split_planes_f16(wp, allow_single=True)
+    assert n == 1
+    kw = dict(w_planes_f16=ph, w_exp=we, x_absmax=xd.abs().max().reshape(1), out_scale=sc.to(DEV))
+    am = torch.zeros(1, device=DEV)
+    monkeypatch.setenv("DBMM_IGEMM_HALO", "1")
+    o = ops.conv_bn_act(xd, wp, b.to(DEV), rd, 3, 3, 1, 1, ops.ACT_RELU, wl, y_absmax=am, **kw)
+    tag = ops._last_igemm_tag()
+    assert tag.startswith("igemm_halo_kernel<"), tag
+    monkeypatch.setenv("DBMM_IGEMM_HALO", "0")
+    o_tap = ops.conv_bn_act(xd, wp, b.to(DEV), rd, 3, 3, 1, 1, ops.ACT_RELU, wl, **kw)
+    assert ops._last_igemm_tag().startswith("igemm_x3_kernel<")
+    assert relerr(o.cpu(), o_tap.cpu()) < 2e-6
+    assert relerr(o.cpu().double(), ref) < 5e-6
+    assert am.item() == o.abs().max().item()
