@@ -989,7 +989,9 @@ __device__ __forceinline__ void igemm_tile_halo(const IgemmP& p, float* lds, int
         }
     };
 
-    const int t_end = ue * 6, g_end = ue * 2;
+    // (an odd number of groups -- Cin = 32 -- leaves half a phantom unit: loads past the end are zeros)
+    const int nk_all = p.K / 32;
+    const int t_end = ue * 6 < nk_all ? ue * 6 : nk_all, g_end = ue * 2 < nk_all / 3 ? ue * 2 : nk_all / 3;
     __syncthreads();                                      // a previous tile of this workgroup may still use the LDS
     // zero rows 130, 131 of both planes of both A stages (never written by the loader)
     if (tid < 2 * 2 * 2 * 4) {                            // 2 stages x 2 planes x 2 rows x 4 chunks of 16 B
@@ -998,10 +1000,10 @@ __device__ __forceinline__ void igemm_tile_halo(const IgemmP& p, float* lds, int
     }
     load_a(2 * ub, true);
     load_w(6 * ub, w_r0, true);
-    load_w(6 * ub + 1, w_r1, true);
+    load_w(6 * ub + 1, w_r1, 6 * ub + 1 < t_end);
     store_a(0);
     store_w(0, w_r0);
-    load_a(2 * ub + 1, true);
+    load_a(2 * ub + 1, 2 * ub + 1 < g_end);
     __syncthreads();
 
     for (int u = ub; u < ue; ++u) {
@@ -1063,7 +1065,7 @@ __global__ __launch_bounds__(256, MINB) void igemm_halo_kernel(const IgemmP p) {
     using G = Geo<128, BN, WAVES_M, WAVES_N, 32>;
     constexpr int LDSF = GeoHalo<BN>::TILE_FLOATS > G::EPI_FLOATS ? GeoHalo<BN>::TILE_FLOATS : G::EPI_FLOATS;
     __shared__ __attribute__((aligned(16))) float lds[LDSF];
-    const int nu = p.K / 192;                             // units of 6 K steps per tile
+    const int nu = (p.K / 32 + 5) / 6;                    // units of 6 K steps per tile (stream-K: K % 192 == 0)
     if constexpr (!SK) {
         igemm_tile_halo<BN, WAVES_M, WAVES_N>(p, lds, xcd_remap(blockIdx.x, p.n_tiles), 0, nu, nullptr);
     } else {
@@ -1315,17 +1317,18 @@ inline int forced_bk() {
 // 3x3 / stride 1 / pad 1 convs on the halo kernel (see igemm_tile_halo).  Returns 1 when it launched.
 template <int BN>
 int launch_halo(IgemmP& p, hipStream_t s, void* ws, size_t ws_bytes, int* rc) {
-    constexpr int BM = 128, MB = 3;
+    constexpr int BM = 128, MB = BN == 32 ? 4 : 3;       // 37 KB / 42 KB / 50 KB of LDS per workgroup
     const int tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = (p.N + BN - 1) / BN;
     p.n_tiles = tiles_m * p.tiles_n;
     if (p.n_tiles < 192) return 0;                  // small problems: the 64x64 tiles fill the chip better
-    const int nu = p.K / 192;
+    const int nu = (p.K / 32 + 5) / 6;
+    const bool whole_units = (p.K % 192) == 0;           // stream-K cuts at unit boundaries
     p.sk_blocks = 0; p.sk_ws = nullptr; p.sk_nk = 0;
     static const int sk_mode = [] { const char* e = getenv("DBMM_IGEMM_STREAMK"); return e ? atoi(e) : 1; }();
     const int grid_sk = NUM_CUS * MB;
     const size_t need = (size_t)grid_sk * 2 * BM * BN * sizeof(float);
-    if (sk_mode && ws && ws_bytes >= need && dbmm_aligned16(ws) && nu >= 4) {
+    if (sk_mode && whole_units && ws && ws_bytes >= need && dbmm_aligned16(ws) && nu >= 4) {
         const double per_slot = (double)p.n_tiles / NUM_CUS;
         const double eff = per_slot / (double)((p.n_tiles + NUM_CUS - 1) / NUM_CUS);
         if (sk_mode == 2 || (eff < 0.93 && (long long)p.n_tiles * nu >= 4LL * grid_sk)) {
@@ -1333,17 +1336,18 @@ int launch_halo(IgemmP& p, hipStream_t s, void* ws, size_t ws_bytes, int* rc) {
         }
     }
     const dim3 g(p.sk_blocks ? p.sk_blocks : p.n_tiles, 1);
+    constexpr int WM = BN == 32 ? 4 : 2, WN = BN == 32 ? 1 : 2;
     if (p.sk_blocks)
-        hipLaunchKernelGGL((igemm_halo_kernel<BN, 2, 2, MB, 1>), g, dim3(256), 0, s, p);
+        hipLaunchKernelGGL((igemm_halo_kernel<BN, WM, WN, MB, 1>), g, dim3(256), 0, s, p);
     else
-        hipLaunchKernelGGL((igemm_halo_kernel<BN, 2, 2, MB, 0>), g, dim3(256), 0, s, p);
+        hipLaunchKernelGGL((igemm_halo_kernel<BN, WM, WN, MB, 0>), g, dim3(256), 0, s, p);
     {
-        const int c[11] = {BM, BN, 2, 2, 1, 0, 32, MB, 4, p.sk_blocks ? 1 : 0, 1};   // [8] = 4: halo kernel
+        const int c[11] = {BM, BN, WM, WN, 1, 0, 32, MB, 4, p.sk_blocks ? 1 : 0, 1};   // [8] = 4: halo kernel
         for (int i = 0; i < 11; ++i) g_last_cfg[i] = c[i];
     }
     *rc = (int)hipGetLastError();
     if (*rc == 0 && p.sk_blocks) {
-        hipLaunchKernelGGL((igemm_fixup_kernel<BM, BN, 2, 2, 32>), dim3(p.sk_blocks - 1), dim3(256), 0, s, p);
+        hipLaunchKernelGGL((igemm_fixup_kernel<BM, BN, WM, WN, 32>), dim3(p.sk_blocks - 1), dim3(256), 0, s, p);
         *rc = (int)hipGetLastError();
     }
     return 1;
@@ -1358,10 +1362,12 @@ int launch_modes(IgemmP& p, hipStream_t s, int nbatch = 1, void* ws = nullptr, s
         // DBMM_IGEMM_HALO=0 selects the per-tap kernel (read on every call: tests compare both in one process)
         const char* e = getenv("DBMM_IGEMM_HALO");
         if ((e ? atoi(e) : 1) && nbatch == 1 && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && p.slab == 32 &&
-            p.wh && p.nw == 1 && p.a_absmax && !p.pool2 && (p.Cin % 64) == 0 && p.N > 32 && p.a_bytes && p.wh_bytes &&
+            p.wh && p.nw == 1 && p.a_absmax && !p.pool2 && (p.Cin % 32) == 0 && p.a_bytes && p.wh_bytes &&
             (p.N & 3) == 0) {
             int rc = 0;
-            if (p.N <= 64 ? launch_halo<64>(p, s, ws, wsb, &rc) : launch_halo<128>(p, s, ws, wsb, &rc)) return rc;
+            if (p.N <= 32 ? launch_halo<32>(p, s, ws, wsb, &rc)
+                          : (p.N <= 64 ? launch_halo<64>(p, s, ws, wsb, &rc) : launch_halo<128>(p, s, ws, wsb, &rc)))
+                return rc;
         }
     }
     if (forced_bk() == 32) {

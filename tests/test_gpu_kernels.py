@@ -674,7 +674,9 @@ def test_conv_chunk32_major_layout(B, H, Cin, Cout, single, pool):
 
 @pytest.mark.parametrize("B,H,W,Cin,Cout,res", [(8, 56, 56, 64, 64, False), (128, 14, 14, 256, 256, False),
                                                 (512, 7, 7, 512, 512, False), (33, 28, 28, 128, 128, False),
-                                                (9, 40, 72, 64, 192, False), (70, 19, 19, 128, 128, True)])
+                                                (9, 40, 72, 64, 192, False), (70, 19, 19, 128, 128, True),
+                                                (4, 112, 112, 32, 32, False), (16, 40, 40, 32, 64, False),
+                                                (40, 26, 26, 96, 128, True)])
 def test_conv3x3_halo_kernel(B, H, W, Cin, Cout, res, monkeypatch):
     """3x3 conv with the activation tile reused across the kw taps (LDS rows shifted, border taps
     redirected to a zero row): equal to the per-tap kernel up to summation order, and to fp64.
