@@ -127,6 +127,8 @@ CONV_SPLIT = os.environ.get("DBMM_CONV_SPLIT", "f16")
 # instead of fabric traffic (measured +1.4 ... +9.8 % per 3x3 layer, HBM-side fetch -75 %).
 # pack_conv_weight falls back to tap-major when Cin % 32 != 0.  DBMM_CONV_K_ORDER=tap restores it.
 _K_ORDER = False if os.environ.get("DBMM_CONV_K_ORDER", "chunk32") == "tap" else 32
+# conv3 + downsample branch of a stage's first block as one dual-source GEMM (DBMM_FUSE_DS=0: two launches)
+_FUSE_DS = os.environ.get("DBMM_FUSE_DS", "1") != "0"
 
 
 def _pack_conv(w64, bias, raw=None, scale=None):
@@ -198,6 +200,13 @@ class ModifiedResNet(nn.Module):
                     e[f"c{i}"] = _conv_bn(getattr(blk, f"conv{i}"), getattr(blk, f"bn{i}"))
                 if blk.downsample is not None:
                     e["ds"] = _conv_bn(getattr(blk.downsample, "0"), getattr(blk.downsample, "1"))
+                    c3, ds = e["c3"], e["ds"]
+                    # conv3 + downsample branch as one dual-source GEMM: needs both weights as single exact
+                    # fp16 planes and a non-zero bn3 scale (the accumulators are rescaled by scale_d / scale_3)
+                    if (c3["sc"] is not None and ds["sc"] is not None and c3["ph"] is not None and ds["ph"] is not None
+                            and c3["ph"].shape[0] == 1 and ds["ph"].shape[0] == 1 and float(c3["sc"].abs().min()) > 0.0):
+                        ratio = ds["sc"].double() / c3["sc"].double() * 2.0 ** (c3["we"] - ds["we"])
+                        e["dual"] = dict(ratio=ratio.float().contiguous(), bias=(c3["b"].double() + ds["b"].double()).float())
                 blocks.append(e)
         P["blocks"] = blocks
         ap = self.attnpool
@@ -246,9 +255,20 @@ class ModifiedResNet(nn.Module):
                     if e["stride"] > 1:
                         out = ops.avgpool2d(out, e["stride"])
                 identity = x
+                fused = None
                 if "ds" in e:
                     if e["stride"] > 1:
                         identity = x_pooled if (x_pooled is not None and e["stride"] == 2) else ops.avgpool2d(x, e["stride"])
+                    if "dual" in e and track and _FUSE_DS:
+                        # out = relu(bn3(conv3(out)) + bn_d(conv_d(identity))) in one launch: the branch
+                        # output is never materialised
+                        y_am = amax[slot[0]:slot[0] + 1]
+                        fused = ops.gemm_dual(out, oam, e["c3"]["ph"], e["c3"]["we"], e["c3"]["sc"], identity, am,
+                                              e["ds"]["ph"], e["dual"]["ratio"], e["dual"]["bias"], ops.ACT_RELU, y_am)
+                    if fused is not None:
+                        slot[0] += 2                      # the two slots the unfused calls would have used
+                        x, am, x_pooled = fused, y_am, None
+                        continue
                     identity, _ = conv(identity, am, e["ds"], None, 1, 0, ops.ACT_NONE)
                 # conv3 + bn3, residual add and the final ReLU fused into one epilogue; when the next
                 # block downsamples, the same launch also writes AvgPool2d(2) of its output for that

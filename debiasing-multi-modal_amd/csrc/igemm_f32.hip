@@ -65,6 +65,12 @@ struct IgemmP {
     unsigned a_bytes, w_bytes;          // FAST loader: buffer extents (< 2 GiB)
     int sk_blocks;                      // stream-K: resident grid size (0 = one tile per block)
     float* sk_ws;                       // stream-K: [sk_blocks][2][BM*BN] partial accumulators
+    // second operand pair of the fused "conv3 + downsample branch" GEMM (TWO = 1): its K2 / 32 chunks
+    // run first, then the accumulators are multiplied per output channel by ratio[n] * 2^(s - s2) and the
+    // main pair (a, wh) continues in the same accumulators
+    const float* a2; long long lda2; unsigned a2_bytes; int K2;
+    const unsigned short* wh2; unsigned wh2_bytes; long long ldw2;
+    const float* a2_absmax; const float* ratio;
     int sk_nk;                          // stream-K: work units per tile when they are not K / BK chunks (0 = chunks)
     const unsigned short* w3;           // split path: W as three bf16 planes [3][N][ldw]
     unsigned w3_bytes;
@@ -558,10 +564,11 @@ struct GeoX3 {   // LDS floats for the split path (NP / NW 16-bit planes of A / 
 template <int BK>
 __device__ __forceinline__ int x3_swz(int row) { return BK == 16 ? ((row >> 3) & 1) : ((row >> 2) & 3); }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int AMODE, int NP, int NW, int BK>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int AMODE, int NP, int NW, int BK, int TWO = 0>
 __device__ __forceinline__ void igemm_tile_x3(const IgemmP& p, float* lds, int tile, int kb, int ke, float* partial) {
     static_assert(BK == 16 || BK == 32, "BK");
     static_assert((NP == 3 && NW == 3) || (NP == 2 && (NW == 2 || NW == 1)), "planes");
+    static_assert(!TWO || (AMODE == 0 && NP == 2 && NW == 1 && BK == 32), "dual-source variant: plain GEMM, one weight plane");
     using G = Geo<BM, BN, WAVES_M, WAVES_N, BK>;
     constexpr int TM = G::TM, TN = G::TN, WTN = G::WTN, LROW = G::LROW;
     constexpr int QPR = BK / 4, RPA = 256 / QPR;   // A: k-quads (4 fp32) per row, rows per pass of the 256 threads
@@ -595,6 +602,41 @@ __device__ __forceinline__ void igemm_tile_x3(const IgemmP& p, float* lds, int t
         const int row = wr + RPW * j;
         fw_off[j] = (row < BN && n0 + row < p.N) ? ((unsigned)(n0 + row) * (unsigned)p.ldw + wc * 8u) * 2u : OOR;
     }
+    // TWO: switch the loader to the second operand pair (a2, wh2) and back
+    auto use_second = [&]() {
+        rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.a2, 0, (int)p.a2_bytes, 0x00020000);
+        rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.wh2, 0, (int)p.wh2_bytes, 0x00020000);
+        rsA0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.a2, 0, 0, 0x00020000);
+        rsW0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.wh2, 0, 0, 0x00020000);
+        a_sc = pow2f(a_scale_exp(p.a2_absmax));
+#pragma unroll
+        for (int j = 0; j < WLD; ++j) {
+            const int row = wr + RPW * j;
+            fw_off[j] = (row < BN && n0 + row < p.N) ? ((unsigned)(n0 + row) * (unsigned)p.ldw2 + wc * 8u) * 2u : OOR;
+        }
+#pragma unroll
+        for (int i = 0; i < ALD; ++i) {
+            const int m = m0 + lr + RPA * i;
+            fa_off[i] = m < p.M ? (unsigned)m * (unsigned)p.lda2 * 4u + lc * 16u : OOR;
+        }
+    };
+    auto use_first = [&]() {
+        rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.a, 0, (int)p.a_bytes, 0x00020000);
+        rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.wh, 0, (int)p.wh_bytes, 0x00020000);
+        rsA0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.a, 0, 0, 0x00020000);
+        rsW0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.wh, 0, 0, 0x00020000);
+        a_sc = pow2f(a_scale_exp(p.a_absmax));
+#pragma unroll
+        for (int j = 0; j < WLD; ++j) {
+            const int row = wr + RPW * j;
+            fw_off[j] = (row < BN && n0 + row < p.N) ? ((unsigned)(n0 + row) * (unsigned)p.ldw + wc * 8u) * 2u : OOR;
+        }
+#pragma unroll
+        for (int i = 0; i < ALD; ++i) {
+            const int m = m0 + lr + RPA * i;
+            fa_off[i] = m < p.M ? (unsigned)m * (unsigned)p.lda * 4u + lc * 16u : OOR;
+        }
+    };
 #pragma unroll
     for (int i = 0; i < ALD; ++i) {
         const int m = m0 + lr + RPA * i;
@@ -760,24 +802,51 @@ __device__ __forceinline__ void igemm_tile_x3(const IgemmP& p, float* lds, int t
         }
     };
 
-    __syncthreads();
-    load_chunk(kb * BK, a_r0, w_r0, true);
-    load_chunk((kb + 1) * BK, a_r1, w_r1, kb + 1 < ke);
-    store_chunk(0, a_r0, w_r0);
-    __syncthreads();
-
-    // chunk kc lives in LDS stage (kc-kb)&1; set r1 holds chunk kc+1 on even steps, r0 on odd ones
-    for (int kc = kb; kc < ke; kc += 2) {
-        // (no branches inside: a chunk past the end arrives as zeros through the zero-extent
-        //  descriptors and adds nothing; an odd chunk count costs one phantom chunk)
-        load_chunk((kc + 2) * BK, a_r0, w_r0, kc + 2 < ke);
-        compute(0);
-        store_chunk(1, a_r1, w_r1);
+    auto kloop = [&](int kb, int ke) {
         __syncthreads();
-        load_chunk((kc + 3) * BK, a_r1, w_r1, kc + 3 < ke);
-        compute(1);
+        load_chunk(kb * BK, a_r0, w_r0, true);
+        load_chunk((kb + 1) * BK, a_r1, w_r1, kb + 1 < ke);
         store_chunk(0, a_r0, w_r0);
         __syncthreads();
+
+        // chunk kc lives in LDS stage (kc-kb)&1; set r1 holds chunk kc+1 on even steps, r0 on odd ones
+        for (int kc = kb; kc < ke; kc += 2) {
+            // (no branches inside: a chunk past the end arrives as zeros through the zero-extent
+            //  descriptors and adds nothing; an odd chunk count costs one phantom chunk)
+            load_chunk((kc + 2) * BK, a_r0, w_r0, kc + 2 < ke);
+            compute(0);
+            store_chunk(1, a_r1, w_r1);
+            __syncthreads();
+            load_chunk((kc + 3) * BK, a_r1, w_r1, kc + 3 < ke);
+            compute(1);
+            store_chunk(0, a_r0, w_r0);
+            __syncthreads();
+        }
+    };
+    if constexpr (!TWO) {
+        kloop(kb, ke);
+    } else {
+        // chunks [0, nk2) belong to the second operand pair (the downsample branch), the rest to the
+        // main pair.  A share that holds second-pair chunks rescales what it accumulated into the
+        // main pair's units before continuing (or before it is written out as a stream-K partial),
+        // so partial sums of different shares add up.
+        const int nk2 = p.K2 / BK;
+        if (kb < nk2) {
+            use_second();
+            kloop(kb, ke < nk2 ? ke : nk2);
+            const float dyn = pow2f(a_scale_exp(p.a_absmax) - a_scale_exp(p.a2_absmax));
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + wn0 + j * 32 + (lane & 31);
+                const float rt = (n < p.N ? p.ratio[n] : 0.f) * dyn;
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] *= rt;
+            }
+            use_first();
+        }
+        if (ke > nk2) kloop((kb > nk2 ? kb : nk2) - nk2, ke - nk2);
     }
 
     if (partial) {
@@ -795,14 +864,14 @@ __device__ __forceinline__ void igemm_tile_x3(const IgemmP& p, float* lds, int t
     }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int AMODE, int MINB, int SK, int NP, int NW, int BK>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int AMODE, int MINB, int SK, int NP, int NW, int BK, int TWO = 0>
 __global__ __launch_bounds__(256, MINB) void igemm_x3_kernel(const IgemmP p) {
     using G = Geo<BM, BN, WAVES_M, WAVES_N, BK>;
     constexpr int LDSF = GeoX3<BM, BN, NP, NW, BK>::TILE_FLOATS > G::EPI_FLOATS ? GeoX3<BM, BN, NP, NW, BK>::TILE_FLOATS : G::EPI_FLOATS;
     __shared__ __attribute__((aligned(16))) float lds[LDSF];
-    const int nk = p.K / BK;
+    const int nk = p.K / BK + (TWO ? p.K2 / BK : 0);
     if constexpr (!SK) {
-        igemm_tile_x3<BM, BN, WAVES_M, WAVES_N, AMODE, NP, NW, BK>(p, lds, xcd_remap(blockIdx.x, p.n_tiles), 0, nk, nullptr);
+        igemm_tile_x3<BM, BN, WAVES_M, WAVES_N, AMODE, NP, NW, BK, TWO>(p, lds, xcd_remap(blockIdx.x, p.n_tiles), 0, nk, nullptr);
     } else {
         const long long U = (long long)p.n_tiles * nk;
         long long u = U * blockIdx.x / p.sk_blocks;
@@ -813,7 +882,7 @@ __global__ __launch_bounds__(256, MINB) void igemm_x3_kernel(const IgemmP p) {
             float* partial = (kb == 0 && ke == nk)
                                  ? nullptr
                                  : p.sk_ws + ((size_t)blockIdx.x * 2 + (seg ? 1 : 0)) * (size_t)(BM * BN);
-            igemm_tile_x3<BM, BN, WAVES_M, WAVES_N, AMODE, NP, NW, BK>(p, lds, tile, kb, ke, partial);
+            igemm_tile_x3<BM, BN, WAVES_M, WAVES_N, AMODE, NP, NW, BK, TWO>(p, lds, tile, kb, ke, partial);
             u += ke - kb;
         }
     }
@@ -1623,6 +1692,63 @@ extern "C" int dbmm_gemm_bias_act_x2(const float* a, int64_t lda, const float* a
     sx.absmax_out = c_absmax; sx.oscale = out_scale;
     return gemm_impl(a, lda, 0, w, ldw, 0, bias, residual, ldr, c, ldc, M, N, K, alpha, act, workspace, workspace_bytes,
                      stream, sx);
+}
+
+// conv3 + downsample branch of a bottleneck as ONE GEMM launch (see dbmm.h)
+extern "C" int dbmm_gemm_dual_bn_act_x2(const float* a, int64_t lda, const float* a_absmax, const void* w_plane_f16,
+                                        int w_exp, int64_t ldw, int64_t K, const float* out_scale, const float* a2,
+                                        int64_t lda2, const float* a2_absmax, const void* w2_plane_f16, int64_t ldw2,
+                                        int64_t K2, const float* ratio, const float* bias, float* c, int64_t ldc,
+                                        float* c_absmax, int64_t M, int64_t N, int act, void* workspace,
+                                        size_t workspace_bytes, void* stream) {
+    if (!a || !a2 || !a_absmax || !a2_absmax || !w_plane_f16 || !w2_plane_f16 || !ratio || !c) return DBMM_E_ARG;
+    if (act < 0 || act > 2) return DBMM_E_ARG;
+    if (M <= 0 || N <= 0 || K <= 0 || K2 <= 0 || M > INT32_MAX || N > INT32_MAX) return DBMM_E_SHAPE;
+    if ((lda & 3) || (lda2 & 3) || (ldw & 7) || (ldw2 & 7) || (ldc & 3) || !dbmm_aligned16(a) || !dbmm_aligned16(a2) ||
+        !dbmm_aligned16(w_plane_f16) || !dbmm_aligned16(w2_plane_f16) || !dbmm_aligned16(c))
+        return DBMM_E_ALIGN;
+    if ((K % 32) || (K2 % 32) || (N & 3) || w_exp < -40 || w_exp > 40) return DBMM_E_UNSUPPORTED;
+    const long long ab = ((M - 1) * lda + K) * 4, ab2 = ((M - 1) * lda2 + K2) * 4, wb = ((N - 1) * ldw + K) * 2,
+                    wb2 = ((N - 1) * ldw2 + K2) * 2, lim = 0x7FFFFFF0LL;
+    if (ab >= lim || ab2 >= lim || wb >= lim || wb2 >= lim) return DBMM_E_UNSUPPORTED;
+    constexpr int BM = 128, BN = 128, MB = 3;
+    IgemmP p{};
+    p.a = a; p.lda = lda; p.a_bytes = (unsigned)ab; p.a_absmax = a_absmax;
+    p.wh = (const unsigned short*)w_plane_f16; p.wh_bytes = (unsigned)wb; p.ldw = ldw; p.w_exp = w_exp; p.nw = 1;
+    p.a2 = a2; p.lda2 = lda2; p.a2_bytes = (unsigned)ab2; p.a2_absmax = a2_absmax; p.K2 = (int)K2;
+    p.wh2 = (const unsigned short*)w2_plane_f16; p.wh2_bytes = (unsigned)wb2; p.ldw2 = ldw2; p.ratio = ratio;
+    p.oscale = out_scale; p.bias = bias; p.c = c; p.ldc = ldc; p.absmax_out = c_absmax;
+    p.M = (int)M; p.N = (int)N; p.K = (int)K; p.act = act; p.alpha = 1.f;
+    p.tiles_n = (p.N + BN - 1) / BN;
+    p.n_tiles = ((p.M + BM - 1) / BM) * p.tiles_n;
+    if (p.n_tiles < 192) return DBMM_E_UNSUPPORTED;
+    const int nk = (int)(K / 32 + K2 / 32);
+    static const int sk_mode = [] { const char* e = getenv("DBMM_IGEMM_STREAMK"); return e ? atoi(e) : 1; }();
+    const int grid_sk = NUM_CUS * MB;
+    const size_t need = (size_t)grid_sk * 2 * BM * BN * sizeof(float);
+    if (sk_mode && workspace && workspace_bytes >= need && dbmm_aligned16(workspace) && nk >= 8) {
+        const double per_cu = (double)p.n_tiles / NUM_CUS;
+        const double eff = per_cu / (double)((p.n_tiles + NUM_CUS - 1) / NUM_CUS);
+        if (sk_mode == 2 || (eff < 0.93 && (long long)p.n_tiles * nk >= 4LL * grid_sk)) {
+            p.sk_blocks = grid_sk; p.sk_ws = (float*)workspace; p.sk_nk = nk;
+        }
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 g(p.sk_blocks ? p.sk_blocks : p.n_tiles, 1);
+    if (p.sk_blocks)
+        hipLaunchKernelGGL((igemm_x3_kernel<BM, BN, 2, 2, 0, MB, 1, 2, 1, 32, 1>), g, dim3(256), 0, s, p);
+    else
+        hipLaunchKernelGGL((igemm_x3_kernel<BM, BN, 2, 2, 0, MB, 0, 2, 1, 32, 1>), g, dim3(256), 0, s, p);
+    {
+        const int cfg[11] = {BM, BN, 2, 2, 0, 0, 32, MB, 5, p.sk_blocks ? 1 : 0, 1};   // [8] = 5: dual-source GEMM
+        for (int i = 0; i < 11; ++i) g_last_cfg[i] = cfg[i];
+    }
+    DBMM_CHECK_LAUNCH();
+    if (p.sk_blocks) {
+        hipLaunchKernelGGL((igemm_fixup_kernel<BM, BN, 2, 2, 32>), dim3(p.sk_blocks - 1), dim3(256), 0, s, p);
+        DBMM_CHECK_LAUNCH();
+    }
+    return DBMM_OK;
 }
 
 extern "C" int dbmm_conv1x1_bn_act(const float* x, const float* w, const float* bias, const float* residual,

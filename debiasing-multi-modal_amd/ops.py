@@ -41,6 +41,8 @@ def _last_igemm_tag():
     """exact instantiation of the igemm launch just issued, spelled like rocprofv3's kernel name"""
     cfg = (ctypes.c_int * 11)()
     _lib.lib().dbmm_debug_last_igemm(cfg)
+    if cfg[8] == 5:        # conv3 + downsample dual-source GEMM: the x3 kernel with TWO = 1
+        return f"igemm_x3_kernel<{cfg[0]}, {cfg[1]}, {cfg[2]}, {cfg[3]}, 0, {cfg[7]}, {cfg[9]}, 2, 1, 32, 1>"
     if cfg[8] == 4:        # 3x3 halo kernel: <BN, WAVES_M, WAVES_N, MINB, SK>
         return f"igemm_halo_kernel<{cfg[1]}, {cfg[2]}, {cfg[3]}, {cfg[7]}, {cfg[9]}>"
     if cfg[8] in (2, 3):   # split-precision kernels: <BM, BN, WAVES_M, WAVES_N, AMODE, MINB, SK, NP, NW, BK>
@@ -243,6 +245,31 @@ def _conv_x2(x, w, bias, residual, y, kh, kw, stride, pad, act, w_layout, w_plan
                                           ptr(bias), ptr(residual), ptr(y), ptr(y_full), ptr(y_absmax), B, H, W, Cin,
                                           w.shape[0], kh,
                                           kw, stride, pad, act, pool, int(w_layout), ptr(ws), ws.numel() * 4, stream())
+
+
+def gemm_dual(a, a_absmax, w_plane, w_exp, out_scale, a2, a2_absmax, w2_plane, ratio, bias, act=ACT_RELU, c_absmax=None):
+    """c = act((a @ w^T) * out_scale + (a2 @ w2^T) * out_scale2 + bias) as one launch -- conv3 and the
+    downsample branch of a bottleneck's first block (see dbmm_gemm_dual_bn_act_x2).  a [.., K],
+    a2 [.., K2] with the same leading shape; planes [1][N][K] / [1][N][K2].  Returns None when the
+    library has no kernel for the shape (the caller then runs the two convs)."""
+    require_cuda(a, a2)
+    _f32c(a); _f32c(a2)
+    K, K2 = a.shape[-1], a2.shape[-1]
+    M, N = a.numel() // K, w_plane.shape[1]
+    if a2.numel() // K2 != M:
+        raise _lib.DbmmError("gemm_dual: operand row counts differ")
+    c = torch.empty(tuple(a.shape[:-1]) + (N,), device=a.device, dtype=torch.float32)
+    ws = igemm_workspace(a.device)
+    t = _Timed(M, N, K + K2, 0, 0)
+    t.__enter__()
+    rc = _lib.lib().dbmm_gemm_dual_bn_act_x2(ptr(a), K, ptr(a_absmax), ptr(w_plane), int(w_exp), K, K, ptr(out_scale),
+                                             ptr(a2), K2, ptr(a2_absmax), ptr(w2_plane), K2, K2, ptr(ratio), ptr(bias),
+                                             ptr(c), N, ptr(c_absmax), M, N, act, ptr(ws), ws.numel() * 4, stream())
+    if rc == _lib.E_UNSUPPORTED:
+        return None
+    check(rc, "gemm_dual_bn_act_x2")
+    t.__exit__(None, None, None)
+    return c
 
 
 def conv_stem_s2(x_nchw, w, bias, y_absmax=None):

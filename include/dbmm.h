@@ -158,6 +158,24 @@ int dbmm_gemm_bias_act_x2(const float* a, int64_t lda, const float* a_absmax, co
                           float* c, int64_t ldc, float* c_absmax, int64_t M, int64_t N, int64_t K, float alpha,
                           int act, void* workspace, size_t workspace_bytes, void* stream);
 
+/* First block of a ResNet stage (clip/model.py:36-38,42-55): out = relu(bn3(conv3(y)) +
+ * bn_d(conv_d(avgpool(x)))).  Both convs are 1x1, so the sum is ONE GEMM over the concatenated
+ * K = K + K2 -- the downsample branch's output is never written or re-read:
+ *   c = act((a @ w^T) * 2^-(s+w_exp) * out_scale[n] + (a2 @ w2^T) * 2^-(s2+w2_exp) * out_scale2[n] + bias[n])
+ * a [M][K] (lda) = conv2 output, a2 [M][K2] (lda2) = (pooled) block input, both with device scalars
+ * a_absmax / a2_absmax; w_plane_f16 / w2_plane_f16 = single exact fp16 planes [N][K] / [N][K2] of
+ * the stored weights times 2^w_exp / 2^w2_exp.  The kernel accumulates the second pair first,
+ * multiplies the accumulators by ratio[n] * 2^(s - s2) and continues with the first pair;
+ * ratio[n] = out_scale2[n] / out_scale[n] * 2^(w_exp - w2_exp) is supplied by the caller (out_scale
+ * must be non-zero), bias = both BatchNorm biases added.  K, K2 multiples of 32.
+ * DBMM_E_UNSUPPORTED (nothing launched) when the shape does not suit the 128x128 fp16-pair tile. */
+int dbmm_gemm_dual_bn_act_x2(const float* a, int64_t lda, const float* a_absmax, const void* w_plane_f16,
+                             int w_exp, int64_t ldw, int64_t K, const float* out_scale, const float* a2,
+                             int64_t lda2, const float* a2_absmax, const void* w2_plane_f16, int64_t ldw2,
+                             int64_t K2, const float* ratio, const float* bias, float* c, int64_t ldc,
+                             float* c_absmax, int64_t M, int64_t N, int act, void* workspace,
+                             size_t workspace_bytes, void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * Device-side preprocessing (clip/clip.py:79-86: Resize(BICUBIC) -> CenterCrop -> ToTensor ->
  * Normalize) of one decoded RGB uint8 image [H][W][3] resident on the device.  Integer

@@ -706,3 +706,42 @@ def test_conv3x3_halo_kernel(B, H, W, Cin, Cout, res, monkeypatch):
     assert relerr(o.cpu(), o_tap.cpu()) < 2e-6
     assert relerr(o.cpu().double(), ref) < 5e-6
     assert am.item() == o.abs().max().item()
+
+
+@pytest.mark.parametrize("M,N,K,K2", [(25088, 256, 64, 64), (50176, 512, 128, 256), (25088, 1024, 256, 512),
+                                      (25000, 2048, 512, 1024)])
+def test_gemm_dual_conv3_plus_downsample(M, N, K, K2):
+    """relu(bn3(conv3(y)) + bn_d(conv_d(x))) as one dual-source GEMM == the two fp32-accurate
+    launches (conv_d, then conv3 with the residual) and an fp64 reference; incl. stream-K shapes
+    and an M tail."""
+    y = torch.relu(rnd(1, "y", (M, K))); x = torch.relu(rnd(2, "x", (M, K2), 3.0))          # different ranges
+    w = rnd(3, "w", (N, K), K ** -0.5).half().float(); w2 = rnd(4, "w2", (N, K2), K2 ** -0.5).half().float()
+    sc = 0.5 + synth.uniform(5, "sc", (N,)); sc2 = 0.5 + synth.uniform(6, "sc2", (N,))
+    b = rnd(7, "b", (N,), 0.1); b2 = rnd(8, "b2", (N,), 0.1)
+    ref = torch.relu(y.double() @ w.double().t() * sc.double() + b.double() + x.double() @ w2.double().t() * sc2.double()
+                     + b2.double())
+    yd, xd = y.to(DEV), x.to(DEV)
+    ph, we, n1 = ops.split_planes_f16(w.to(DEV), allow_single=True); ph2, we2, n2 = ops.split_planes_f16(w2.to(DEV), allow_single=True)
+    assert n1 == 1 and n2 == 1
+    ratio = (sc2.double() / sc.double() * 2.0 ** (we - we2)).float().to(DEV)
+    ya, xa = yd.abs().max().reshape(1), (xd.abs().max() * 1.7).reshape(1)               # a bound, not the exact max
+    cam = torch.zeros(1, device=DEV)
+    out = ops.gemm_dual(yd, ya, ph, we, sc.to(DEV), xd, xa, ph2, ratio, (b + b2).to(DEV), ops.ACT_RELU, cam)
+    assert out is not None and ops._last_igemm_tag().endswith(", 2, 1, 32, 1>")
+    # unfused: identity = conv_d(x) * sc2 + b2 ; out = relu(conv3(y) * sc + b + identity)
+    v = lambda t: t.reshape(1, 1, M, -1)
+    ident = ops.conv_bn_act(v(xd), w2.to(DEV), b2.to(DEV), None, 1, 1, 1, 0, ops.ACT_NONE, w_planes_f16=ph2, w_exp=we2,
+                            x_absmax=xa, out_scale=sc2.to(DEV))
+    unf = ops.conv_bn_act(v(yd), w.to(DEV), b.to(DEV), ident, 1, 1, 1, 0, ops.ACT_RELU, w_planes_f16=ph, w_exp=we,
+                          x_absmax=ya, out_scale=sc.to(DEV)).reshape(M, N)
+    e_f, e_u = relerr(out.cpu().double(), ref), relerr(unf.cpu().double(), ref)
+    assert e_f < 5e-6 and e_f < 5 * e_u + 5e-7, (e_f, e_u)
+    assert cam.item() == out.abs().max().item()
+
+
+def test_gemm_dual_reports_unsupported_shapes():
+    y = rnd(1, "y", (256, 64)).to(DEV); x = rnd(2, "x", (256, 64)).to(DEV)
+    w = rnd(3, "w", (128, 64)).half().float().to(DEV)
+    ph, we, _ = ops.split_planes_f16(w, allow_single=True)
+    one = torch.ones(128, device=DEV)
+    assert ops.gemm_dual(y, y.abs().max().reshape(1), ph, we, one, x, x.abs().max().reshape(1), ph, one, one) is None
