@@ -48,12 +48,12 @@ SPLIT_PRODUCTS = {(2, 1): 2, (2, 2): 3, (3, 3): 6}
 # algorithmic GFLOP per image, SURVEY.md section 8d (RN50: conv 5.367 + attn-pool 0.426 GMAC)
 GFLOP_PER_IMG = {"RN50": 11.59, "ViT-B/32": 8.82, "ViT-L/14@336px": 381.9}
 # dominant kernel: 3x3 implicit-GEMM conv, 128x128 tile, one tile per workgroup
-# (template arguments <BM, BN, WAVES_M, WAVES_N, AMODE=1 (conv), MINB, SK=0, NP, NW, BK>; NP / NW = 16-bit planes
-#  of the activations / weights: 2, 1 = fp16 pair x exact fp16 weight; 2, 2 = fp16 pair x pair; 3, 3 = bf16 triple)
-DOMINANT_SPLIT = ("igemm_x3_kernel<128, 128, 2, 2, 1, 3, 0, 2, 1, 32>",     # default path
-                  "igemm_x3_kernel<128, 128, 2, 2, 1, 2, 0, 2, 2, 32>",     # weights not exact in fp16
-                  "igemm_x3_kernel<128, 128, 2, 2, 1, 2, 0, 2, 2, 16>",     # DBMM_IGEMM_X2_BK=16
-                  "igemm_x3_kernel<128, 128, 2, 2, 1, 2, 0, 3, 3, 16>")     # DBMM_CONV_SPLIT=bf16
+# (template arguments <BM, BN, WAVES_M, WAVES_N, AMODE=1 (conv), MINB, SK=0, NP, NW, BK, TWO=0>; NP / NW = 16-bit
+#  planes of the activations / weights: 2, 1 = fp16 pair x exact fp16 weight; 2, 2 = fp16 pair x pair; 3, 3 = bf16 triple)
+DOMINANT_SPLIT = ("igemm_x3_kernel<128, 128, 2, 2, 1, 3, 0, 2, 1, 32, 0>",  # default path (the three pooled 3x3 convs)
+                  "igemm_x3_kernel<128, 128, 2, 2, 1, 2, 0, 2, 2, 32, 0>",  # weights not exact in fp16
+                  "igemm_x3_kernel<128, 128, 2, 2, 1, 2, 0, 2, 2, 16, 0>",  # DBMM_IGEMM_X2_BK=16
+                  "igemm_x3_kernel<128, 128, 2, 2, 1, 2, 0, 3, 3, 16, 0>")  # DBMM_CONV_SPLIT=bf16
 DOMINANT_F32 = "igemm_f32_kernel<128, 128, 2, 2, 1, 0, 16, 4, 1, 0, 1>"    # fp32-MFMA path (DBMM_CONV_SPLIT=off)
 
 
@@ -191,7 +191,7 @@ def main():
         if DOMINANT is None:     # other towers (ViT): the MFMA kernel instantiation with the most time
             DOMINANT = max(prof, key=lambda k: prof[k][2]) if prof else DOMINANT_F32
         split = DOMINANT.startswith("igemm_x3_kernel<")
-        n_prod = SPLIT_PRODUCTS[tuple(int(v) for v in DOMINANT.rstrip(">").split(",")[-3:-1])] if split else 1
+        n_prod = SPLIT_PRODUCTS.get(tuple(int(v) for v in DOMINANT.rstrip(">").split(",")[-4:-2]), 2) if split else 1
         peak = F16_MFMA_PEAK_TFLOPS / n_prod if split else FP32_MFMA_PEAK_TFLOPS
         n, fl, ms = prof.get(DOMINANT, (0, 0.0, 0.0))
         ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0

@@ -471,7 +471,7 @@ def test_conv_fp16_pair_stream_k():
                             x_absmax=xd.abs().max().reshape(1), y_absmax=yam)
         tag = ops._last_igemm_tag()
         e = ((o.cpu().double() - ref).abs().max() / ref.abs().max()).item()
-        assert tag.startswith("igemm_x3_kernel<") and tag.endswith(", 1, 2, 2, 32>"), tag   # SK = 1, NP = 2, NW = 2, BK = 32
+        assert tag.startswith("igemm_x3_kernel<") and tag.endswith(", 1, 2, 2, 32, 0>"), tag   # SK = 1, NP = 2, NW = 2, BK = 32, TWO = 0
         assert e < 5e-6, e
         assert yam.item() == o.abs().max().item()
         print("ok")
@@ -520,7 +520,7 @@ def test_conv_fp16_single_plane_with_out_scale(B, H, Cin, Cout, k, res, x2):
                         x_absmax=xd.abs().max().reshape(1), y_absmax=yam, out_scale=sc.to(DEV))
     tag = ops._last_igemm_tag()
     if x2:       # (small problems take the 64x64 fp32-MFMA tile, which also honours out_scale)
-        assert tag.startswith("igemm_x3_kernel<") and tag.endswith(", 2, 1, 32>"), tag   # NP = 2, NW = 1, BK = 32
+        assert tag.startswith("igemm_x3_kernel<") and tag.endswith(", 2, 1, 32, 0>"), tag   # NP = 2, NW = 1, BK = 32, TWO = 0
     # same op on the fp32-MFMA kernel (no planes): identical semantics of out_scale
     o32 = ops.conv_bn_act(xd, wp, b.to(DEV), rd, k, k, 1, k // 2, ops.ACT_RELU, wl, out_scale=sc.to(DEV))
     assert ops._last_igemm_tag().startswith("igemm_f32_kernel<")
