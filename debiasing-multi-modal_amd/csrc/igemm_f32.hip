@@ -1245,6 +1245,19 @@ thread_local int g_last_cfg[11] = {0};
 
 // resident workgroups per CU of the fp16-pair kernels: the 128x128 tile with two W planes is held
 // to 2 by its 64 KB of LDS; with one W plane (48 KB, <= 168 VGPRs) and for the narrower tiles it is 3
+inline int sk_mode_env() {
+    static const int m = [] { const char* e = getenv("DBMM_IGEMM_STREAMK"); return e ? atoi(e) : 1; }();
+    return m;
+}
+// The split-precision kernels keep 2-4 workgroups resident per CU, which already smooths the tile
+// quantisation the one-round model predicts: a CU that runs a leftover tile alone runs it ~3x
+// faster.  Same-box A/B at B = 512: stream-K was +4..5 % on two layer shapes and -6..-52 % on
+// three (layer3/4 conv1: partial sums, extra pipeline fills, a fix-up launch).  It is kept for
+// grids that cannot fill every resident slot once (small batches); DBMM_IGEMM_STREAMK=2 forces it.
+inline bool sk_skip(int n_tiles, int resident_per_cu) {
+    return sk_mode_env() != 2 && n_tiles >= NUM_CUS * resident_per_cu;
+}
+
 constexpr int X2_MINB(int BN, int NW) { return (BN == 128 && NW == 2) ? 2 : 3; }
 
 template <int BM, int BN, int WM, int WN, int AMODE, int WMODE, int BK, int MINB>
@@ -1255,7 +1268,7 @@ int launch_cfg(IgemmP& p, hipStream_t s, int nbatch, void* ws, size_t ws_bytes) 
     p.sk_blocks = 0; p.sk_ws = nullptr;
     // stream-K when whole tiles leave >7 % of the chip idle in the last round and the tile's K
     // loop is long enough to be worth cutting (DBMM_IGEMM_STREAMK=0 disables, =2 forces)
-    static const int sk_mode = [] { const char* e = getenv("DBMM_IGEMM_STREAMK"); return e ? atoi(e) : 1; }();
+    static const int sk_mode = sk_mode_env();
     const int nk = (p.K + BK - 1) / BK;
     const int grid_sk = NUM_CUS * MINB;
     const size_t need = (size_t)grid_sk * 2 * BM * BN * sizeof(float);
@@ -1288,7 +1301,7 @@ int launch_cfg(IgemmP& p, hipStream_t s, int nbatch, void* ws, size_t ws_bytes) 
             const int nkx = p.K / (bk32 ? 32 : 16);
             if (p.sk_blocks) {
                 p.sk_blocks = NUM_CUS * MB;
-                if ((long long)p.n_tiles * nkx < 4LL * p.sk_blocks || nkx < 8) p.sk_blocks = 0;
+                if ((long long)p.n_tiles * nkx < 4LL * p.sk_blocks || nkx < 8 || sk_skip(p.n_tiles, MB)) p.sk_blocks = 0;
             }
             const dim3 g3(p.sk_blocks ? p.sk_blocks : p.n_tiles, 1);
             if (p.nw == 1) {          // W exact in one fp16 plane: two partial products (bk32 guaranteed above)
@@ -1400,7 +1413,7 @@ int launch_halo(IgemmP& p, hipStream_t s, void* ws, size_t ws_bytes, int* rc) {
     if (sk_mode && whole_units && ws && ws_bytes >= need && dbmm_aligned16(ws) && nu >= 4) {
         const double per_slot = (double)p.n_tiles / NUM_CUS;
         const double eff = per_slot / (double)((p.n_tiles + NUM_CUS - 1) / NUM_CUS);
-        if (sk_mode == 2 || (eff < 0.93 && (long long)p.n_tiles * nu >= 4LL * grid_sk)) {
+        if (sk_mode == 2 || (eff < 0.93 && (long long)p.n_tiles * nu >= 4LL * grid_sk && !sk_skip(p.n_tiles, MB))) {
             p.sk_blocks = grid_sk; p.sk_ws = (float*)ws; p.sk_nk = nu;
         }
     }
@@ -1729,7 +1742,7 @@ extern "C" int dbmm_gemm_dual_bn_act_x2(const float* a, int64_t lda, const float
     if (sk_mode && workspace && workspace_bytes >= need && dbmm_aligned16(workspace) && nk >= 8) {
         const double per_cu = (double)p.n_tiles / NUM_CUS;
         const double eff = per_cu / (double)((p.n_tiles + NUM_CUS - 1) / NUM_CUS);
-        if (sk_mode == 2 || (eff < 0.93 && (long long)p.n_tiles * nk >= 4LL * grid_sk)) {
+        if (sk_mode == 2 || (eff < 0.93 && (long long)p.n_tiles * nk >= 4LL * grid_sk && !sk_skip(p.n_tiles, MB))) {
             p.sk_blocks = grid_sk; p.sk_ws = (float*)workspace; p.sk_nk = nk;
         }
     }
