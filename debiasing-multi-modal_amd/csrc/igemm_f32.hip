@@ -1463,7 +1463,7 @@ int launch_modes(IgemmP& p, hipStream_t s, int nbatch = 1, void* ws = nullptr, s
     // epilogue always leaves others feeding the matrix pipe.
     // batched GEMMs with at most 32 rows per problem (attention pool: 32 heads x tokens per image):
     // a 32x128 tile wastes nothing along M where the 128-row tiles idle three quarters of the MFMA rows
-    if (p.M <= 32 && nbatch > 1 && p.N > 64) return launch_cfg<32, 128, 1, 4, AMODE, WMODE, 16, 6>(p, s, nbatch, ws, wsb);
+    if (p.M <= 32 && nbatch > 1 && p.N > 32) return launch_cfg<32, 128, 1, 4, AMODE, WMODE, 16, 6>(p, s, nbatch, ws, wsb);
     if (p.N <= 32) return launch_cfg<128, 32, 4, 1, AMODE, WMODE, 16, 6>(p, s, nbatch, ws, wsb);
     if (p.N <= 64) return launch_cfg<128, 64, 2, 2, AMODE, WMODE, 16, 5>(p, s, nbatch, ws, wsb);
     if (t128 < 192) return launch_cfg<64, 64, 2, 2, AMODE, WMODE, 16, 6>(p, s, nbatch, ws, wsb);
