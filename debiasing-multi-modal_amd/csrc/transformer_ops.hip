@@ -203,33 +203,48 @@ __global__ __launch_bounds__(64) void mha_core_kernel(const float* __restrict__ 
 // ---------------------------------------------------------------------------------------
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-__global__ __launch_bounds__(64) void mha_mfma_kernel(const float* __restrict__ qkv, float* __restrict__ out,
-                                                      int L, int E, int causal) {
+// NW = 1: one wave per workgroup, its own K / V tiles (short sequences: one query tile per head).
+// NW = 4: four query tiles of the same (head, image) share each K / V block in LDS; the next block's
+// global loads (8 float4 per thread) are issued before the current block's MFMAs and stored after
+// the barrier, so the fetch overlaps the compute (long sequences: ViT-L/14, L = 577).
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void mha_mfma_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+                                                           int L, int E, int causal) {
     __shared__ __attribute__((aligned(16))) float Ks[64 * 64];   // K block (first: the Q tile), swizzled chunks
     __shared__ __attribute__((aligned(16))) float Vs[64 * 64];   // V block, plain row-major
-    const int lane = threadIdx.x, h = blockIdx.y, b = blockIdx.z;
-    const int q0 = blockIdx.x * 64;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, h = blockIdx.y, b = blockIdx.z;
+    const int q0 = (blockIdx.x * NW + wv) * 64;       // may be >= L for the last waves of a row of tiles
     const int fr = lane & 31, fh = lane >> 5;
     const long long ld = 3LL * E;
     const float* base = qkv + (long long)b * L * ld + h * 64;
 
     // Q tile -> LDS (swizzled) -> B-operand fragments in registers, pre-scaled by head_dim^-0.5
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int idx = i * 64 + lane, r = idx >> 4, c4 = idx & 15;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (q0 + r < L) v = *(const f32x4*)(base + (long long)(q0 + r) * ld + c4 * 4);
-        *(f32x4*)(Ks + r * 64 + ((c4 ^ (r & 15)) << 2)) = v * 0.125f;
-    }
-    __syncthreads();
+    // (NW = 4: the waves take turns with the K buffer, two at a time via Ks and Vs)
     f32x4 qf[2][8];
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int turn = 0; turn < (NW + 1) / 2; ++turn) {
+        float* Qs = (wv & 1) ? Vs : Ks;
+        if ((wv >> 1) == turn) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int r = 32 * t + fr;
-            qf[t][j] = *(const f32x4*)(Ks + r * 64 + (((2 * j + fh) ^ (r & 15)) << 2));
+            for (int i = 0; i < 16; ++i) {
+                const int idx = i * 64 + lane, r = idx >> 4, c4 = idx & 15;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (q0 + r < L) v = *(const f32x4*)(base + (long long)(q0 + r) * ld + c4 * 4);
+                *(f32x4*)(Qs + r * 64 + ((c4 ^ (r & 15)) << 2)) = v * 0.125f;
+            }
         }
+        __syncthreads();
+        if ((wv >> 1) == turn) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int r = 32 * t + fr;
+                    qf[t][j] = *(const f32x4*)(Qs + r * 64 + (((2 * j + fh) ^ (r & 15)) << 2));
+                }
+        }
+        __syncthreads();
+    }
 
     f32x16 o[2][2];                       // O^T tiles [d tile][query tile]
 #pragma unroll
@@ -240,21 +255,33 @@ __global__ __launch_bounds__(64) void mha_mfma_kernel(const float* __restrict__ 
             for (int r = 0; r < 16; ++r) o[a][c][r] = 0.f;
     float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};   // per query tile; l is this half's partial sum
 
-    const int kend = causal ? min(L, q0 + 64) : L;   // keys beyond the tile's last query are masked
-    for (int k0 = 0; k0 < kend; k0 += 64) {
-        __syncthreads();                  // previous block's (or the Q tile's) LDS reads are done
+    // keys beyond the last query of the workgroup's last tile are masked for every wave
+    const int kend = causal ? min(L, (int)(blockIdx.x * NW + NW) * 64) : L;
+    constexpr int LPT = 16 / NW;          // float4 of K (and of V) per thread per block
+    f32x4 kpre[LPT], vpre[LPT];
+    auto fetch = [&](int k0) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int idx = i * 64 + lane, r = idx >> 4, c4 = idx & 15;
-            f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
-            if (k0 + r < L) {
-                kv = *(const f32x4*)(base + (long long)(k0 + r) * ld + E + c4 * 4);
-                vv = *(const f32x4*)(base + (long long)(k0 + r) * ld + 2 * E + c4 * 4);
+        for (int i = 0; i < LPT; ++i) {
+            const int idx = i * 64 * NW + (int)threadIdx.x, r = idx >> 4, c4 = idx & 15;
+            kpre[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; vpre[i] = kpre[i];
+            if (k0 + r < L && k0 < kend) {
+                kpre[i] = *(const f32x4*)(base + (long long)(k0 + r) * ld + E + c4 * 4);
+                vpre[i] = *(const f32x4*)(base + (long long)(k0 + r) * ld + 2 * E + c4 * 4);
             }
-            *(f32x4*)(Ks + r * 64 + ((c4 ^ (r & 15)) << 2)) = kv;
-            *(f32x4*)(Vs + r * 64 + c4 * 4) = vv;
+        }
+    };
+    if (NW > 1) fetch(0);
+    for (int k0 = 0; k0 < kend; k0 += 64) {
+        __syncthreads();                  // previous block's LDS reads are done
+        if (NW == 1) fetch(k0);           // one wave per workgroup: no registers to spare for a prefetch
+#pragma unroll
+        for (int i = 0; i < LPT; ++i) {
+            const int idx = i * 64 * NW + (int)threadIdx.x, r = idx >> 4, c4 = idx & 15;
+            *(f32x4*)(Ks + r * 64 + ((c4 ^ (r & 15)) << 2)) = kpre[i];
+            *(f32x4*)(Vs + r * 64 + c4 * 4) = vpre[i];
         }
         __syncthreads();
+        if (NW > 1) fetch(k0 + 64);       // in flight during this block's MFMAs
 
         // S^T = K Q^T
         f32x16 sT[2][2];                  // [key tile][query tile]
@@ -447,10 +474,14 @@ extern "C" int dbmm_mha_core(const float* qkv, float* out, int64_t B, int64_t L,
     // matrix-core kernel by default; DBMM_MHA_VALU=1 selects the lane-per-query VALU kernel (ablation)
     static const int valu = [] { const char* e = getenv("DBMM_MHA_VALU"); return e ? atoi(e) : 0; }();
     const dim3 grid((unsigned)((L + 63) / 64), (unsigned)heads, (unsigned)B);
+    const int qt = (int)((L + 63) / 64);
     if (valu)
         hipLaunchKernelGGL(mha_core_kernel, grid, dim3(64), 0, (hipStream_t)stream, qkv, out, (int)L, (int)E, causal);
+    else if (qt >= 4)      // long sequences: four query tiles share the K / V blocks
+        hipLaunchKernelGGL(mha_mfma_kernel<4>, dim3((unsigned)((qt + 3) / 4), (unsigned)heads, (unsigned)B), dim3(256), 0,
+                           (hipStream_t)stream, qkv, out, (int)L, (int)E, causal);
     else
-        hipLaunchKernelGGL(mha_mfma_kernel, grid, dim3(64), 0, (hipStream_t)stream, qkv, out, (int)L, (int)E, causal);
+        hipLaunchKernelGGL(mha_mfma_kernel<1>, grid, dim3(64), 0, (hipStream_t)stream, qkv, out, (int)L, (int)E, causal);
     DBMM_CHECK_LAUNCH();
     return DBMM_OK;
 }

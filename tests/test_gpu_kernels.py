@@ -168,7 +168,9 @@ def test_layernorm_strided_rows():
 
 
 @pytest.mark.parametrize("B,L,heads,causal", [(3, 50, 2, False), (2, 77, 8, True), (2, 130, 1, False),
-                                              (1, 130, 2, True), (2, 5, 1, False), (1, 577, 1, False)])
+                                              (1, 130, 2, True), (2, 5, 1, False), (1, 577, 1, False),
+                                              (2, 197, 3, False), (2, 300, 2, True), (1, 256, 1, False),
+                                              (1, 257, 2, True)])
 def test_mha_core(B, L, heads, causal):
     """matrix-core attention kernel (default) against torch softmax attention"""
     E = heads * 64
