@@ -204,7 +204,9 @@ class ModifiedResNet(nn.Module):
                     # conv3 + downsample branch as one dual-source GEMM: needs both weights as single exact
                     # fp16 planes and a non-zero bn3 scale (the accumulators are rescaled by scale_d / scale_3)
                     if (c3["sc"] is not None and ds["sc"] is not None and c3["ph"] is not None and ds["ph"] is not None
-                            and c3["ph"].shape[0] == 1 and ds["ph"].shape[0] == 1 and float(c3["sc"].abs().min()) > 0.0):
+                            and c3["ph"].shape[0] == 1 and ds["ph"].shape[0] == 1
+                            and float(c3["sc"].abs().min()) > 1e-20     # the rescale divides by bn3's scale ...
+                            and float(ds["sc"].abs().max()) < 1e12 * float(c3["sc"].abs().min())):   # ... and must stay finite
                         ratio = ds["sc"].double() / c3["sc"].double() * 2.0 ** (c3["we"] - ds["we"])
                         e["dual"] = dict(ratio=ratio.float().contiguous(), bias=(c3["b"].double() + ds["b"].double()).float())
                 blocks.append(e)
