@@ -108,3 +108,29 @@ def test_large_batch_property_rn50(models):
     assert relerr(big[17:19].cpu(), small.cpu()) < 1e-5
     again = model.encode_image(img)
     assert torch.equal(big, again)               # same shape -> same schedule -> bit-identical
+
+
+def test_rn_tower_wide_dynamic_range_and_unrounded_weights():
+    """hostile statistics for the fp16-pair path: BatchNorm scales spread over four decades,
+    activations with huge outlier channels, conv weights that are NOT fp16-representable in the
+    checkpoint (the reference rounds them on load, clip/model.py:433 -- so must we).  Batch 40 at
+    96 px gives every kernel family work (halo, pooled, dual-source, 1x1)."""
+    from dbmm_amd.clip.model import build_model, _as_loaded
+    arch, seed = "tiny-RN-w32", 21
+    sd = synth.clip_state_dict(seed, arch)
+    for i, k in enumerate(sorted(k for k in sd if k.startswith("visual.") and k.endswith(".weight") and ".bn" in k
+                                 or k.startswith("visual.bn") and k.endswith(".weight")
+                                 or "downsample.1.weight" in k)):
+        sd[k] = sd[k] * (50.0 if i % 3 == 0 else (0.02 if i % 3 == 1 else 1.0))
+    for k in list(sd):
+        if k.startswith("visual.") and ("conv" in k or "downsample.0" in k) and k.endswith(".weight"):
+            sd[k] = sd[k] * 1.0003                      # no longer exact in fp16
+    model = build_model({k: v.clone() for k, v in sd.items()}).cuda()
+    loaded = {k: _as_loaded(k, v) for k, v in sd.items()}          # what the reference's build_model would hold
+    img = synth.images(5, 40, 96)
+    img[:, 1] *= 30.0                                    # one colour plane dominates the stem
+    with torch.no_grad():
+        ref = CO.encode_image(loaded, img)
+    out = model.encode_image(img.cuda())
+    assert torch.isfinite(out).all()
+    assert relerr(out.cpu(), ref) < 5e-5
