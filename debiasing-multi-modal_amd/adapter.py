@@ -392,6 +392,24 @@ def balance_val_indices(group_array, n_groups, batch_size_reg):
     return balanced, (batch_size_reg if batch_size_reg <= len(balanced) else len(balanced))
 
 
+def stratified_split_indices(group_array, test_size=0.5):
+    """Index arrays of stratified_split_dataset (data/celeba_embeddings_reg.py:95-102): the
+    reference delegates to sklearn's train_test_split with random_state=42 stratified on the group
+    array, and so does this (same dependency, same RNG stream -> identical indices)."""
+    from sklearn.model_selection import train_test_split
+    group_array = np.asarray(group_array)
+    reg_idx, val_idx = train_test_split(np.arange(len(group_array)), test_size=test_size, random_state=42,
+                                        stratify=group_array)
+    return reg_idx, val_idx
+
+
+def stratified_split_dataset(dataset, test_size=0.5):
+    """data/celeba_embeddings_reg.py:95-107: two torch Subsets (reg, val) of a dataset that carries
+    `.group_array`."""
+    reg_idx, val_idx = stratified_split_indices(dataset.group_array, test_size)
+    return torch.utils.data.Subset(dataset, reg_idx), torch.utils.data.Subset(dataset, val_idx)
+
+
 def minority_flags(dataset, target, target_s, pred):
     """clip_inference.py:219-233."""
     if dataset == "waterbirds":

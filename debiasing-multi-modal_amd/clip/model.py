@@ -185,6 +185,14 @@ class ModifiedResNet(nn.Module):
         self._plan = None
         return super()._apply(fn, *a, **k)
 
+    def _load_from_state_dict(self, *a, **k):        # load_state_dict(): the folded / packed plan is stale
+        self._plan = None
+        return super()._load_from_state_dict(*a, **k)
+
+    def _param_key(self):
+        """changes whenever a parameter or buffer is replaced or edited in place (optimizer step, .copy_())"""
+        return tuple((t.data_ptr(), t._version) for t in list(self.parameters()) + list(self.buffers()))
+
     @torch.no_grad()
     def _compile(self):
         P = {}
@@ -219,10 +227,13 @@ class ModifiedResNet(nn.Module):
             bkv=torch.cat([ap.k_proj.bias, ap.v_proj.bias], 0).detach().float().contiguous(),
             wc=ap.c_proj.weight.detach().float().contiguous(), bc=ap.c_proj.bias.detach().float().contiguous())
         self._plan = P
+        self._plan_key = self._param_key()
         return P
 
     @torch.no_grad()
     def forward(self, x, return_stages=False):
+        if self._plan is not None and self._plan_key != self._param_key():
+            self._plan = None
         P = self._plan or self._compile()
         x = x.float().contiguous()                      # NCHW image at the boundary
         # One device scalar per conv output: its epilogue leaves max|y| there and the consumer
@@ -320,6 +331,10 @@ class Transformer(nn.Module):
         self._planes = None
         return super()._apply(fn, *a, **k)
 
+    def _weight_key(self):
+        return tuple((w.data_ptr(), w._version) for b in self.resblocks
+                     for w in (b.attn.in_proj_weight, b.attn.out_proj.weight, b.mlp.c_fc.weight, b.mlp.c_proj.weight))
+
     @torch.no_grad()
     def _split_planes(self):
         """pre-split planes of the four projection weights of every block for the split-precision
@@ -335,6 +350,7 @@ class Transformer(nn.Module):
             return {}
         self._planes = [tuple(one(w) for w in (b.attn.in_proj_weight, b.attn.out_proj.weight, b.mlp.c_fc.weight,
                                                 b.mlp.c_proj.weight)) for b in self.resblocks]
+        self._planes_key = self._weight_key()
         return self._planes
 
     @torch.no_grad()
@@ -345,7 +361,9 @@ class Transformer(nn.Module):
         GEMM epilogues; the attention core's output is a convex combination of V rows, so the
         qkv GEMM's scalar bounds it."""
         E = self.width
-        planes = getattr(self, "_planes", None) or self._split_planes()
+        planes = getattr(self, "_planes", None)
+        if planes is None or self._planes_key != self._weight_key():     # load_state_dict / in-place edits
+            planes = self._split_planes()
         amax = torch.zeros(4 * len(self.resblocks), device=x.device, dtype=torch.float32)
         f16 = CONV_SPLIT == "f16"
         for i, (blk, (p_in, p_out, p_fc, p_proj)) in enumerate(zip(self.resblocks, planes)):

@@ -81,8 +81,11 @@ def relerr(a, b):
 
 # ---------------------------------------------------------------------------------------
 
-def gen_clip(M):
-    cases = [("tiny-RN", 3, 2), ("tiny-RN-w32", 3, 2), ("RN50", 2, 2), ("tiny-ViT", 3, 2), ("ViT-B/32", 2, 2)]
+def gen_clip(M, only=None):
+    cases = [("tiny-RN", 3, 2), ("tiny-RN-w32", 3, 2), ("RN50", 2, 2), ("tiny-ViT", 3, 2), ("ViT-B/32", 2, 2),
+             ("ViT-L/14@336px", 2, 1)]          # full depth (24 layers, 577 tokens): BASELINE configs[4]'s tower
+    if only:
+        cases = [c for c in cases if c[0] in only]
     for arch, seed, B in cases:
         sd = synth.clip_state_dict(seed, arch)
         model = M.build_model({k: v.clone() for k, v in sd.items()}).float().eval()
@@ -158,10 +161,13 @@ def _write_text_json(path, mat, names):
         json.dump({n: mat[:, i].numpy().tolist() for i, n in enumerate(names)}, f)
 
 
-def gen_adapter(FM):
+def gen_adapter(FM, D=1024, Bs=(4, 256, 1024), fname="adapter.npz"):
+    """D = 1024 is the reference's hard-coded RN50 width (final_main.py:31,304); D = 512 / 768 are the
+    ViT-B/32 and ViT-L/14 widths BASELINE configs[3] / [4] need (D becomes a parameter),
+    run through the reference's own Adapter(D, 128) / CustomCLIP / MultipleAdapter classes."""
     from demo.util import set_optimizer, set_optimizer_reg  # reference's own helpers
     tmp = tempfile.mkdtemp(prefix="dbmm_golden_")
-    D, H = 1024, 128
+    H = 128
     tcls, tsp, tgrp = (synth.text_matrix(1, D, 2, "class"), synth.text_matrix(1, D, 2, "spurious"),
                        synth.text_matrix(1, D, 4, "group"))
     paths = [os.path.join(tmp, n) for n in ("clip_class.json", "clip_spurious.json", "clip_group.json")]
@@ -178,7 +184,7 @@ def gen_adapter(FM):
             else:
                 out[f"{tag}/{k}_sums"], out[f"{tag}/{k}_sample"] = summary(t)
 
-    for B in (4, 256, 1024):
+    for B in Bs:
         x = synth.normal(5, f"x{B}", (B, D), 0.5)
         y, c, g = synth.labels(6, B)
         # ---- stage 1: CustomCLIP, class prompt, 3 SGD steps in train mode -------------
@@ -257,14 +263,30 @@ def gen_adapter(FM):
                     ol, ologits, _ = AO.train_step(osd, obufs, x, labels, text, 0.05, multiple=True)
                     assert relerr(ologits, logits.detach()) < 2e-5, tag
                 record(tag + "/after3", dict(ma.state_dict()))
+                # conditioning of this trajectory: the REFERENCE itself re-run from the same start on an input
+                # perturbed by one ulp.  At T = 0.01 a few cases amplify 6e-8 to 6e-4 in three steps; no
+                # implementation can be held to less than that, so the tolerance is stored with the case.
+                with contextlib.redirect_stdout(io.StringIO()):
+                    new_ad2 = FM.Adapter(D, H); new_ad2.load_state_dict(synth.adapter_state_dict(4, D, H))
+                    ma2 = FM.MultipleAdapter(copy.deepcopy(stage1), new_ad2, init_near_identity=near_identity, ebd_weight=0.5)
+                optim2 = set_optimizer_reg(opt_ns, ma2); ma2.train()
+                xp = x * (1.0 + 2.0 ** -23)
+                for step in range(3):
+                    l2 = crit(ma2(xp.detach(), use_group), labels)
+                    optim2.zero_grad(); l2.backward(); optim2.step()
+                sens = max(relerr(ma2.state_dict()[k], v) for k, v in ma.state_dict().items() if v.dtype.is_floating_point)
+                tol = max(2e-5, 4 * sens)
+                out[f"{tag}/traj_tol"] = np.float64(tol)
+                if tol > 2e-5:
+                    print(f"[adapter] {tag}: ill-conditioned trajectory, 1-ulp sensitivity {sens:.2e} -> tol {tol:.2e}")
                 for k, v in ma.state_dict().items():
                     if v.dtype.is_floating_point:
-                        assert relerr(osd[k], v) < 2e-5, (tag, k)
+                        assert relerr(osd[k], v) < tol, (tag, k, relerr(osd[k], v))
                 ma.eval()
                 with torch.no_grad():
                     record(tag + "/eval", {"logits": ma(x), "logits_spurious": ma.forward_spurious(x)})
-        print(f"[adapter] B={B} done")
-    np.savez_compressed(os.path.join(GOLD, "adapter.npz"), **out)
+        print(f"[adapter] D={D} B={B} done")
+    np.savez_compressed(os.path.join(GOLD, fname), **out)
     return FM
 
 
@@ -307,6 +329,63 @@ def gen_indices(FM):
     print("[indices] done")
 
 
+def gen_split():
+    """stratified_split_dataset (data/celeba_embeddings_reg.py:95-107) of the reference on seeded
+    synthetic group arrays (sklearn train_test_split, random_state=42)."""
+    for n in ("torchvision", "torchvision.transforms"):
+        if n not in sys.modules:
+            sys.modules[n] = types.ModuleType(n)
+    sys.modules["torchvision"].transforms = sys.modules["torchvision.transforms"]
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    mod = _load_by_path("ref_celeba_embeddings_reg", os.path.join(REF, "data", "celeba_embeddings_reg.py"))
+    out = {}
+    for name, n, skew in (("a", 1000, 7), ("b", 19867, 11)):       # b: the size of CelebA's val split
+        garr = np.minimum(synth.integers(21, "split_" + name, (n,), skew).numpy(), 3)
+        for ts in (0.5, 0.25):
+            reg, val = mod.stratified_split_dataset(SimpleNamespace(group_array=garr), test_size=ts)
+            out[f"{name}_garr"] = garr
+            out[f"{name}_reg_{ts}"] = np.asarray(reg.indices, dtype=np.int64)
+            out[f"{name}_val_{ts}"] = np.asarray(val.indices, dtype=np.int64)
+    np.savez_compressed(os.path.join(GOLD, "split.npz"), **out)
+    print("[split] done")
+
+
+def gen_lr():
+    """LR schedule helpers of the reference (demo/util.py:70-115) on a grid of epochs / batches."""
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    from demo import util as U
+    base = dict(learning_rate=0.1, learning_rate_reg=1.0, lr_decay_rate=0.1, lr_decay_epochs=[30, 60, 90], epochs=100,
+                epochs_feature_learning=50, cosine=False, warm=True, warm_epochs=10, warmup_from=0.001, warmup_to=0.1,
+                warm_reg=True, warm_epochs_reg=2, warmup_from_reg=0.01, warmup_to_reg=1.0)
+    opt = torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=0.5)
+    lr = lambda: opt.param_groups[0]["lr"]
+    rows = []
+    for cosine in (False, True):
+        a = SimpleNamespace(**dict(base, cosine=cosine))
+        for epoch in (0, 1, 2, 10, 30, 31, 60, 61, 90, 91, 100):
+            U.adjust_learning_rate(a, opt, epoch)
+            rows.append(["adjust_learning_rate", cosine, epoch, 0, 0, lr()])
+            try:
+                U.adjust_learning_rate_reg(a, opt, epoch)
+                rows.append(["adjust_learning_rate_reg", cosine, epoch, 0, 0, lr()])
+            except AttributeError as e:
+                rows.append(["adjust_learning_rate_reg", cosine, epoch, 0, 0, "AttributeError"])
+    a = SimpleNamespace(**base)
+    for epoch in (1, 2, 3, 10, 11):
+        for batch_id in (0, 1, 7, 18):
+            opt.param_groups[0]["lr"] = 0.5
+            U.warmup_learning_rate(a, epoch, batch_id, 19, opt)
+            rows.append(["warmup_learning_rate", False, epoch, batch_id, 19, lr()])
+            opt.param_groups[0]["lr"] = 0.5
+            U.warmup_learning_rate_reg(a, epoch, batch_id, 19, opt)
+            rows.append(["warmup_learning_rate_reg", False, epoch, batch_id, 19, lr()])
+    with open(os.path.join(GOLD, "lr_schedule.json"), "w") as f:
+        json.dump({"args": base, "rows": rows}, f, indent=0)
+    print(f"[lr] {len(rows)} rows")
+
+
 def gen_checkpoint_contract():
     """state-dict key/shape contract of the shipped MultipleAdapter checkpoint (weights_only load)."""
     d = os.path.join(REF, "trained_model")
@@ -346,17 +425,26 @@ def gen_fp16_keys(M):
 
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ["clip", "tokens", "adapter", "indices", "ckpt", "fp16keys"]
+    which = sys.argv[1:] or ["clip", "tokens", "adapter", "adapter_vit", "indices", "ckpt", "fp16keys", "split", "lr"]
     if "fp16keys" in which:
         gen_fp16_keys(ref_model_module())
     if "clip" in which:
         gen_clip(ref_model_module())
+    if "clip_vitl" in which:                      # only the full-depth ViT-L/14@336px case (minutes on CPU)
+        gen_clip(ref_model_module(), only=("ViT-L/14@336px",))
+    if "split" in which:
+        gen_split()
+    if "lr" in which:
+        gen_lr()
     if "tokens" in which:
         gen_tokens()
-    if "adapter" in which or "indices" in which:
+    if "adapter" in which or "indices" in which or "adapter_vit" in which:
         FM = ref_final_main()
         if "adapter" in which:
             gen_adapter(FM)
+        if "adapter_vit" in which:                # BASELINE configs[3] / [4] adapter widths and global batches
+            gen_adapter(FM, D=512, Bs=(256, 4096), fname="adapter_D512.npz")
+            gen_adapter(FM, D=768, Bs=(256, 8192), fname="adapter_D768.npz")
         if "indices" in which:
             gen_indices(FM)
     if "ckpt" in which:
