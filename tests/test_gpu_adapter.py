@@ -17,9 +17,8 @@ pytestmark = pytest.mark.gpu
 D, H = 1024, 128
 
 
-@pytest.fixture(scope="module")
-def text_paths(tmp_path_factory):
-    d = tmp_path_factory.mktemp("text")
+def _text_paths(tmp_path_factory, D):
+    d = tmp_path_factory.mktemp(f"text{D}")
     mats = dict(clip_class=(synth.text_matrix(1, D, 2, "class"), ["c0", "c1"]),
                 clip_spurious=(synth.text_matrix(1, D, 2, "spurious"), ["s0", "s1"]),
                 clip_group=(synth.text_matrix(1, D, 4, "group"), ["g0", "g1", "g2", "g3"]))
@@ -29,6 +28,22 @@ def text_paths(tmp_path_factory):
         json.dump({n: m[:, i].numpy().tolist() for i, n in enumerate(cols)}, open(p, "w"))
         paths.append(p)
     return paths
+
+
+@pytest.fixture(scope="module")
+def text_paths(tmp_path_factory):
+    return _text_paths(tmp_path_factory, 1024)
+
+
+@pytest.fixture(scope="module")
+def text_paths_by_dim(tmp_path_factory):
+    cache = {}
+
+    def get(D):
+        if D not in cache:
+            cache[D] = _text_paths(tmp_path_factory, D)
+        return cache[D]
+    return get
 
 
 def _check(g, tag, name, t, tol=1e-4):
@@ -48,10 +63,17 @@ def _ns(**k):
     return SimpleNamespace(learning_rate=0.1, learning_rate_reg=0.05, momentum=0.9, weight_decay=5e-5, **k)
 
 
-@pytest.mark.parametrize("B", [4, 256, 1024])
+# (D, B): 1024 = RN50 (the reference's hard-coded width, final_main.py:31,304); 512 / 4096 = ViT-B/32 at BASELINE
+# configs[3]'s global batch; 768 / 8192 = ViT-L/14 at configs[4]'s.  All fixtures come from the reference's own
+# Adapter(D, 128) / CustomCLIP / MultipleAdapter classes (oracle/make_golden.py).
+CASES = [(1024, 4), (1024, 256), (1024, 1024), (512, 256), (512, 4096), (768, 256), (768, 8192)]
+
+
+@pytest.mark.parametrize("D,B", CASES)
 @pytest.mark.parametrize("fused", [False, True])
-def test_custom_clip_and_multiple_adapter(B, fused, golden, text_paths):
-    g = golden("adapter.npz")
+def test_custom_clip_and_multiple_adapter(D, B, fused, golden, text_paths_by_dim):
+    g = golden("adapter.npz" if D == 1024 else f"adapter_D{D}.npz")
+    text_paths = text_paths_by_dim(D)
     x = synth.normal(5, f"x{B}", (B, D), 0.5).cuda()
     y, c, grp = (t.cuda() for t in synth.labels(6, B))
     crit = torch.nn.CrossEntropyLoss()
@@ -121,12 +143,15 @@ def test_custom_clip_and_multiple_adapter(B, fused, golden, text_paths):
                         else:
                             _check(g, tag + "/step0/grad", n, p.grad, 3e-4)
                 opt.step()
+            # ill-conditioned trajectories carry the reference's own 1-ulp input sensitivity (x 4) as tolerance
+            ttol = float(g[tag + "/traj_tol"]) if tag + "/traj_tol" in g.files else 0.0
             for k, v in ma.state_dict().items():
                 if v.dtype.is_floating_point:
-                    _check(g, tag + "/after3", k, v, 3e-4)
+                    _check(g, tag + "/after3", k, v, max(3e-4, 10 * ttol))
             ma.eval()
             with torch.no_grad():
-                assert (ma(x).cpu() - torch.from_numpy(g[tag + "/eval/logits"])).abs().max() < 3e-3
+                etol = 3e-3 if ttol <= 2e-5 else 3e-3 * ttol / 2e-5
+                assert (ma(x).cpu() - torch.from_numpy(g[tag + "/eval/logits"])).abs().max() < etol
 
 
 def test_per_group_loss_and_flags(text_paths):

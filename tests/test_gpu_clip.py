@@ -11,7 +11,7 @@ from dbmm_amd import adapter, synth
 from dbmm_amd.clip.model import build_model
 
 pytestmark = pytest.mark.gpu
-ARCHS = ["tiny-RN", "tiny-RN-w32", "tiny-ViT", "RN50", "ViT-B/32"]
+ARCHS = ["tiny-RN", "tiny-RN-w32", "tiny-ViT", "RN50", "ViT-B/32", "ViT-L/14@336px"]   # last: full depth, B = 1 (BASELINE configs[4])
 
 
 def gname(arch):

@@ -12,7 +12,7 @@ import clip_oracle as CO
 from conftest import GOLDEN, relerr, summary
 from dbmm_amd import synth
 
-ARCHS = ["tiny-RN", "tiny-RN-w32", "tiny-ViT", "RN50", "ViT-B/32"]
+ARCHS = ["tiny-RN", "tiny-RN-w32", "tiny-ViT", "RN50", "ViT-B/32", "ViT-L/14@336px"]   # last: full depth, B = 1 (BASELINE configs[4])
 
 
 def gname(arch):
@@ -44,31 +44,30 @@ def test_encode_image_and_text(arch, golden):
         assert (pred.numpy() == g["zs_pred"]).all()
 
 
-def _text_mats():
-    D = 1024
+def _text_mats(D=1024):
     return (synth.text_matrix(1, D, 2, "class"), synth.text_matrix(1, D, 2, "spurious"),
             synth.text_matrix(1, D, 4, "group"))
 
 
-@pytest.mark.parametrize("B", [4, 256, 1024])
-def test_adapter_steps(B, golden):
-    g = golden("adapter.npz")
-    D, H = 1024, 128
-    tcls, tsp, tgrp = _text_mats()
+@pytest.mark.parametrize("D,B", [(1024, 4), (1024, 256), (1024, 1024), (512, 256), (512, 4096), (768, 256), (768, 8192)])
+def test_adapter_steps(D, B, golden):
+    g = golden("adapter.npz" if D == 1024 else f"adapter_D{D}.npz")
+    H = 128
+    tcls, tsp, tgrp = _text_mats(D)
     x = synth.normal(5, f"x{B}", (B, D), 0.5)
     y, c, grp = synth.labels(6, B)
 
-    def check(tag, name, t):
+    def check(tag, name, t, tol=3e-5):
         if tag.endswith("/grad") and name.endswith("layers.0.bias"):
             # the bias in front of a train-mode BatchNorm has an analytically zero gradient:
             # both sides hold rounding noise only
             assert t.abs().max() < 1e-6 and np.abs(g[f"{tag}/{name}"]).max() < 1e-6
         elif f"{tag}/{name}" in g.files:
-            assert relerr(t, g[f"{tag}/{name}"]) < 3e-5, (tag, name)
+            assert relerr(t, g[f"{tag}/{name}"]) < tol, (tag, name)
         else:
             sums, sample = summary(t)
             ref = g[f"{tag}/{name}_sample"]
-            assert np.abs(sample - ref).max() <= 3e-5 * max(np.abs(ref).max(), 1e-6), (tag, name)
+            assert np.abs(sample - ref).max() <= tol * max(np.abs(ref).max(), 1e-6), (tag, name)
 
     stage1 = None
     for use_group in (False, True):
@@ -108,10 +107,12 @@ def test_adapter_steps(B, golden):
                     check(tag + "/step0", "logits", logits)
                     for k, v in grads.items():
                         check(tag + "/step0/grad", k, v)
+            # an ill-conditioned trajectory carries the reference's own 1-ulp input sensitivity (x 4) as its tolerance
+            ttol = max(3e-5, float(g[tag + "/traj_tol"])) if tag + "/traj_tol" in g.files else 3e-5
             for k, v in sd.items():
                 if v.dtype.is_floating_point:
-                    check(tag + "/after3", k, v)
-            check(tag + "/eval", "logits", AO.multiple_adapter_logits(sd, x, tcls, 0.01, train=False))
+                    check(tag + "/after3", k, v, ttol)
+            check(tag + "/eval", "logits", AO.multiple_adapter_logits(sd, x, tcls, 0.01, train=False), 100 * ttol if ttol > 3e-5 else 3e-5)
 
 
 def test_indices(golden):
