@@ -1,28 +1,30 @@
 #!/usr/bin/env python3
 """images/sec of one "embed + adapter step" (BASELINE.json metric) on N MI355X of one node.
 
-Roofline note: the dense contractions run on the split-precision kernel (each fp32 value = three
-bf16 values, six bf16 MFMA partial products per fp32 product, fp32-level accuracy).  Its MFMA
-roofline in ALGORITHMIC FLOP/s is the dense bf16 peak / 6 = 416.7 TFLOP/s; `achieved` and
-`frac` are quoted against that, and `achieved_over_fp32_mfma_peak` against the 157.3 TFLOP/s an
-fp32-input MFMA kernel could reach at most.
-
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-A step = CLIP-RN50 encode_image on this rank's B_l = 512 synthetic 224x224x3 images (resident
-in HBM) -> RCCL all-gather of embeddings + labels -> replicated adapter forward + CE +
-backward + SGD on the global batch (B = 512 x N: BASELINE.json configs[1] at N = 1,
-configs[2] = the bs-1024 CelebA case at N = 2).  Weak scaling.  fp32 end to end (fp32-input
-MFMA) -- the precision the 1e-3 logit parity against the reference's CPU path is defined in.
+A step = CLIP-RN50 encode_image on this rank's B_l synthetic 224x224x3 images (resident in HBM) ->
+RCCL all-gather of embeddings + labels -> replicated adapter forward + CE + backward + SGD on the
+global batch.  N = 1: B = 1024, the configuration BASELINE.json's metric is quoted on ("CLIP-RN50 224px
+bs=1024").  N >= 2: 512 images per GPU (N = 2 is BASELINE configs[2], the bs-1024 DP=2 case), weak scaling.
+
+Arithmetic ("dtype": "f32"): activations and accumulators are fp32 in HBM / registers; each product runs
+on the 16-bit matrix cores as fp16 hi + lo pair (22-bit mantissa, exact power-of-two scale per tensor) x
+the checkpoint's fp16-exact weight, fp32 accumulate -- error vs fp64 equal to an fp32-input-MFMA kernel's
+(DESIGN.md section 4).  The line also carries `fp32_input_mfma`: the same step with every product on
+v_mfma_f32_32x32x2_f32 (DBMM_CONV_SPLIT=off), measured in the same process.
 
 Besides the contract line, rank 0 reports
-  roofline      the dominant kernel (3x3 implicit-GEMM conv on the 128x128 tile), HIP events
-                around every launch of it inside the timed region; algorithmic FLOPs
-                (2*M*N*K per launch) / mean launch time vs the 157.3 TFLOP/s fp32 MFMA peak
-  cpu_baseline  the oracle (torch-CPU restatement, proved == reference) on the host cores,
-                bounded sample, N = 1 only
+  roofline      every igemm launch of the timed region is bracketed by HIP events on its stream; kernels are
+                grouped by instantiation (the names rocprofv3 prints) and ranked by MEASURED time share.  The
+                top kernel is reported against its own binding roof: `bound` = whichever of algorithmic
+                FLOPs / MFMA peak and algorithmic bytes / 8 TB/s is the larger time; `kernels` holds the same
+                for the top five.  `traffic` / `mfma_busy` / `hbm_tbps` come from the committed rocprofv3 PMC
+                passes of this command (profiles/r02_pmc.json), when they match this configuration.
+  cpu_baseline  the oracle (torch-CPU restatement, proved == reference) on the host cores, bounded sample,
+                N = 1 only
 """
 import argparse
 import json
@@ -47,14 +49,54 @@ F16_MFMA_PEAK_TFLOPS = 2500.0          # dense fp16 MFMA, same table (same rate 
 SPLIT_PRODUCTS = {(2, 1): 2, (2, 2): 3, (3, 3): 6}
 # algorithmic GFLOP per image, SURVEY.md section 8d (RN50: conv 5.367 + attn-pool 0.426 GMAC)
 GFLOP_PER_IMG = {"RN50": 11.59, "ViT-B/32": 8.82, "ViT-L/14@336px": 381.9}
-# dominant kernel: 3x3 implicit-GEMM conv, 128x128 tile, one tile per workgroup
-# (template arguments <BM, BN, WAVES_M, WAVES_N, AMODE=1 (conv), MINB, SK=0, NP, NW, BK, TWO=0>; NP / NW = 16-bit
-#  planes of the activations / weights: 2, 1 = fp16 pair x exact fp16 weight; 2, 2 = fp16 pair x pair; 3, 3 = bf16 triple)
-DOMINANT_SPLIT = ("igemm_x3_kernel<128, 128, 2, 2, 1, 3, 0, 2, 1, 32, 0>",  # default path (the three pooled 3x3 convs)
-                  "igemm_x3_kernel<128, 128, 2, 2, 1, 2, 0, 2, 2, 32, 0>",  # weights not exact in fp16
-                  "igemm_x3_kernel<128, 128, 2, 2, 1, 2, 0, 2, 2, 16, 0>",  # DBMM_IGEMM_X2_BK=16
-                  "igemm_x3_kernel<128, 128, 2, 2, 1, 2, 0, 3, 3, 16, 0>")  # DBMM_CONV_SPLIT=bf16
-DOMINANT_F32 = "igemm_f32_kernel<128, 128, 2, 2, 1, 0, 16, 4, 1, 0, 1>"    # fp32-MFMA path (DBMM_CONV_SPLIT=off)
+HBM_PEAK_GBS = 8000.0                  # HBM3E spec, same table (measured copy ceiling there: 6290 GB/s)
+
+
+def kernel_products(tag):
+    """16-bit partial products per fp32 product of an igemm instantiation name (1 = fp32-input MFMA)."""
+    if tag.startswith("igemm_halo_kernel<") or tag.startswith("bottleneck_fused_kernel<"):
+        return 2                                                  # fp16 pair x one exact weight plane
+    if tag.startswith("igemm_x3_kernel<"):
+        a = [v.strip() for v in tag[tag.index("<") + 1:tag.rindex(">")].split(",")]
+        return SPLIT_PRODUCTS.get((int(a[7]), int(a[8])), 2)     # <BM, BN, WM, WN, AMODE, MINB, SK, NP, NW, BK, TWO>
+    return 1
+
+
+def kernel_rows(prof, steps, step_ms, pmc):
+    """one roofline record per kernel instantiation, ranked by measured time: each against the roof that binds it"""
+    rows = []
+    for tag, (n, fl, ms, by) in prof.items():
+        if ms <= 0:
+            continue
+        nprod = kernel_products(tag)
+        mfma_peak = F16_MFMA_PEAK_TFLOPS / nprod if nprod > 1 else FP32_MFMA_PEAK_TFLOPS
+        tf, gbs = fl / (ms * 1e-3) / 1e12, by / (ms * 1e-3) / 1e9
+        t_mfma, t_hbm = fl / (mfma_peak * 1e12), by / (HBM_PEAK_GBS * 1e9)
+        hbm = t_hbm >= t_mfma
+        row = {"kernel": tag, "share_of_step": round(ms / steps / step_ms, 4), "launches_per_step": round(n / steps, 2),
+               "ms_per_step": round(ms / steps, 4), "avg_launch_ms": round(ms / n, 4),
+               "bound": "hbm" if hbm else "mfma",
+               "achieved": round(gbs if hbm else tf, 2), "peak": HBM_PEAK_GBS if hbm else round(mfma_peak, 1),
+               "unit": "GB/s" if hbm else "TFLOP/s", "frac": round((gbs / HBM_PEAK_GBS) if hbm else (tf / mfma_peak), 4),
+               "algorithmic_tflops": round(tf, 2), "algorithmic_gbs": round(gbs, 1),
+               "frac_of_mfma_roof": round(tf / mfma_peak, 4), "frac_of_hbm_roof": round(gbs / HBM_PEAK_GBS, 4),
+               "flops_per_launch": fl / n, "bytes_per_launch": by / n,
+               "partial_products_per_fp32_product": nprod, "traffic": None, "traffic_over_algorithmic": None,
+               "mfma_busy": None, "hbm_tbps": None}
+        k = (pmc or {}).get("kernels", {}).get(tag)
+        if k:                                            # committed rocprofv3 --pmc passes of this very command
+            if k.get("hbm_bytes_per_launch"):
+                row["traffic"] = round(k["hbm_bytes_per_launch"])
+                row["traffic_over_algorithmic"] = round(k["hbm_bytes_per_launch"] / (by / n), 3)
+                if k.get("avg_launch_ms"):
+                    row["hbm_tbps"] = round(k["hbm_bytes_per_launch"] / (k["avg_launch_ms"] * 1e-3) / 1e12, 3)
+            row["mfma_busy"] = k.get("mfma_busy")
+            for extra in ("waves_per_simd", "lds_bank_conflict"):
+                if extra in k:
+                    row[extra] = k[extra]
+        rows.append(row)
+    rows.sort(key=lambda r: -r["ms_per_step"])
+    return rows
 
 
 def write_text_jsons(D):
@@ -109,14 +151,28 @@ def cpu_baseline(sd, D, paths_unused, bs=32, iters=3):
             "sample": f"oracle (torch-CPU fp32) RN50 encode_image + adapter step, bs={bs}, median of {iters}"}
 
 
+def build_step(arch, dev, world, rank, Bl, D_hidden=128):
+    sd = synth.clip_state_dict(2, arch)
+    model = build_model(sd).to(dev)
+    D, R = model.visual.output_dim, model.visual.input_resolution
+    paths = write_text_jsons(D)
+    ad = adapter.Adapter(D, D_hidden); ad.load_state_dict(synth.adapter_state_dict(3, D, D_hidden))
+    clf = adapter.CustomCLIP(ad, *paths, temperature=0.01).to(dev).train()
+    from types import SimpleNamespace
+    opt = optim.set_optimizer(SimpleNamespace(learning_rate=0.1, momentum=0.9, weight_decay=5e-5), clf)
+    return sd, model, D, R, paths, dp.EmbedAdapterStep(model.encode_image, clf, opt)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch-per-gpu", type=int, default=512)
+    ap.add_argument("--batch-per-gpu", type=int, default=0,
+                    help="default: 1024 at one GPU (the metric's bs=1024), 512 per GPU otherwise (BASELINE configs[2])")
     ap.add_argument("--arch", default="RN50")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fp32-mfma-leg", action="store_true")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -135,11 +191,10 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
-    Bl = args.batch_per_gpu
+    default_bl = {"RN50": 1024 if world == 1 else 512, "ViT-B/32": 512, "ViT-L/14@336px": 128}
+    Bl = args.batch_per_gpu or default_bl.get(args.arch, 512)
     B = Bl * world
-    sd = synth.clip_state_dict(2, args.arch)
-    model = build_model(sd).to(dev)
-    D, R = model.visual.output_dim, model.visual.input_resolution
+    sd, model, D, R, paths, stepper = build_step(args.arch, dev, world, rank, Bl)
     # this rank's shard of the global synthetic batch (rows [rank*Bl, (rank+1)*Bl))
     base = synth.images(1000 + rank, min(Bl, 64), R)
     reps = (Bl + base.shape[0] - 1) // base.shape[0]
@@ -148,13 +203,6 @@ def main():
     y, c, g = synth.labels(6, B)
     lo, hi = dp.shard_rows(B, world, rank)
     y_l, g_l = y[lo:hi].to(dev), g[lo:hi].to(dev)
-
-    paths = write_text_jsons(D)
-    ad = adapter.Adapter(D, 128); ad.load_state_dict(synth.adapter_state_dict(3, D, 128))
-    clf = adapter.CustomCLIP(ad, *paths, temperature=0.01).to(dev).train()
-    from types import SimpleNamespace
-    opt = optim.set_optimizer(SimpleNamespace(learning_rate=0.1, momentum=0.9, weight_decay=5e-5), clf)
-    stepper = dp.EmbedAdapterStep(model.encode_image, clf, opt)
 
     def barrier():
         if world > 1:
@@ -167,16 +215,17 @@ def main():
     for _ in range(args.warmup):
         stepper.step(images, y_l, g_l)
     barrier()
-    # RN towers: time only the KxK conv launches (the dominant kernel lives there); DBMM_BENCH_PROFILE_ALL=1
-    # or a transformer tower: every MFMA launch
-    conv_only = args.arch.startswith("RN") and os.environ.get("DBMM_BENCH_PROFILE_ALL") != "1"
-    ops.profile_begin(conv_only=conv_only)
+    # every igemm launch of the timed region is bracketed by HIP events (an event pair is ~4 us of stream time:
+    # ~70 launches per RN50 step = 0.3 ms of a ~38 ms step); DBMM_BENCH_PROFILE=0 times none
+    profiling = os.environ.get("DBMM_BENCH_PROFILE", "1") != "0"
+    if profiling:
+        ops.profile_begin(conv_only=False)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss, logits, emb = stepper.step(images, y_l, g_l)
     barrier()
     dt = time.perf_counter() - t0
-    prof = ops.profile_end()
+    prof = ops.profile_end() if profiling else {}
 
     tmax = torch.tensor([dt], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
     if world > 1:
@@ -187,52 +236,77 @@ def main():
 
     if rank == 0:
         value = B * args.steps / dt
-        DOMINANT = next((k for k in DOMINANT_SPLIT + (DOMINANT_F32,) if k in prof), None)
-        if DOMINANT is None:     # other towers (ViT): the MFMA kernel instantiation with the most time
-            DOMINANT = max(prof, key=lambda k: prof[k][2]) if prof else DOMINANT_F32
-        split = DOMINANT.startswith("igemm_x3_kernel<")
-        n_prod = SPLIT_PRODUCTS.get(tuple(int(v) for v in DOMINANT.rstrip(">").split(",")[-4:-2]), 2) if split else 1
-        peak = F16_MFMA_PEAK_TFLOPS / n_prod if split else FP32_MFMA_PEAK_TFLOPS
-        n, fl, ms = prof.get(DOMINANT, (0, 0.0, 0.0))
-        ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-        traffic = None          # HBM-side bytes per launch of the dominant kernel from the committed PMC passes
+        step_ms = dt / args.steps * 1e3
+        pmc = None
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-            if Bl == 512 and args.arch == "RN50":
-                traffic = round(tj["kernels"][DOMINANT]["hbm_bytes_per_launch"])
-        except (OSError, KeyError, ValueError):
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc.json")))
+            if pmc.get("arch") != args.arch or pmc.get("batch_per_gpu") != Bl:
+                pmc = None
+        except (OSError, ValueError):
             pass
-        all_fl = sum(v[1] for v in prof.values()); all_ms = sum(v[2] for v in prof.values())
+        rows = kernel_rows(prof, args.steps, step_ms, pmc)
+        top = rows[0] if rows else {"kernel": None, "bound": "hbm", "achieved": 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                    "frac": 0.0, "traffic": None}
+        all_fl = sum(v[1] for v in prof.values()); all_ms = sum(v[2] for v in prof.values()); all_by = sum(v[3] for v in prof.values())
+        roof = {k: top.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "share_of_step",
+                                        "launches_per_step", "avg_launch_ms", "flops_per_launch", "bytes_per_launch",
+                                        "frac_of_mfma_roof", "frac_of_hbm_roof", "traffic_over_algorithmic", "mfma_busy",
+                                        "hbm_tbps")}
+        roof["how"] = ("kernel = largest measured time share among all igemm launches (HIP events on the launch stream inside "
+                       "the timed region); achieved = algorithmic bytes (operands read once, outputs written once) or "
+                       "2*M*N*K FLOPs / measured time; bound = the larger of bytes/8 TB/s and FLOPs/(2500 TF / partial "
+                       "products per fp32 product)")
+        roof["kernels"] = rows[:5]
+        roof["timed_igemm_launches"] = {"ms_per_step": round(all_ms / args.steps, 3), "share_of_step": round(all_ms / (dt * 1e3), 4),
+                                        "algorithmic_tflops": round(all_fl / (all_ms * 1e-3) / 1e12, 2) if all_ms else 0.0,
+                                        "algorithmic_gbs": round(all_by / (all_ms * 1e-3) / 1e9, 1) if all_ms else 0.0}
+        roof["end_to_end_over_fp32_mfma_peak"] = round(
+            value / world * GFLOP_PER_IMG.get(args.arch, float("nan")) * 1e9 / (FP32_MFMA_PEAK_TFLOPS * 1e12), 4)
+        cfgs = {("RN50", 1, 1024): "the metric's configuration, CLIP-RN50 224px bs=1024 on one GPU",
+                ("RN50", 1, 512): "BASELINE configs[1]", ("RN50", 2, 512): "BASELINE configs[2]"}
         line = {
-            "metric": f"images/sec (embed+adapter step), CLIP-{args.arch} {R}px", "value": round(value, 2),
+            "metric": f"images/sec (embed+adapter step), CLIP-{args.arch} {R}px bs={B}", "value": round(value, 2),
             "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"CLIP-{args.arch} {R}px encode_image + adapter(1024-128-1024) CE step, "
-                                   f"{Bl} images/GPU (BASELINE configs[1]; configs[2] at 2 GPUs)",
+            "ms_per_step": round(step_ms, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32",
+            "dtype_detail": "fp32 activations/accumulators; products on 16-bit MFMA as fp16 hi+lo pair (22-bit mantissa, "
+                            "exact per-tensor power-of-two scale) x fp16-exact checkpoint weight; parity suite at 1e-3 logits",
+            "data": "synthetic",
+            "config": {"workload": f"CLIP-{args.arch} {R}px encode_image + adapter({D}-128-{D}) CE/SGD step, {Bl} images/GPU, "
+                                   f"global batch {B}" + (f" ({cfgs[(args.arch, world, Bl)]})" if (args.arch, world, Bl) in cfgs else ""),
                        "global_batch": B, "batch_per_gpu": Bl, "parallelism": f"dp{world}",
                        "collective": "all_gather(embeddings+labels) per step" if world > 1 else "none"},
-            "roofline": {"bound": "mfma", "kernel": DOMINANT, "achieved": round(ach, 2),
-                         "peak": round(peak, 1), "unit": "TFLOP/s",
-                         "frac": round(ach / peak, 4), "traffic": traffic,
-                         "peak_basis": (f"dense 16-bit MFMA 2500 TFLOP/s / {n_prod} partial products per fp32 product"
-                                        if split else "fp32-input MFMA 157.3 TFLOP/s"),
-                         "executed_mfma_tflops": round(ach * n_prod, 1),
-                         "achieved_over_fp32_mfma_peak": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
-                         "launches": n, "avg_launch_ms": round(ms / n, 4) if n else None,
-                         "flops_per_launch_avg": fl / n if n else None,
-                         "timed_scope": "KxK conv launches" if conv_only else "all MFMA launches",
-                         "timed_mfma_kernels": {"achieved": round(all_fl / (all_ms * 1e-3) / 1e12, 2) if all_ms else 0.0,
-                                              "ms_per_step": round(all_ms / args.steps, 3),
-                                              "share_of_step": round(all_ms / (dt * 1e3), 4)},
-                         "end_to_end_over_fp32_mfma_peak": round(value / world * GFLOP_PER_IMG.get(args.arch, float("nan")) * 1e9 / (FP32_MFMA_PEAK_TFLOPS * 1e12), 4)},
+            "roofline": roof,
         }
+        if world == 1 and not args.no_fp32_mfma_leg and args.arch.startswith("RN"):
+            line["fp32_input_mfma"] = fp32_mfma_leg(args.arch, dev, Bl, images, y_l, g_l)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(sd, D, paths)
         print(json.dumps(line), flush=True)
     if world > 1:
         barrier()
         dist.destroy_process_group()
+
+
+def fp32_mfma_leg(arch, dev, Bl, images, y_l, g_l, steps=2):
+    """the same step with every product on the fp32-input MFMA (v_mfma_f32_32x32x2_f32): what "f32" would cost
+    without the fp16-pair split -- printed beside the headline so the label cannot be misread"""
+    from dbmm_amd.clip import model as M
+    saved = M.CONV_SPLIT
+    M.CONV_SPLIT = "off"
+    try:
+        _, _, _, _, _, stepper = build_step(arch, dev, 1, 0, Bl)
+        stepper.step(images, y_l, g_l)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            stepper.step(images, y_l, g_l)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    finally:
+        M.CONV_SPLIT = saved
+    return {"value": round(Bl * steps / dt, 2), "unit": "images/sec", "steps": steps,
+            "note": "DBMM_CONV_SPLIT=off: fp32-input MFMA for every product, same process, same batch"}
 
 
 if __name__ == "__main__":

@@ -62,7 +62,10 @@ struct IgemmP {
     float alpha;
     int tiles_n, n_tiles;
     long long sa, sw, sbias, sres, sc;  // per-batch element strides (grid.y = batch index)
-    unsigned a_bytes, w_bytes;          // FAST loader: buffer extents (< 2 GiB)
+    unsigned a_bytes, w_bytes;          // FAST loader: eligibility (0 = not eligible) / W buffer extent (< 2 GiB)
+    long long a_total, a2_total;        // bytes of the A operands.  They may exceed 2 GiB (RN50 layer 1 from B = 668):
+                                        // every tile builds its buffer descriptor on a 64-bit base of its own (a_desc)
+                                        // so the 32-bit offsets only ever span one tile's rows
     int sk_blocks;                      // stream-K: resident grid size (0 = one tile per block)
     float* sk_ws;                       // stream-K: [sk_blocks][2][BM*BN] partial accumulators
     // second operand pair of the fused "conv3 + downsample branch" GEMM (TWO = 1): its K2 / 32 chunks
@@ -108,6 +111,16 @@ __device__ __forceinline__ float igemm_acc_scale(const IgemmP& p) {
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr unsigned OOR = 0x80000000u;   // >= any accepted extent, and OOR + (K offset) cannot wrap
+constexpr long long EXT_LIM = 0x7FFFFFF0LL;
+
+// Buffer descriptor of an A operand rebased to `shift` bytes (16-B aligned, wave-uniform) past its start: extent =
+// what is left of the tensor, capped below 2 GiB.  Offsets are then relative to the tile's first row / image, a few
+// MB at most, while the tensor itself may be any size.  zero = the zero-extent twin (loads return 0).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t a_desc(const float* base, long long total, long long shift, bool zero = false) {
+    long long ext = total - shift;
+    ext = ext < 0 ? 0 : (ext > EXT_LIM ? EXT_LIM : ext);
+    return __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)base + shift), 0, zero ? 0 : (int)ext, 0x00020000);
+}
 
 __device__ __forceinline__ f32x4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
@@ -213,7 +226,11 @@ __device__ __forceinline__ void igemm_tile(const IgemmP& p, float* lds, int tile
     int f_ci0 = 0, f_kh = 0, f_kw = 0, f_tap = 0;     // conv: wave-uniform position along K
     if constexpr (FAST) {
         static_assert(!FAST || (AMODE != 2 && WMODE == 0), "FAST loader: K-contiguous operands only");
-        rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.a, 0, (int)p.a_bytes, 0x00020000);
+        // A descriptor rebased to the tile: row m0 (row-major) / the image of row m0 (conv gather)
+        int fn0 = 0;
+        if constexpr (AMODE == 1) fn0 = m0 / (p.Ho * p.Wo);
+        const long long a_shift = AMODE == 0 ? (long long)m0 * p.lda * 4 : (long long)fn0 * p.H * p.W * p.Cin * 4;
+        rsA = a_desc(p.a, p.a_total, a_shift);
         rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)p.w_bytes, 0x00020000);
 #pragma unroll
         for (int i = 0; i < WLD; ++i) {
@@ -227,16 +244,16 @@ __device__ __forceinline__ void igemm_tile(const IgemmP& p, float* lds, int tile
             const bool rv = (lr + RPP * i < BM) && (m < p.M);
             const unsigned ca = DMA ? (unsigned)(lc ^ lds_swz<BK>(lr + RPP * i)) : (unsigned)lc;   // source chunk
             if constexpr (AMODE == 0) {
-                fa_off[i] = rv ? (unsigned)m * (unsigned)p.lda * 4u + ca * 16u : OOR;
+                fa_off[i] = rv ? (unsigned)(m - m0) * (unsigned)p.lda * 4u + ca * 16u : OOR;
                 fa_mask[i] = 0;
             } else {
                 const int hw = p.Ho * p.Wo;
                 const int n = m / hw, rem = m - n * hw;
                 const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
                 const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
-                // modular 32-bit arithmetic: the halo start may lie "before" the tensor, the tap
+                // modular 32-bit arithmetic: the halo start may lie "before" the tile's first image, the tap
                 // offset added per load brings every valid tap back into range
-                fa_off[i] = ((unsigned)(n * p.H + hi0) * (unsigned)p.W + (unsigned)wi0) * (unsigned)p.Cin * 4u + ca * 16u;
+                fa_off[i] = ((unsigned)((n - fn0) * p.H + hi0) * (unsigned)p.W + (unsigned)wi0) * (unsigned)p.Cin * 4u + ca * 16u;
                 unsigned msk = 0;
                 for (int kh = 0; kh < p.KH; ++kh)
                     for (int kw = 0; kw < p.KW; ++kw)
@@ -585,14 +602,20 @@ __device__ __forceinline__ void igemm_tile_x3(const IgemmP& p, float* lds, int t
 
     unsigned fa_off[ALD], fa_mask[ALD], fw_off[WLD];
     int f_ci0 = 0, f_kh = 0, f_kw = 0, f_tap = 0;
-    __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.a, 0, (int)p.a_bytes, 0x00020000);
+    // A descriptor rebased to the tile (see a_desc): row-major -> the tile's first row (pool2: the first window's
+    // corner pixel, window corners grow with the pooled index); conv gather -> the image of the tile's first row
+    int fr0 = 0, fn0 = 0;
+    if constexpr (AMODE == 0) fr0 = p.pool2 ? pool2_base_pixel(p, m0 >> 2) : m0;
+    else fn0 = p.pool2 ? (m0 >> 2) / ((p.Ho >> 1) * (p.Wo >> 1)) : m0 / (p.Ho * p.Wo);
+    const long long a_shift = AMODE == 0 ? (long long)fr0 * p.lda * 4 : (long long)fn0 * p.H * p.W * p.Cin * 4;
+    __amdgpu_buffer_rsrc_t rsA = a_desc(p.a, p.a_total, a_shift);
     __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)(NP == 3 ? p.w3 : p.wh), 0,
                                                                    (int)(NP == 3 ? p.w3_bytes : p.wh_bytes), 0x00020000);
     // zero-extent twins: a load through them returns zeros without touching memory.  The chunk
     // loads past the end of the K range go through these instead of being branched around -- a
     // conditional load makes the compiler's vmcnt bookkeeping assume the worst path and wait for
     // the NEWEST loads before the split, which silently turned the two-chunk prefetch into one.
-    __amdgpu_buffer_rsrc_t rsA0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.a, 0, 0, 0x00020000);
+    __amdgpu_buffer_rsrc_t rsA0 = a_desc(p.a, p.a_total, a_shift, true);
     __amdgpu_buffer_rsrc_t rsW0 = __builtin_amdgcn_make_buffer_rsrc((void*)(NP == 3 ? p.w3 : p.wh), 0, 0, 0x00020000);
     float a_sc = 1.f;
     if constexpr (NP == 2) a_sc = pow2f(a_scale_exp(p.a_absmax));
@@ -604,9 +627,9 @@ __device__ __forceinline__ void igemm_tile_x3(const IgemmP& p, float* lds, int t
     }
     // TWO: switch the loader to the second operand pair (a2, wh2) and back
     auto use_second = [&]() {
-        rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.a2, 0, (int)p.a2_bytes, 0x00020000);
+        rsA = a_desc(p.a2, p.a2_total, (long long)m0 * p.lda2 * 4);
         rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.wh2, 0, (int)p.wh2_bytes, 0x00020000);
-        rsA0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.a2, 0, 0, 0x00020000);
+        rsA0 = a_desc(p.a2, p.a2_total, (long long)m0 * p.lda2 * 4, true);
         rsW0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.wh2, 0, 0, 0x00020000);
         a_sc = pow2f(a_scale_exp(p.a2_absmax));
 #pragma unroll
@@ -617,13 +640,13 @@ __device__ __forceinline__ void igemm_tile_x3(const IgemmP& p, float* lds, int t
 #pragma unroll
         for (int i = 0; i < ALD; ++i) {
             const int m = m0 + lr + RPA * i;
-            fa_off[i] = m < p.M ? (unsigned)m * (unsigned)p.lda2 * 4u + lc * 16u : OOR;
+            fa_off[i] = m < p.M ? (unsigned)(m - m0) * (unsigned)p.lda2 * 4u + lc * 16u : OOR;
         }
     };
     auto use_first = [&]() {
-        rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.a, 0, (int)p.a_bytes, 0x00020000);
+        rsA = a_desc(p.a, p.a_total, a_shift);
         rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.wh, 0, (int)p.wh_bytes, 0x00020000);
-        rsA0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.a, 0, 0, 0x00020000);
+        rsA0 = a_desc(p.a, p.a_total, a_shift, true);
         rsW0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.wh, 0, 0, 0x00020000);
         a_sc = pow2f(a_scale_exp(p.a_absmax));
 #pragma unroll
@@ -634,7 +657,7 @@ __device__ __forceinline__ void igemm_tile_x3(const IgemmP& p, float* lds, int t
 #pragma unroll
         for (int i = 0; i < ALD; ++i) {
             const int m = m0 + lr + RPA * i;
-            fa_off[i] = m < p.M ? (unsigned)m * (unsigned)p.lda * 4u + lc * 16u : OOR;
+            fa_off[i] = m < p.M ? (unsigned)(m - m0) * (unsigned)p.lda * 4u + lc * 16u : OOR;
         }
     };
 #pragma unroll
@@ -643,7 +666,7 @@ __device__ __forceinline__ void igemm_tile_x3(const IgemmP& p, float* lds, int t
         const bool rv = m < p.M;
         if constexpr (AMODE == 0) {
             const int row = p.pool2 ? pool2_base_pixel(p, m >> 2) + ((m & 3) >> 1) * p.Wo + (m & 1) : m;
-            fa_off[i] = rv ? (unsigned)row * (unsigned)p.lda * 4u + lc * 16u : OOR;
+            fa_off[i] = rv ? (unsigned)(row - fr0) * (unsigned)p.lda * 4u + lc * 16u : OOR;
             fa_mask[i] = 0;
         } else {
             int n, ho, wo;
@@ -659,7 +682,7 @@ __device__ __forceinline__ void igemm_tile_x3(const IgemmP& p, float* lds, int t
                 ho = rem / p.Wo; wo = rem - ho * p.Wo;
             }
             const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
-            fa_off[i] = ((unsigned)(n * p.H + hi0) * (unsigned)p.W + (unsigned)wi0) * (unsigned)p.Cin * 4u + lc * 16u;
+            fa_off[i] = ((unsigned)((n - fn0) * p.H + hi0) * (unsigned)p.W + (unsigned)wi0) * (unsigned)p.Cin * 4u + lc * 16u;
             unsigned msk = 0;
             for (int kh = 0; kh < p.KH; ++kh)
                 for (int kw = 0; kw < p.KW; ++kw)
@@ -927,9 +950,13 @@ __device__ __forceinline__ void igemm_tile_halo(const IgemmP& p, float* lds, int
     const int wc = tid & 3, wr = tid >> 2;                // W: chunk wc of rows wr + 64 j
     const int fr = lane & 31, fh = lane >> 5;
 
-    __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.a, 0, (int)p.a_bytes, 0x00020000);
+    // A descriptor rebased to the first pixel the tile can touch, m0 - 1 - W (see a_desc); for the tiles at the very
+    // start of the tensor the base stays 0 and "negative" pixels wrap past the extent = zeros, as before
+    const int px0 = m0 - 1 - p.W > 0 ? m0 - 1 - p.W : 0;
+    const long long a_shift = (long long)px0 * p.Cin * 4;
+    __amdgpu_buffer_rsrc_t rsA = a_desc(p.a, p.a_total, a_shift);
     __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.wh, 0, (int)p.wh_bytes, 0x00020000);
-    __amdgpu_buffer_rsrc_t rsA0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.a, 0, 0, 0x00020000);
+    __amdgpu_buffer_rsrc_t rsA0 = a_desc(p.a, p.a_total, a_shift, true);
     __amdgpu_buffer_rsrc_t rsW0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.wh, 0, 0, 0x00020000);
     const float a_sc = pow2f(a_scale_exp(p.a_absmax));
 
@@ -939,7 +966,7 @@ __device__ __forceinline__ void igemm_tile_halo(const IgemmP& p, float* lds, int
 #pragma unroll
     for (int i = 0; i < ALD; ++i) {
         const int j = lr + 32 * i;
-        fa_off[i] = j < 130 ? (unsigned)((m0 - 1 + j) * p.Cin) * 4u + lc * 16u : OOR;
+        fa_off[i] = j < 130 ? (unsigned)((m0 - 1 + j - px0) * p.Cin) * 4u + lc * 16u : OOR;
     }
     unsigned fw_off[WLD];
 #pragma unroll
@@ -1470,10 +1497,12 @@ int launch_modes(IgemmP& p, hipStream_t s, int nbatch = 1, void* ws = nullptr, s
     return launch_cfg<128, 128, 2, 2, AMODE, WMODE, 16, 4>(p, s, nbatch, ws, wsb);
 }
 
-// buffer extents for the FAST loader; 0 (= not eligible) when an operand reaches 2 GiB
+// buffer extents for the FAST loader.  A may be any size (tiles rebase their descriptors, see a_desc); a weight
+// operand of 2 GiB or more is not eligible (0)
 inline void set_extents(IgemmP& p, long long a_bytes, long long w_bytes) {
-    const long long lim = 0x7FFFFFF0LL;
-    p.a_bytes = (a_bytes > 0 && a_bytes < lim) ? (unsigned)a_bytes : 0u;
+    const long long lim = EXT_LIM;
+    p.a_total = a_bytes > 0 ? a_bytes : 0;
+    p.a_bytes = a_bytes > 0 ? (unsigned)(a_bytes < lim ? a_bytes : lim) : 0u;
     p.w_bytes = (w_bytes > 0 && w_bytes < lim) ? (unsigned)w_bytes : 0u;
 }
 
@@ -1726,12 +1755,12 @@ extern "C" int dbmm_gemm_dual_bn_act_x2(const float* a, int64_t lda, const float
     if ((K % 32) || (K2 % 32) || (N & 3) || w_exp < -40 || w_exp > 40) return DBMM_E_UNSUPPORTED;
     const long long ab = ((M - 1) * lda + K) * 4, ab2 = ((M - 1) * lda2 + K2) * 4, wb = ((N - 1) * ldw + K) * 2,
                     wb2 = ((N - 1) * ldw2 + K2) * 2, lim = 0x7FFFFFF0LL;
-    if (ab >= lim || ab2 >= lim || wb >= lim || wb2 >= lim) return DBMM_E_UNSUPPORTED;
+    if (wb >= lim || wb2 >= lim) return DBMM_E_UNSUPPORTED;      // (activations may exceed 2 GiB: tiles rebase, a_desc)
     constexpr int BM = 128, BN = 128, MB = 3;
     IgemmP p{};
-    p.a = a; p.lda = lda; p.a_bytes = (unsigned)ab; p.a_absmax = a_absmax;
+    p.a = a; p.lda = lda; p.a_bytes = (unsigned)(ab < lim ? ab : lim); p.a_total = ab; p.a_absmax = a_absmax;
     p.wh = (const unsigned short*)w_plane_f16; p.wh_bytes = (unsigned)wb; p.ldw = ldw; p.w_exp = w_exp; p.nw = 1;
-    p.a2 = a2; p.lda2 = lda2; p.a2_bytes = (unsigned)ab2; p.a2_absmax = a2_absmax; p.K2 = (int)K2;
+    p.a2 = a2; p.lda2 = lda2; p.a2_bytes = (unsigned)(ab2 < lim ? ab2 : lim); p.a2_total = ab2; p.a2_absmax = a2_absmax; p.K2 = (int)K2;
     p.wh2 = (const unsigned short*)w2_plane_f16; p.wh2_bytes = (unsigned)wb2; p.ldw2 = ldw2; p.ratio = ratio;
     p.oscale = out_scale; p.bias = bias; p.c = c; p.ldc = ldc; p.absmax_out = c_absmax;
     p.M = (int)M; p.N = (int)N; p.K = (int)K; p.act = act; p.alpha = 1.f;

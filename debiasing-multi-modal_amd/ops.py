@@ -26,14 +26,14 @@ def profile_begin(conv_only=False):
 
 
 def profile_end():
-    """stop collecting; returns {tag: (launches, total_flops, total_ms)} (synchronises)."""
+    """stop collecting; returns {tag: (launches, total_flops, total_ms, total_algorithmic_bytes)} (synchronises)."""
     global _prof
     rec, _prof = _prof or [], None
     torch.cuda.synchronize()
     out = {}
-    for tag, flops, e0, e1 in rec:
-        n, f, ms = out.get(tag, (0, 0.0, 0.0))
-        out[tag] = (n + 1, f + flops, ms + e0.elapsed_time(e1))
+    for tag, flops, nbytes, e0, e1 in rec:
+        n, f, ms, by = out.get(tag, (0, 0.0, 0.0, 0.0))
+        out[tag] = (n + 1, f + flops, ms + e0.elapsed_time(e1), by + nbytes)
     return out
 
 
@@ -52,8 +52,11 @@ def _last_igemm_tag():
 
 
 class _Timed:
-    def __init__(self, M, N, K, amode, wmode):
+    """HIP events (on the launch stream = torch's current stream) around one igemm launch.  nbytes = the launch's
+    ALGORITHMIC bytes: every operand read once, every output written once."""
+    def __init__(self, M, N, K, amode, wmode, nbytes=0):
         self.args = (M, N, K, amode, wmode)
+        self.nbytes = float(nbytes)
 
     def __enter__(self):
         self.on = _prof is not None and (self.args[3] == 1 or not _prof_conv_only)
@@ -66,7 +69,7 @@ class _Timed:
             M, N, K, amode, wmode = self.args
             e1 = torch.cuda.Event(enable_timing=True)
             e1.record()
-            _prof.append((_last_igemm_tag(), 2.0 * M * N * K, self.e0, e1))
+            _prof.append((_last_igemm_tag(), 2.0 * M * N * K, self.nbytes, self.e0, e1))
 
 
 _ws_cache = {}
@@ -143,21 +146,24 @@ def gemm(a, w, bias=None, residual=None, act=ACT_NONE, alpha=1.0, trans_a=False,
         out = torch.empty((M, N), device=a.device, dtype=torch.float32)
     ldr = residual.shape[-1] if residual is not None else 0
     ws = igemm_workspace(a.device)
+    # algorithmic bytes: A and the residual read once, C written once, W once in the form the kernel reads it
+    nby = 4 * (M * K + M * N * (2 if residual is not None else 1)) + \
+        (w_planes_f16.numel() * 2 if w_planes_f16 is not None else (w_planes.numel() * 2 if w_planes is not None else 4 * N * K))
     if (w_planes_f16 is not None or c_absmax is not None) and not trans_a and not trans_w:
         nw = 2 if w_planes_f16 is None else int(w_planes_f16.shape[0])
-        with _Timed(M, N, K, 0, 0):
+        with _Timed(M, N, K, 0, 0, nby):
             check(_lib.lib().dbmm_gemm_bias_act_x2(ptr(a), lda, ptr(a_absmax), ptr(w), ptr(w_planes_f16), nw, int(w_exp),
                                                    w.shape[-1], None, ptr(bias), ptr(residual), ldr, ptr(out),
                                                    out.shape[-1], ptr(c_absmax), M, N, K, float(alpha), act, ptr(ws),
                                                    ws.numel() * 4, stream()), "gemm_bias_act_x2")
         return out
     if w_planes is not None and not trans_a and not trans_w:
-        with _Timed(M, N, K, 0, 0):
+        with _Timed(M, N, K, 0, 0, nby):
             check(_lib.lib().dbmm_gemm_bias_act_x3(ptr(a), lda, ptr(w), ptr(w_planes), w.shape[-1], ptr(bias),
                                                    ptr(residual), ldr, ptr(out), out.shape[-1], M, N, K, float(alpha),
                                                    act, ptr(ws), ws.numel() * 4, stream()), "gemm_bias_act_x3")
         return out
-    with _Timed(M, N, K, 2 if trans_a else 0, int(trans_w)):
+    with _Timed(M, N, K, 2 if trans_a else 0, int(trans_w), nby):
         check(_lib.lib().dbmm_gemm_bias_act_ws(ptr(a), lda, int(trans_a), ptr(w), w.shape[-1], int(trans_w), ptr(bias),
                                                ptr(residual), ldr, ptr(out), out.shape[-1], M, N, K, float(alpha), act,
                                                ptr(ws), ws.numel() * 4, stream()), "gemm_bias_act")
@@ -205,10 +211,15 @@ def conv_bn_act(x, w, bias, residual, kh, kw, stride, pad, act, w_layout=WL_TAP_
         raise _lib.DbmmError("conv_bn_act: pool must be 1 or 2")
     plain = kh == 1 and kw == 1 and stride == 1 and pad == 0
     split = w_planes_f16 is not None or y_absmax is not None or out_scale is not None
+    # algorithmic bytes: input map and residual read once, output(s) written once, weights once
+    wby = w_planes_f16.numel() * 2 if w_planes_f16 is not None else (w_planes.numel() * 2 if w_planes is not None else w.numel() * 4)
+    oel = B * Ho * Wo * Cout
+    nby_pool = 4 * (x.numel() + (residual.numel() if residual is not None else 0) + oel // 4 + (oel if keep_full else 0)) + wby
+    nby = 4 * (x.numel() + (residual.numel() if residual is not None else 0) + oel) + wby
     if pool == 2 and split and Ho % 2 == 0 and Wo % 2 == 0:
         y = torch.empty((B, Ho // 2, Wo // 2, Cout), device=x.device, dtype=torch.float32)
         yf = torch.empty((B, Ho, Wo, Cout), device=x.device, dtype=torch.float32) if keep_full else None
-        t = _Timed(B * Ho * Wo, Cout, kh * kw * Cin, 0 if plain else 1, 0)
+        t = _Timed(B * Ho * Wo, Cout, kh * kw * Cin, 0 if plain else 1, 0, nby_pool)
         t.__enter__()
         rc = _conv_x2(x, w, bias, residual, y, kh, kw, stride, pad, act, w_layout, w_planes_f16, w_exp, x_absmax,
                       y_absmax, out_scale, 2, yf)
@@ -218,7 +229,7 @@ def conv_bn_act(x, w, bias, residual, kh, kw, stride, pad, act, w_layout=WL_TAP_
         if rc != _lib.E_UNSUPPORTED:
             check(rc, "conv_bn_act_x2(pool)")
     y = torch.empty((B, Ho, Wo, Cout), device=x.device, dtype=torch.float32)
-    with _Timed(B * Ho * Wo, Cout, kh * kw * Cin, 0 if plain else 1, 0):
+    with _Timed(B * Ho * Wo, Cout, kh * kw * Cin, 0 if plain else 1, 0, nby):
         ws = igemm_workspace(x.device)
         if split:
             check(_conv_x2(x, w, bias, residual, y, kh, kw, stride, pad, act, w_layout, w_planes_f16, w_exp, x_absmax,
@@ -260,7 +271,7 @@ def gemm_dual(a, a_absmax, w_plane, w_exp, out_scale, a2, a2_absmax, w2_plane, r
         raise _lib.DbmmError("gemm_dual: operand row counts differ")
     c = torch.empty(tuple(a.shape[:-1]) + (N,), device=a.device, dtype=torch.float32)
     ws = igemm_workspace(a.device)
-    t = _Timed(M, N, K + K2, 0, 0)
+    t = _Timed(M, N, K + K2, 0, 0, 4 * (M * K + M * K2 + M * N) + 2 * (N * K + N * K2))
     t.__enter__()
     rc = _lib.lib().dbmm_gemm_dual_bn_act_x2(ptr(a), K, ptr(a_absmax), ptr(w_plane), int(w_exp), K, K, ptr(out_scale),
                                              ptr(a2), K2, ptr(a2_absmax), ptr(w2_plane), K2, K2, ptr(ratio), ptr(bias),

@@ -252,11 +252,18 @@ def gen_adapter(FM, D=1024, Bs=(4, 256, 1024), fname="adapter.npz"):
                 labels = g if use_group else y
                 text = tgrp if use_group else tcls
                 ma.train()
+                # smallest |BatchNorm output| of the trainable adapter at step 0 = distance of the nearest ReLU input
+                # from its kink.  ReLU'(0) is a tie: an implementation whose pre-activation lands 1e-8 on the other side
+                # has a different (equally valid) gradient in layers 0 / 1, so tests skip those when the margin is ~0.
+                margins = []
+                hook = ma.new_adapter.layers[1].register_forward_hook(lambda m, i, o: margins.append(o.detach().abs().min().item()))
                 for step in range(3):
                     logits = ma(x.detach(), use_group)
                     loss = crit(logits, labels)
                     optim.zero_grad(); loss.backward()
                     if step == 0:
+                        hook.remove()
+                        out[f"{tag}/step0/relu_margin"] = np.float64(margins[0])
                         record(tag + "/step0", {"logits": logits, "loss": loss})
                         record(tag + "/step0/grad", {n: p.grad for n, p in ma.named_parameters() if p.grad is not None})
                     optim.step()

@@ -747,3 +747,86 @@ def test_gemm_dual_reports_unsupported_shapes():
     ph, we, _ = ops.split_planes_f16(w, allow_single=True)
     one = torch.ones(128, device=DEV)
     assert ops.gemm_dual(y, y.abs().max().reshape(1), ph, we, one, x, x.abs().max().reshape(1), ph, one, one) is None
+
+
+def _last_cfg():
+    import ctypes
+    from dbmm_amd import _lib
+    cfg = (ctypes.c_int * 11)()
+    _lib.lib().dbmm_debug_last_igemm(cfg)
+    return list(cfg)
+
+
+def test_operands_over_2gib_stay_on_the_split_kernels():
+    """RN50 layer 1 at the headline batch 1024 holds 3.3 GB activation tensors.  Buffer descriptors
+    address 32 bits, so every tile rebases its descriptor on a 64-bit base (a_desc in igemm_f32.hip):
+    operands past 2 GiB must still run the fp16-pair / halo / dual-source kernels (cfg[8] in 2, 4, 5 --
+    not the fp32 fallback) and give the same numbers as the same images in a small batch."""
+    torch.manual_seed(0)
+    g = torch.Generator(device=DEV); g.manual_seed(1)
+    # --- 1x1 conv, 256 -> 64 channels on 56x56 maps: 720 images = 2.31 GB input
+    B, H, Cin, Cout = 720, 56, 256, 64
+    x = torch.randn((B, H, H, Cin), device=DEV, generator=g)
+    assert x.numel() * 4 > 2 ** 31
+    w = (torch.randn((Cout, Cin), device=DEV, generator=g) * Cin ** -0.5).half().float()
+    sc = 0.5 + torch.rand((Cout,), device=DEV, generator=g); b = torch.randn((Cout,), device=DEV, generator=g) * 0.1
+    ph, we, n = ops.split_planes_f16(w, allow_single=True)
+    assert n == 1
+    xa = x.abs().max().reshape(1)
+    am = torch.zeros(1, device=DEV)
+    y = ops.conv_bn_act(x, w, b, None, 1, 1, 1, 0, ops.ACT_RELU, w_planes_f16=ph, w_exp=we, x_absmax=xa, y_absmax=am,
+                        out_scale=sc)
+    assert _last_cfg()[8] == 2, _last_cfg()
+    for i in (0, 359, B - 1):           # first image, one straddling the 2 GiB line's neighbourhood, the last
+        ref = torch.relu(x[i].double() @ w.double().t() * sc.double() + b.double())
+        assert relerr(y[i].double().cpu(), ref.cpu()) < 5e-6, i
+    assert am.item() == y.abs().max().item()
+    # --- the same tensor as the branch operand of the dual-source GEMM (conv3 + downsample)
+    M = B * H * H
+    y2 = torch.relu(torch.randn((M, 64), device=DEV, generator=g))
+    w3 = (torch.randn((256, 64), device=DEV, generator=g) * 64 ** -0.5).half().float()
+    wd = (torch.randn((256, Cin), device=DEV, generator=g) * Cin ** -0.5).half().float()
+    p3, e3, _ = ops.split_planes_f16(w3, allow_single=True); pd, ed, _ = ops.split_planes_f16(wd, allow_single=True)
+    s3 = 0.5 + torch.rand((256,), device=DEV, generator=g); sd = 0.5 + torch.rand((256,), device=DEV, generator=g)
+    ratio = (sd.double() / s3.double() * 2.0 ** (e3 - ed)).float()
+    bb = torch.randn((256,), device=DEV, generator=g) * 0.1
+    out = ops.gemm_dual(y2, y2.abs().max().reshape(1), p3, e3, s3, x.view(M, Cin), xa, pd, ratio, bb, ops.ACT_RELU)
+    assert out is not None and _last_cfg()[8] == 5, _last_cfg()
+    assert out.numel() * 4 > 2 ** 31
+    for r0 in (0, M // 2 - 64, M - 200):
+        sl = slice(r0, r0 + 200)
+        ref = torch.relu(y2[sl].double() @ w3.double().t() * s3.double() + x.view(M, Cin)[sl].double() @ wd.double().t() * sd.double()
+                         + bb.double())
+        assert relerr(out[sl].double().cpu(), ref.cpu()) < 5e-6, r0
+    # --- conv3-style 1x1 with a residual > 2 GiB and the pooled second output (64-bit row pointers in the epilogue)
+    res = out.view(B, H, H, 256)
+    (yp, yf), _ = (ops.conv_bn_act(y2.view(B, H, H, 64), w3, bb, res, 1, 1, 1, 0, ops.ACT_RELU, w_planes_f16=p3, w_exp=e3,
+                                   x_absmax=y2.abs().max().reshape(1), out_scale=s3, pool=2, keep_full=True), None)
+    assert _last_cfg()[8] == 2
+    i = B - 1
+    ref = torch.relu(y2.view(B, H * H, 64)[i].double() @ w3.double().t() * s3.double() + bb.double() + res[i].view(H * H, 256).double())
+    assert relerr(yf[i].view(H * H, 256).double().cpu(), ref.cpu()) < 5e-6
+    refp = F.avg_pool2d(ref.view(H, H, 256).permute(2, 0, 1)[None], 2)[0].permute(1, 2, 0)
+    assert relerr(yp[i].double().cpu(), refp.cpu()) < 5e-6
+    del out, res, yp, yf, y2, x, y
+    torch.cuda.empty_cache()
+    # --- 3x3 halo kernel, 64 -> 64 channels on 56x56 maps: 2880 images = 2.31 GB input
+    B, Cin, Cout = 2880, 64, 64
+    x = torch.randn((B, H, H, Cin), device=DEV, generator=g)
+    assert x.numel() * 4 > 2 ** 31
+    w = (torch.randn((Cout, Cin, 3, 3), device=DEV, generator=g) * (9 * Cin) ** -0.5).half().float()
+    wp, wl = ops.pack_conv_weight(w, chunk_major=32)
+    ph, we, n = ops.split_planes_f16(wp, allow_single=True)
+    y = ops.conv_bn_act(x, wp, b, None, 3, 3, 1, 1, ops.ACT_RELU, wl, w_planes_f16=ph, w_exp=we,
+                        x_absmax=x.abs().max().reshape(1), out_scale=sc)
+    assert _last_cfg()[8] == 4, _last_cfg()
+    for i in (0, 1439, 1440, B - 1):
+        ref = F.conv2d(x[i].permute(2, 0, 1)[None].double(), w.double(), None, padding=1)[0].permute(1, 2, 0)
+        ref = torch.relu(ref * sc.double() + b.double())
+        assert relerr(y[i].double().cpu(), ref.cpu()) < 5e-6, i
+    # --- the per-tap conv kernel on the same tensor, pooled (window-major rows)
+    yp = ops.conv_bn_act(x, wp, b, None, 3, 3, 1, 1, ops.ACT_RELU, wl, w_planes_f16=ph, w_exp=we,
+                         x_absmax=x.abs().max().reshape(1), out_scale=sc, pool=2)
+    assert _last_cfg()[8] == 2 and _last_cfg()[4] == 1, _last_cfg()
+    for i in (0, 1440, B - 1):
+        assert relerr(yp[i].cpu(), F.avg_pool2d(y[i].permute(2, 0, 1)[None], 2)[0].permute(1, 2, 0).cpu()) < 2e-6, i
