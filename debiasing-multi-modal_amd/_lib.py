@@ -23,30 +23,36 @@ def sources():
 
 
 def build(force=False, verbose=False):
-    """hipcc --offload-arch=gfx950 -> libdbmm_hip.so (in-tree, so it travels with the repo)."""
+    """hipcc --offload-arch=gfx950 -> libdbmm_hip.so (in-tree, so it travels with the repo).  Incremental: a source
+    is recompiled when it, a shared header or include/dbmm.h is newer than its object; `force` recompiles all.
+    Returns the library path; `build.last` lists the sources compiled by the most recent call."""
     srcs = sources()
-    deps = srcs + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.inc")) + [os.path.join(INCLUDE, "dbmm.h")]
-    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
-        return LIB_PATH
+    hdrs = glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.inc")) + [os.path.join(INCLUDE, "dbmm.h")]
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    objs = []
-    procs = []
     os.makedirs(os.path.join(_HERE, "build"), exist_ok=True)
+    objs, procs = [], []
+    newest_hdr = max(os.path.getmtime(h) for h in hdrs)
     for s in srcs:
         o = os.path.join(_HERE, "build", os.path.basename(s) + ".o")
         objs.append(o)
+        if not force and os.path.exists(o) and os.path.getmtime(o) >= max(os.path.getmtime(s), newest_hdr):
+            continue
         cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", INCLUDE, "-c", s, "-o", o]
         if verbose:
             print(" ".join(cmd))
-        procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
-    for cmd, p in procs:
+        procs.append((s, cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for s, cmd, p in procs:
         out, _ = p.communicate()
         if p.returncode != 0:
             errs = [l for l in out.decode().splitlines() if "error" in l][:8]
             raise RuntimeError("hipcc failed: %s\n%s" % (" ".join(cmd), "\n".join(errs) or out.decode()[-2000:]))
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs
-    subprocess.run(cmd, check=True)
+    build.last = [os.path.basename(s) for s, _, _ in procs]
+    if procs or not os.path.exists(LIB_PATH) or any(os.path.getmtime(LIB_PATH) < os.path.getmtime(o) for o in objs):
+        subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs, check=True)
     return LIB_PATH
+
+
+build.last = []
 
 
 _F, _I, _L, _P, _Z = c_float, c_int, c_int64, c_void_p, c_size_t
@@ -71,6 +77,7 @@ _SIGS = {
     "dbmm_conv_bn_act_x2": [_P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _L, _L, _L, _L, _L, _L, _L, _L, _L, _I, _I, _I, _P, _Z, _P],
     "dbmm_gemm_bias_act_x2": [_P, _L, _P, _P, _P, _I, _I, _L, _P, _P, _P, _L, _P, _L, _P, _L, _L, _L, _F, _I, _P, _Z, _P],
     "dbmm_gemm_dual_bn_act_x2": [_P, _L, _P, _P, _I, _L, _L, _P, _P, _L, _P, _P, _L, _L, _P, _P, _P, _L, _P, _L, _L, _I, _P, _Z, _P],
+    "dbmm_bottleneck_chain_x2": [_P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _L, _L, _L, _L, _L, _L, _P],
     "dbmm_gemm_bias_act_x3": [_P, _L, _P, _P, _L, _P, _P, _L, _P, _L, _L, _L, _L, _F, _I, _P, _Z, _P],
     "dbmm_gemm_batched": [_P, _L, _L, _I, _P, _L, _L, _I, _P, _L, _P, _L, _L, _L, _L, _L, _L, _F, _I, _P],
     "dbmm_conv_stem_s2": [_P, _P, _P, _P, _P, _L, _L, _L, _L, _P],

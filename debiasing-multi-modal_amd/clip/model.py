@@ -129,6 +129,8 @@ CONV_SPLIT = os.environ.get("DBMM_CONV_SPLIT", "f16")
 _K_ORDER = False if os.environ.get("DBMM_CONV_K_ORDER", "chunk32") == "tap" else 32
 # conv3 + downsample branch of a stage's first block as one dual-source GEMM (DBMM_FUSE_DS=0: two launches)
 _FUSE_DS = os.environ.get("DBMM_FUSE_DS", "1") != "0"
+# conv3 + residual chained with the next block's conv1 in one launch (layer 1; DBMM_FUSE_CHAIN=0: separate launches)
+_FUSE_CHAIN = os.environ.get("DBMM_FUSE_CHAIN", "1") != "0"
 
 
 def _pack_conv(w64, bias, raw=None, scale=None):
@@ -256,11 +258,15 @@ class ModifiedResNet(nn.Module):
         stages = {"stem": x}
         blocks = P["blocks"]
         x_pooled = None          # AvgPool2d(2) of x when the previous conv3 already produced it
+        y1_next = None           # (conv1 output, its max slot) of the next block when the previous chain launch made it
         bi = 0
         for li in (1, 2, 3, 4):
             for _ in getattr(self, f"layer{li}"):
                 e = blocks[bi]; bi += 1
-                out, oam = conv(x, am, e["c1"], None, 1, 0, ops.ACT_RELU)
+                if y1_next is not None:
+                    (out, oam), y1_next = y1_next, None
+                else:
+                    out, oam = conv(x, am, e["c1"], None, 1, 0, ops.ACT_RELU)
                 if e["stride"] == 2:      # conv2 + bn2 + ReLU + AvgPool2d(2) in one epilogue
                     out, oam = conv(out, oam, e["c2"], None, 3, 1, ops.ACT_RELU, pool=2)
                 else:
@@ -287,8 +293,23 @@ class ModifiedResNet(nn.Module):
                 # block downsamples, the same launch also writes AvgPool2d(2) of its output for that
                 # block's downsample branch
                 nxt = blocks[bi] if bi < len(blocks) else None
-                if nxt is not None and nxt["stride"] == 2 and "ds" in nxt and x.shape[1] % 2 == 0 and x.shape[2] % 2 == 0 \
-                        and identity.shape[1] % 2 == 0 and identity.shape[2] % 2 == 0:
+                want_pool = nxt is not None and nxt["stride"] == 2 and "ds" in nxt and x.shape[1] % 2 == 0 and x.shape[2] % 2 == 0 \
+                    and identity.shape[1] % 2 == 0 and identity.shape[2] % 2 == 0
+                if (nxt is not None and track and _FUSE_CHAIN and e["c3"]["sc"] is not None and nxt["c1"]["sc"] is not None
+                        and e["c3"]["ph"] is not None and nxt["c1"]["ph"] is not None
+                        and (want_pool or not (nxt["stride"] == 2 and "ds" in nxt))):
+                    # the same launch continues into the next block's conv1: x is written once, not re-read
+                    x_am, y1_am = amax[slot[0]:slot[0] + 1], amax[slot[0] + 1:slot[0] + 2]
+                    r = ops.bottleneck_chain(out, oam, e["c3"], identity, nxt["c1"], x_am, y1_am, pooled=want_pool)
+                    if r is not None:
+                        slot[0] += 2                      # this conv3's slot and the next conv1's
+                        if want_pool:
+                            x, x_pooled, y1 = r
+                        else:
+                            (x, y1), x_pooled = r, None
+                        am, y1_next = x_am, (y1, y1_am)
+                        continue
+                if want_pool:
                     (x_pooled, x), am = conv(out, oam, e["c3"], identity, 1, 0, ops.ACT_RELU, pool=2, keep_full=True)
                 else:
                     x_pooled = None

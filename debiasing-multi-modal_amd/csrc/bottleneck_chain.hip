@@ -1,0 +1,399 @@
+// conv3 + residual of one bottleneck block CHAINED with conv1 of the next block in one launch.
+//
+//   x' = relu( (y2 @ W3^T) * sc3 + b3 + x )          [M][N]   written to HBM (it is the next residual)
+//   y1' = relu( (x' @ W1^T) * sc1 + b1 )             [M][P]   written to HBM
+//   (POOL: also avgpool2x2(x') [M/4][N] for the downsample branch of the next stage's first block)
+//
+// Why: at the headline batch the 1x1 convs of layers 1-2 are HBM-bound and conv1 of the NEXT block re-reads
+// the 256/512-channel tensor conv3 has just written (clip/model.py:42-55 back to back): 3.3 GB of the 13 GB a
+// layer-1 block moves at B = 1024.  Here one workgroup owns 128 pixel rows for ALL N output channels of conv3,
+// walks them in 64-channel slabs, and every finished slab is at once the next 64-deep K chunk of conv1': the
+// wide tensor is written once and never read back for conv1.
+//
+// Arithmetic = the fp16-pair path of igemm_f32.hip (fp32 value = fp16 hi + lo with an exact power-of-two scale,
+// weights exact in one fp16 plane, fp32 accumulate).  conv3 takes its scale from the producer's device scalar
+// (a_absmax); the slab's scale is WAVE-LOCAL: every wave owns 32 pixel rows through both GEMMs (4x1 wave layout),
+// so it can use the running maximum of its own finished slabs and rescale its conv1' accumulators (exactly, by a
+// power of two) when that maximum crosses a binade -- no a-priori bound, no grid-wide reduction.
+//
+// Data movement.  y2 tile -> LDS as fp16 planes (coalesced 16-B loads, all threads) -> A fragments live in
+// registers for the whole tile.  Weights (W3 slab [64][K], W1 chunk [P][64]) are prefetched one slab ahead into
+// registers and staged in LDS.  Residual loads and x' / y1' stores go straight from / to the MFMA accumulator
+// layout: one register of a 32x32 accumulator is two 128-B row segments per wave instruction, which streams at
+// full rate (MI355X_MICROARCH.md, "access shape per wave-instruction"); the next slab's residual is in flight
+// during the current slab's conv1' MFMAs.  The finished slab goes to a wave-private fp32 LDS slab and is split
+// into hi / lo when the conv1' A fragments are read.
+//
+// Bound: HBM.  Algorithmic bytes per pixel row: 4 * (K + 2 N + P) (+ N for the pooled copy).
+#include <stdlib.h>
+#include "common.h"
+
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16;
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr unsigned OOR = 0x80000000u;
+constexpr long long EXT_LIM = 0x7FFFFFF0LL;
+
+struct ChainP {
+    const float* a; const float* a_absmax;                 // y2 [M][K] in standard pixel order
+    const u16* w3; int w3_exp; const float* sc3; const float* b3;      // [N][K] fp16 plane of W3 * 2^w3_exp
+    const float* res; float* x; float* xp; float* x_absmax;            // residual [M][N], x' [M][N], pooled [M/4][N]
+    const u16* w1; int w1_exp; const float* sc1; const float* b1;      // [P][N] fp16 plane of W1 * 2^w1_exp
+    float* y1; float* y1_absmax;                            // [M][P]
+    int M, N;
+    int Ho, Wo;                                             // POOL: map of the M = B * Ho * Wo pixels
+};
+
+__device__ __forceinline__ int scale_exp(float amax) {      // s with amax * 2^s in [2^13, 2^14)
+    const unsigned b = __float_as_uint(amax) & 0x7fffffffu;
+    int s = b ? 13 - ((int)(b >> 23) - 127) : 0;
+    return s < -60 ? -60 : (s > 60 ? 60 : s);
+}
+__device__ __forceinline__ float pow2f(int e) { return __uint_as_float((unsigned)(e + 127) << 23); }
+
+// (hi, lo) fp16 pairs of x0 * sc and x1 * sc, packed {x0 | x1 << 16}
+__device__ __forceinline__ void split2h_pair(float x0, float x1, float sc, unsigned& hi, unsigned& lo) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(hi) : "v"(x0), "v"(sc));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(hi) : "v"(x1), "v"(sc));
+    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(lo) : "v"(x0), "v"(sc), "v"(hi));
+    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(lo) : "v"(x1), "v"(sc), "v"(hi));
+#else
+    (void)x0; (void)x1; (void)sc; hi = lo = 0;
+#endif
+}
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t desc(const void* base, long long total, long long shift) {
+    long long ext = total - shift;
+    ext = ext < 0 ? 0 : (ext > EXT_LIM ? EXT_LIM : ext);
+    return __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)base + shift), 0, (int)ext, 0x00020000);
+}
+
+// LDS rows of RH halves (2 * RH bytes): XOR of the 16-B chunk index with row bits keeps the 16 lanes of a ds_read_b128
+// group on distinct bank quads -- 64-B rows: 4 rows per 256-B bank sweep; 128-B rows: 2; 256-B rows: every row starts a sweep
+template <int RH>
+__device__ __forceinline__ int swz(int row) { return RH == 32 ? ((row >> 2) & 3) : (RH == 64 ? ((row >> 1) & 7) : (row & 15)); }
+
+constexpr int BM = 128;                      // pixel rows per workgroup
+
+// K = 64 (layer 1): 64-channel slabs.  K = 128 (layer 2): the A fragments take 64 registers, so the slab (conv3
+// accumulators, residual prefetch, weight prefetch) is halved to 32 channels to stay inside 256 VGPRs at 2 workgroups / CU.
+template <int K, int P>
+struct ChainGeo {
+    static constexpr int BNS = K == 64 ? 64 : 32;                 // channels per slab
+    static constexpr int SLROW = BNS + 4;                         // slab row pitch in floats (272 / 144 B: conflict-free b128 rows)
+    static constexpr int R1_BYTES = BM * SLROW * 4 > 2 * BM * 64 * 2 ? BM * SLROW * 4 : 2 * BM * 64 * 2;   // slab | y2 planes (64 k at a time)
+    static constexpr int W3_BYTES = BNS * K * 2;
+    static constexpr int W1_BYTES = P * BNS * 2;
+    static constexpr int LDS_BYTES = R1_BYTES + W3_BYTES + W1_BYTES;
+};
+
+// pixel (standard order) of tile row m: identity, or 2x2-window-major (m = 4 * pooled pixel + dy * 2 + dx)
+template <int POOL>
+__device__ __forceinline__ int row_pixel(const ChainP& p, int m) {
+    if constexpr (!POOL) return m;
+    const int mp = m >> 2, q = m & 3, wp2 = p.Wo >> 1, hwp = (p.Ho >> 1) * wp2;
+    const int n = mp / hwp, rem = mp - n * hwp, hp = rem / wp2;
+    return (n * p.Ho + 2 * hp + (q >> 1)) * p.Wo + 2 * (rem - hp * wp2) + (q & 1);
+}
+
+template <int K, int P, int POOL>
+__global__ __launch_bounds__(256, 2) void bottleneck_chain_kernel(const ChainP p) {
+    static_assert(K == 64 || K == 128, "conv3 reduction depth: 64 (layer 1) or 128 (layer 2)");
+    static_assert(P == 64 || P == 128, "conv1' width");
+    using G = ChainGeo<K, P>;
+    constexpr int BNS = G::BNS, SLROW = G::SLROW;
+    constexpr int KS = K / 16, TN3 = BNS / 32, TN1 = P / 32;
+    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[G::LDS_BYTES];
+    u16* Ay = (u16*)lds_raw;                                       // [2 planes][128][64] (prologue only)
+    float* slab = (float*)lds_raw;                                 // [4 waves][32][SLROW]   (aliases Ay)
+    u16* W3b = (u16*)(lds_raw + G::R1_BYTES);                      // [BNS][K]
+    u16* W1b = (u16*)(lds_raw + G::R1_BYTES + G::W3_BYTES);        // [P][BNS]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 31, fh = lane >> 5;
+    const int m0 = xcd_remap(blockIdx.x, gridDim.x) * BM;
+    const int NT = p.N / BNS;
+
+    // ---- descriptors rebased to the tile's first pixel (tensors may exceed 2 GiB) ---------------------------
+    const int g0 = row_pixel<POOL>(p, m0);
+    const long long Mll = p.M;
+    const __amdgpu_buffer_rsrc_t rsA = desc(p.a, Mll * K * 4, (long long)g0 * K * 4);
+    const __amdgpu_buffer_rsrc_t rsR = desc(p.res, Mll * p.N * 4, (long long)g0 * p.N * 4);
+    const __amdgpu_buffer_rsrc_t rsX = desc(p.x, Mll * p.N * 4, (long long)g0 * p.N * 4);
+    const __amdgpu_buffer_rsrc_t rsY = desc(p.y1, Mll * P * 4, (long long)g0 * P * 4);
+    __amdgpu_buffer_rsrc_t rsXP = rsX;
+    if constexpr (POOL) rsXP = desc(p.xp, (Mll >> 2) * p.N * 4, (long long)(m0 >> 2) * p.N * 4);
+
+    // This lane's 16 accumulator rows are 4 groups (t = r >> 2) of 4 consecutive tile rows 8t + 4fh + q (q = r & 3).
+    // M is a multiple of 4, so a group is valid or not as a whole; its 4 pixels are the group's first pixel plus a
+    // WAVE-UNIFORM step (q, or (dy * Wo + dx) of a 2x2 window), which goes into the scalar offset of every access:
+    // no per-access address arithmetic.  Byte offsets relative to g0, + this lane's column; OOR = past M.
+    unsigned gx[4], gy[4];                              // into the [.][N] tensors / the [.][P] tensor
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int m = m0 + wave * 32 + 8 * t + 4 * fh;
+        const int dp = row_pixel<POOL>(p, m) - g0;
+        gx[t] = m < p.M ? (unsigned)dp * (unsigned)(p.N * 4) + (unsigned)(fr * 4) : OOR;
+        gy[t] = m < p.M ? (unsigned)dp * (unsigned)(P * 4) + (unsigned)(fr * 4) : OOR;
+    }
+    auto qpix = [&](int q) { return POOL ? (q >> 1) * p.Wo + (q & 1) : q; };       // wave-uniform pixel step of row q
+
+    // ---- prologue: first weight slabs and residual slab in flight; y2 tile -> fp16 planes in LDS -> A fragments ----
+    // weight slabs: W3 [BNS n][K] and the W1 chunk [P][BNS k], 16-B chunks dealt over the 256 threads
+    constexpr int CPR3 = K / 8, RPP3 = 256 / CPR3, W3LD = BNS * CPR3 / 256;        // chunks per row, rows per pass, loads per thread
+    constexpr int CPR1 = BNS / 8, RPP1 = 256 / CPR1, W1LD = P * CPR1 / 256;
+    static_assert(W3LD >= 1 && W1LD >= 1, "weight slabs smaller than one pass of the workgroup");
+    const int wc3 = tid % CPR3, wr3 = tid / CPR3, wc1 = tid % CPR1, wr1 = tid / CPR1;
+    u32x4 w3r[W3LD], w1r[W1LD];
+    auto load_w = [&](int nt) {
+#pragma unroll
+        for (int j = 0; j < W3LD; ++j)
+            w3r[j] = *(const u32x4*)(p.w3 + (size_t)(nt * BNS + wr3 + RPP3 * j) * K + wc3 * 8);
+#pragma unroll
+        for (int j = 0; j < W1LD; ++j)
+            w1r[j] = *(const u32x4*)(p.w1 + (size_t)(wr1 + RPP1 * j) * p.N + nt * BNS + wc1 * 8);
+    };
+    auto store_w = [&]() {
+#pragma unroll
+        for (int j = 0; j < W3LD; ++j) {
+            const int row = wr3 + RPP3 * j;
+            *(u32x4*)(W3b + row * K + ((wc3 ^ swz<K>(row)) << 3)) = w3r[j];
+        }
+#pragma unroll
+        for (int j = 0; j < W1LD; ++j) {
+            const int row = wr1 + RPP1 * j;
+            *(u32x4*)(W1b + row * BNS + ((wc1 ^ swz<BNS>(row)) << 3)) = w1r[j];
+        }
+    };
+    load_w(0);
+    // residual slab nt: this lane's 16 rows x TN3 column blocks, element (row r, col j*32 + fr)
+    float rr[TN3][16];
+    auto load_res = [&](int nt) {
+#pragma unroll
+        for (int j = 0; j < TN3; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                rr[j][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                    rsR, gx[r >> 2], (unsigned)((nt * BNS + j * 32) * 4 + qpix(r & 3) * p.N * 4), 0));
+    };
+    load_res(0);
+    // y2, 64 k at a time: 128 rows x 16 quads, thread (lc = tid & 15, lr = tid >> 4) loads rows lr + 16 i, splits them
+    // into (hi, lo) fp16 planes in LDS; then every wave reads the A fragments of its 32 rows into registers, where they
+    // stay for the whole tile: lane (row fr, k half fh) holds 8 k values per 16-deep step
+    const float a_sc = pow2f(scale_exp(*p.a_absmax));
+    u32x4 af[KS][2];
+#pragma unroll
+    for (int kp = 0; kp < K / 64; ++kp) {
+        const int lc = tid & 15, lr = tid >> 4;
+        f32x4 q[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int row = lr + 16 * i, m = m0 + row;
+            const unsigned off = m < p.M ? (unsigned)(row_pixel<POOL>(p, m) - g0) * (unsigned)(K * 4) + lc * 16u : OOR;
+            q[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, off, (unsigned)(kp * 256), 0));
+        }
+        if (kp) __syncthreads();                          // the previous pass's fragments have been read
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int row = lr + 16 * i;
+            unsigned hp[2], lp[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) split2h_pair(q[i][2 * j], q[i][2 * j + 1], a_sc, hp[j], lp[j]);
+            const int off = row * 64 + (((lc >> 1) ^ swz<64>(row)) << 3) + ((lc & 1) << 2);
+            *(u32x2*)(Ay + off) = (u32x2){hp[0], hp[1]};
+            *(u32x2*)(Ay + BM * 64 + off) = (u32x2){lp[0], lp[1]};
+        }
+        if (kp == 0) store_w();
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int row = wave * 32 + fr;
+            const int off = row * 64 + (((2 * ks + fh) ^ swz<64>(row)) << 3);
+            af[kp * 4 + ks][0] = *(const u32x4*)(Ay + off);
+            af[kp * 4 + ks][1] = *(const u32x4*)(Ay + BM * 64 + off);
+        }
+    }
+    __syncthreads();                                    // the y2 planes are dead: the region becomes the slab
+
+    float* Ls = slab + wave * (32 * SLROW);
+    const float acc3_scale = pow2f(-scale_exp(*p.a_absmax) - p.w3_exp);
+    f32x16 acc1[TN1];
+#pragma unroll
+    for (int j = 0; j < TN1; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc1[j][r] = 0.f;
+    float run_max = 0.f, x_amax = 0.f;
+    int s_cur = 0;                                      // exponent the conv1' accumulators are scaled by so far
+
+    for (int nt = 0; nt < NT; ++nt) {
+        const int n0 = nt * BNS;
+        if (nt + 1 < NT) load_w(nt + 1);                // lands during this slab's MFMAs
+        // ---- conv3 slab: acc3[32 x 64] = y2 rows . W3[n0 .. n0+63]^T ----------------------------------------
+        f32x16 acc3[TN3];
+#pragma unroll
+        for (int j = 0; j < TN3; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc3[j][r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            u32x4 wf[TN3];
+#pragma unroll
+            for (int j = 0; j < TN3; ++j) {
+                const int row = j * 32 + fr;
+                wf[j] = *(const u32x4*)(W3b + row * K + (((2 * ks + fh) ^ swz<K>(row)) << 3));
+            }
+#pragma unroll
+            for (int pl = 1; pl >= 0; --pl)              // (lo, w) first, then (hi, w)
+#pragma unroll
+                for (int j = 0; j < TN3; ++j)
+                    acc3[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[ks][pl]),
+                                                                     __builtin_bit_cast(f16x8, wf[j]), acc3[j], 0, 0, 0);
+        }
+        // ---- epilogue: BatchNorm scale / bias, residual, ReLU; store x'; slab; (pooled copy) ---------------------
+        float tmax = 0.f;
+#pragma unroll
+        for (int j = 0; j < TN3; ++j) {
+            const int n = n0 + j * 32 + fr;
+            const float sv = p.sc3[n] * acc3_scale, bv = p.b3[n];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = fmaxf(fmaf(acc3[j][r], sv, bv) + rr[j][r], 0.f);
+                if (gx[r >> 2] == OOR) v = 0.f;          // rows past M: keep the slab clean (their stores are dropped)
+                acc3[j][r] = v;
+                tmax = fmaxf(tmax, v);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsX, gx[r >> 2],
+                                                      (unsigned)((n0 + j * 32) * 4 + qpix(r & 3) * p.N * 4), 0);
+                Ls[((r & 3) + 8 * (r >> 2) + 4 * fh) * SLROW + j * 32 + fr] = v;
+            }
+            if constexpr (POOL) {
+                // rows 4i .. 4i+3 of the wave are one 2x2 window = registers 4t .. 4t+3 of this lane (i = 2t + fh);
+                // summed in (dy, dx) order like avgpool_kernel
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const float s = (((acc3[j][4 * t] + acc3[j][4 * t + 1]) + acc3[j][4 * t + 2]) + acc3[j][4 * t + 3]) * 0.25f;
+                    const int mp = wave * 8 + 2 * t + fh;                    // pooled row within the tile
+                    const unsigned off = gx[t] != OOR ? (unsigned)mp * (unsigned)(p.N * 4) + (unsigned)(fr * 4) : OOR;
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, s), rsXP, off, (unsigned)((n0 + j * 32) * 4), 0);
+                }
+            }
+        }
+        if (nt + 1 < NT) load_res(nt + 1);              // in flight during the conv1' MFMAs below
+        // ---- conv1' chunk: acc1[32 x P] += slab[32 x 64] . W1[:, n0 .. n0+63]^T, slab scale = wave-local ---------
+        tmax = wave_max(tmax);
+        x_amax = fmaxf(x_amax, tmax);
+        if (tmax > run_max) {
+            run_max = tmax;
+            const int s_new = scale_exp(run_max);
+            if (s_new != s_cur) {                        // wave-uniform: the running maximum crossed a binade
+                const float f = pow2f(s_new - s_cur);
+#pragma unroll
+                for (int j = 0; j < TN1; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc1[j][r] *= f;
+                s_cur = s_new;
+            }
+        }
+        const float t_sc = pow2f(s_cur);
+#pragma unroll
+        for (int ks = 0; ks < BNS / 16; ++ks) {
+            const f32x4 x0 = *(const f32x4*)(Ls + fr * SLROW + 16 * ks + 8 * fh);
+            const f32x4 x1 = *(const f32x4*)(Ls + fr * SLROW + 16 * ks + 8 * fh + 4);
+            unsigned h[4], l[4];
+            split2h_pair(x0[0], x0[1], t_sc, h[0], l[0]); split2h_pair(x0[2], x0[3], t_sc, h[1], l[1]);
+            split2h_pair(x1[0], x1[1], t_sc, h[2], l[2]); split2h_pair(x1[2], x1[3], t_sc, h[3], l[3]);
+            const u32x4 ah = {h[0], h[1], h[2], h[3]}, al = {l[0], l[1], l[2], l[3]};
+            u32x4 wf[TN1];
+#pragma unroll
+            for (int j = 0; j < TN1; ++j) {
+                const int row = j * 32 + fr;
+                wf[j] = *(const u32x4*)(W1b + row * BNS + (((2 * ks + fh) ^ swz<BNS>(row)) << 3));
+            }
+#pragma unroll
+            for (int j = 0; j < TN1; ++j)
+                acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, al), __builtin_bit_cast(f16x8, wf[j]),
+                                                                 acc1[j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < TN1; ++j)
+                acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah), __builtin_bit_cast(f16x8, wf[j]),
+                                                                 acc1[j], 0, 0, 0);
+        }
+        __syncthreads();                                // every wave is done with this slab's weights
+        if (nt + 1 < NT) store_w();
+        __syncthreads();
+    }
+
+    // ---- y1' = relu(bn1(acc1)) ---------------------------------------------------------------------------------
+    float y_amax = 0.f;
+    const float acc1_scale = pow2f(-s_cur - p.w1_exp);
+#pragma unroll
+    for (int j = 0; j < TN1; ++j) {
+        const int n = j * 32 + fr;
+        const float sv = p.sc1[n] * acc1_scale, bv = p.b1[n];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float v = fmaxf(fmaf(acc1[j][r], sv, bv), 0.f);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsY, gy[r >> 2],
+                                                  (unsigned)(j * 32 * 4 + qpix(r & 3) * P * 4), 0);
+            if (gy[r >> 2] != OOR) y_amax = fmaxf(y_amax, v);
+        }
+    }
+    // ---- maxima for the consumers' fp16 scales: one filtered atomic per workgroup and tensor ------------------
+    y_amax = wave_max(y_amax);
+    float* red = (float*)W3b;                           // (past the last barrier: the weight slabs are dead)
+    if (lane == 0) { red[wave] = x_amax; red[4 + wave] = y_amax; }
+    __syncthreads();
+    if (tid == 0) {
+        const float xm = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        const float ym = fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7]));
+        if (p.x_absmax && xm > *(volatile const float*)p.x_absmax) atomicMax((unsigned*)p.x_absmax, __float_as_uint(xm));
+        if (p.y1_absmax && ym > *(volatile const float*)p.y1_absmax) atomicMax((unsigned*)p.y1_absmax, __float_as_uint(ym));
+    }
+}
+
+}  // namespace
+
+// see include/dbmm.h
+extern "C" int dbmm_bottleneck_chain_x2(const float* y2, const float* y2_absmax, const void* w3_plane_f16, int w3_exp,
+                                        const float* scale3, const float* bias3, const float* residual, float* x_out,
+                                        float* x_pooled, float* x_absmax, const void* w1_plane_f16, int w1_exp,
+                                        const float* scale1, const float* bias1, float* y1_out, float* y1_absmax,
+                                        int64_t B, int64_t Ho, int64_t Wo, int64_t K, int64_t N, int64_t P, void* stream) {
+    if (!y2 || !y2_absmax || !w3_plane_f16 || !scale3 || !bias3 || !residual || !x_out || !w1_plane_f16 || !scale1 || !bias1 ||
+        !y1_out)
+        return DBMM_E_ARG;
+    if (B <= 0 || Ho <= 0 || Wo <= 0 || K <= 0 || N <= 0 || P <= 0) return DBMM_E_SHAPE;
+    const int64_t M = B * Ho * Wo;
+    if (M > (INT32_MAX >> 1)) return DBMM_E_SHAPE;
+    if (M & 3) return DBMM_E_UNSUPPORTED;               // the kernel validates rows in groups of 4
+    if ((K != 64 && K != 128) || (N % 64) != 0 || (P != 64 && P != 128)) return DBMM_E_UNSUPPORTED;
+    if (w3_exp < -40 || w3_exp > 40 || w1_exp < -40 || w1_exp > 40) return DBMM_E_UNSUPPORTED;
+    if (x_pooled && ((Ho & 1) || (Wo & 1))) return DBMM_E_UNSUPPORTED;
+    if (!dbmm_aligned16(y2) || !dbmm_aligned16(w3_plane_f16) || !dbmm_aligned16(w1_plane_f16) || !dbmm_aligned16(residual) ||
+        !dbmm_aligned16(x_out) || !dbmm_aligned16(y1_out) || (x_pooled && !dbmm_aligned16(x_pooled)))
+        return DBMM_E_ALIGN;
+    ChainP p{};
+    p.a = y2; p.a_absmax = y2_absmax;
+    p.w3 = (const u16*)w3_plane_f16; p.w3_exp = w3_exp; p.sc3 = scale3; p.b3 = bias3;
+    p.res = residual; p.x = x_out; p.xp = x_pooled; p.x_absmax = x_absmax;
+    p.w1 = (const u16*)w1_plane_f16; p.w1_exp = w1_exp; p.sc1 = scale1; p.b1 = bias1;
+    p.y1 = y1_out; p.y1_absmax = y1_absmax;
+    p.M = (int)M; p.N = (int)N; p.Ho = (int)Ho; p.Wo = (int)Wo;
+    const dim3 grid((unsigned)((M + BM - 1) / BM));
+    hipStream_t s = (hipStream_t)stream;
+#define CHAIN_LAUNCH(KK, PP, PL) hipLaunchKernelGGL((bottleneck_chain_kernel<KK, PP, PL>), grid, dim3(256), 0, s, p)
+    if (K == 64) {
+        if (x_pooled) { if (P == 64) CHAIN_LAUNCH(64, 64, 1); else CHAIN_LAUNCH(64, 128, 1); }
+        else          { if (P == 64) CHAIN_LAUNCH(64, 64, 0); else CHAIN_LAUNCH(64, 128, 0); }
+    } else {
+        if (x_pooled) { if (P == 64) CHAIN_LAUNCH(128, 64, 1); else CHAIN_LAUNCH(128, 128, 1); }
+        else          { if (P == 64) CHAIN_LAUNCH(128, 64, 0); else CHAIN_LAUNCH(128, 128, 0); }
+    }
+#undef CHAIN_LAUNCH
+    DBMM_CHECK_LAUNCH();
+    return DBMM_OK;
+}

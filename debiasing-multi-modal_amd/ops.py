@@ -69,7 +69,8 @@ class _Timed:
             M, N, K, amode, wmode = self.args
             e1 = torch.cuda.Event(enable_timing=True)
             e1.record()
-            _prof.append((_last_igemm_tag(), 2.0 * M * N * K, self.nbytes, self.e0, e1))
+            tag = _chain_tag if amode == -1 else _last_igemm_tag()
+            _prof.append((tag, 2.0 * M * N * K, self.nbytes, self.e0, e1))
 
 
 _ws_cache = {}
@@ -281,6 +282,42 @@ def gemm_dual(a, a_absmax, w_plane, w_exp, out_scale, a2, a2_absmax, w2_plane, r
     check(rc, "gemm_dual_bn_act_x2")
     t.__exit__(None, None, None)
     return c
+
+
+def bottleneck_chain(y2, y2_absmax, c3, residual, c1, x_absmax=None, y1_absmax=None, pooled=False):
+    """x' = relu(bn3(conv3(y2)) + residual); y1' = relu(bn1'(conv1'(x'))) in ONE launch (dbmm_bottleneck_chain_x2);
+    c3 / c1 = plan entries of the two 1x1 convs (single exact fp16 plane `ph`, `we`, `sc`, `b`).  y2 NHWC [B,H,W,K].
+    Returns (x', y1') or (x', x'_pooled, y1') with pooled=True; None when the library has no kernel for the shape
+    (the caller then runs the two convs)."""
+    require_cuda(y2, residual)
+    _f32c(y2); _f32c(residual)
+    B, H, W, K = y2.shape
+    N, P = c3["ph"].shape[1], c1["ph"].shape[1]
+    if c3["ph"].shape[0] != 1 or c1["ph"].shape[0] != 1 or tuple(residual.shape) != (B, H, W, N):
+        return None
+    if K not in (64, 128) or N % 64 or P not in (64, 128) or (pooled and (H % 2 or W % 2)):     # shapes the library serves
+        return None
+    dev = y2.device
+    x = torch.empty((B, H, W, N), device=dev, dtype=torch.float32)
+    y1 = torch.empty((B, H, W, P), device=dev, dtype=torch.float32)
+    xp = torch.empty((B, H // 2, W // 2, N), device=dev, dtype=torch.float32) if pooled else None
+    M = B * H * W
+    # tagged like an igemm launch for bench.py's per-kernel table: FLOPs of both GEMMs, algorithmic bytes
+    global _chain_tag
+    _chain_tag = f"bottleneck_chain_kernel<{K}, {P}, {int(pooled)}>"
+    t = _Timed(M, N, K + P, -1, 0, 4 * (M * K + 2 * M * N + M * P + (M // 4 * N if pooled else 0)) + 2 * (N * K + P * N))
+    t.__enter__()
+    rc = _lib.lib().dbmm_bottleneck_chain_x2(ptr(y2), ptr(y2_absmax), ptr(c3["ph"]), int(c3["we"]), ptr(c3["sc"]), ptr(c3["b"]),
+                                            ptr(residual), ptr(x), ptr(xp), ptr(x_absmax), ptr(c1["ph"]), int(c1["we"]),
+                                            ptr(c1["sc"]), ptr(c1["b"]), ptr(y1), ptr(y1_absmax), B, H, W, K, N, P, stream())
+    if rc == _lib.E_UNSUPPORTED:
+        return None
+    check(rc, "bottleneck_chain_x2")
+    t.__exit__(None, None, None)
+    return (x, xp, y1) if pooled else (x, y1)
+
+
+_chain_tag = None
 
 
 def conv_stem_s2(x_nchw, w, bias, y_absmax=None):

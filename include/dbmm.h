@@ -176,6 +176,23 @@ int dbmm_gemm_dual_bn_act_x2(const float* a, int64_t lda, const float* a_absmax,
                              float* c_absmax, int64_t M, int64_t N, int act, void* workspace,
                              size_t workspace_bytes, void* stream);
 
+/* conv3 + residual of one bottleneck block chained with conv1 of the NEXT block (clip/model.py:42-55, two
+ * consecutive Bottleneck.forward bodies) in one launch:
+ *   x_out  = relu((y2 @ w3^T) * scale3 + bias3 + residual)        [B*Ho*Wo][N]
+ *   y1_out = relu((x_out @ w1^T) * scale1 + bias1)                [B*Ho*Wo][P]
+ *   x_pooled (optional) = AvgPool2d(2) of x_out                   [B*Ho/2*Wo/2][N]  (next stage's downsample input)
+ * The wide tensor x_out is written once and not read back for conv1.  y2 [B*Ho*Wo][K] fp32 with its device scalar
+ * y2_absmax >= max|y2|; w3_plane_f16 [N][K] / w1_plane_f16 [P][N] = the stored (fp16-exact) weights times
+ * 2^w3_exp / 2^w1_exp as single fp16 planes; scale / bias = eval-mode BatchNorm per channel.  x_absmax / y1_absmax
+ * (optional, zeroed by the caller) receive the maxima for the consumers' fp16 scales.  Same fp16-pair arithmetic
+ * as dbmm_conv_bn_act_x2.  Shapes served: K in {64, 128}, N % 64 == 0, P in {64, 128}, B*Ho*Wo % 4 == 0; DBMM_E_UNSUPPORTED (nothing
+ * launched) otherwise -- the caller then issues the two convs separately. */
+int dbmm_bottleneck_chain_x2(const float* y2, const float* y2_absmax, const void* w3_plane_f16, int w3_exp,
+                             const float* scale3, const float* bias3, const float* residual, float* x_out,
+                             float* x_pooled, float* x_absmax, const void* w1_plane_f16, int w1_exp,
+                             const float* scale1, const float* bias1, float* y1_out, float* y1_absmax,
+                             int64_t B, int64_t Ho, int64_t Wo, int64_t K, int64_t N, int64_t P, void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * Device-side preprocessing (clip/clip.py:79-86: Resize(BICUBIC) -> CenterCrop -> ToTensor ->
  * Normalize) of one decoded RGB uint8 image [H][W][3] resident on the device.  Integer

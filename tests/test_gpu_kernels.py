@@ -830,3 +830,59 @@ def test_operands_over_2gib_stay_on_the_split_kernels():
     assert _last_cfg()[8] == 2 and _last_cfg()[4] == 1, _last_cfg()
     for i in (0, 1440, B - 1):
         assert relerr(yp[i].cpu(), F.avg_pool2d(y[i].permute(2, 0, 1)[None], 2)[0].permute(1, 2, 0).cpu()) < 2e-6, i
+
+
+@pytest.mark.parametrize("B,H,W,K,N,P,pooled", [(8, 56, 56, 64, 256, 64, False), (8, 56, 56, 64, 256, 128, True), (3, 10, 14, 64, 128, 64, False),
+                                                (5, 6, 10, 64, 192, 128, True), (1, 2, 2, 64, 64, 64, True), (40, 56, 56, 64, 256, 64, True),
+                                                (3, 10, 14, 64, 128, 128, False), (16, 28, 28, 128, 512, 128, False),
+                                                (9, 28, 28, 128, 512, 128, True), (3, 10, 14, 128, 256, 64, False),
+                                                (2, 6, 6, 128, 64, 64, True)])
+def test_bottleneck_chain_conv3_residual_then_next_conv1(B, H, W, K, N, P, pooled):
+    """relu(bn3(conv3(y2)) + x) and the NEXT block's relu(bn1(conv1(.))) as one launch (clip/model.py:42-55 twice) ==
+    fp64, and == the two separate fp32-accurate launches; optional 2x2-pooled copy == avg-pool of the written x';
+    maxima == the written tensors' maxima.  Shapes: layer-1 and layer-2 geometry (K = 64 / 128), ragged M (not a
+    multiple of 128), one window."""
+    g = torch.Generator(device=DEV); g.manual_seed(B * 1000 + N + P)
+    y2 = torch.relu(torch.randn((B, H, W, K), device=DEV, generator=g))
+    res = torch.relu(torch.randn((B, H, W, N), device=DEV, generator=g) * 3.0)
+    res[0, 0, 0, :7] = 300.0                                          # one wave's slab maximum far above the others'
+    w3 = (torch.randn((N, K), device=DEV, generator=g) * K ** -0.5).half().float()
+    w1 = (torch.randn((P, N), device=DEV, generator=g) * N ** -0.5).half().float()
+    mk = lambda n: (0.5 + torch.rand((n,), device=DEV, generator=g), torch.randn((n,), device=DEV, generator=g) * 0.1)
+    (s3, b3), (s1, b1) = mk(N), mk(P)
+    p3, e3, n3 = ops.split_planes_f16(w3, allow_single=True); p1, e1, n1 = ops.split_planes_f16(w1, allow_single=True)
+    assert n3 == 1 and n1 == 1
+    c3 = dict(w=w3, ph=p3, we=e3, sc=s3, b=b3); c1 = dict(w=w1, ph=p1, we=e1, sc=s1, b=b1)
+    ya = (y2.abs().max() * 1.3).reshape(1)
+    xam, yam = torch.zeros(1, device=DEV), torch.zeros(1, device=DEV)
+    r = ops.bottleneck_chain(y2, ya, c3, res, c1, xam, yam, pooled=pooled)
+    assert r is not None
+    x, y1 = r[0], r[-1]
+    M = B * H * W
+    xr = torch.relu(y2.view(M, K).double() @ w3.double().t() * s3.double() + b3.double() + res.view(M, N).double())
+    yr = torch.relu(xr @ w1.double().t() * s1.double() + b1.double())
+    assert relerr(x.view(M, N).double().cpu(), xr.cpu()) < 5e-6
+    assert relerr(y1.view(M, P).double().cpu(), yr.cpu()) < 5e-6
+    assert xam.item() == max(x.abs().max().item(), r[1].abs().max().item() if pooled else 0.0) and yam.item() == y1.abs().max().item()
+    if pooled:
+        ref_p = F.avg_pool2d(x.permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1)
+        assert tuple(r[1].shape) == (B, H // 2, W // 2, N) and relerr(r[1].cpu(), ref_p.cpu()) < 2e-6
+    # the two separate launches
+    xu = ops.conv_bn_act(y2, w3, b3, res, 1, 1, 1, 0, ops.ACT_RELU, w_planes_f16=p3, w_exp=e3, x_absmax=ya, out_scale=s3)
+    yu = ops.conv_bn_act(xu, w1, b1, None, 1, 1, 1, 0, ops.ACT_RELU, w_planes_f16=p1, w_exp=e1,
+                         x_absmax=xu.abs().max().reshape(1), out_scale=s1)
+    assert relerr(x.cpu(), xu.cpu()) < 2e-6 and relerr(y1.cpu(), yu.cpu()) < 3e-6
+
+
+def test_bottleneck_chain_reports_unsupported_shapes():
+    g = torch.Generator(device=DEV); g.manual_seed(3)
+    mk = lambda n, k: (torch.randn((n, k), device=DEV, generator=g) * k ** -0.5).half().float()
+    def entry(w):
+        ph, we, _ = ops.split_planes_f16(w, allow_single=True)
+        return dict(w=w, ph=ph, we=we, sc=torch.ones(w.shape[0], device=DEV), b=torch.zeros(w.shape[0], device=DEV))
+    y = torch.rand((2, 4, 4, 256), device=DEV); res = torch.rand((2, 4, 4, 1024), device=DEV)
+    assert ops.bottleneck_chain(y, y.max().reshape(1), entry(mk(1024, 256)), res, entry(mk(128, 1024))) is None    # K = 256
+    y = torch.rand((2, 4, 4, 64), device=DEV); res = torch.rand((2, 4, 4, 256), device=DEV)
+    assert ops.bottleneck_chain(y, y.max().reshape(1), entry(mk(256, 64)), res, entry(mk(256, 256))) is None        # P = 256
+    y = torch.rand((1, 3, 3, 64), device=DEV); res = torch.rand((1, 3, 3, 256), device=DEV)
+    assert ops.bottleneck_chain(y, y.max().reshape(1), entry(mk(256, 64)), res, entry(mk(64, 256))) is None         # M % 4 != 0
