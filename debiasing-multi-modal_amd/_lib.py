@@ -78,6 +78,7 @@ _SIGS = {
     "dbmm_gemm_bias_act_x2": [_P, _L, _P, _P, _P, _I, _I, _L, _P, _P, _P, _L, _P, _L, _P, _L, _L, _L, _F, _I, _P, _Z, _P],
     "dbmm_gemm_dual_bn_act_x2": [_P, _L, _P, _P, _I, _L, _L, _P, _P, _L, _P, _P, _L, _L, _P, _P, _P, _L, _P, _L, _L, _I, _P, _Z, _P],
     "dbmm_bottleneck_chain_x2": [_P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _L, _L, _L, _L, _L, _L, _P],
+    "dbmm_bottleneck_chain_dual_x2": [_P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _L, _L, _L, _L, _L, _P],
     "dbmm_gemm_bias_act_x3": [_P, _L, _P, _P, _L, _P, _P, _L, _P, _L, _L, _L, _L, _F, _I, _P, _Z, _P],
     "dbmm_gemm_batched": [_P, _L, _L, _I, _P, _L, _L, _I, _P, _L, _P, _L, _L, _L, _L, _L, _L, _F, _I, _P],
     "dbmm_conv_stem_s2": [_P, _P, _P, _P, _P, _L, _L, _L, _L, _P],

@@ -278,6 +278,17 @@ class ModifiedResNet(nn.Module):
                 if "ds" in e:
                     if e["stride"] > 1:
                         identity = x_pooled if (x_pooled is not None and e["stride"] == 2) else ops.avgpool2d(x, e["stride"])
+                    nxt = blocks[bi] if bi < len(blocks) else None
+                    if ("dual" in e and track and _FUSE_DS and _FUSE_CHAIN and e["stride"] == 1 and nxt is not None
+                            and nxt["c1"]["sc"] is not None and nxt["c1"]["ph"] is not None and "ds" not in nxt):
+                        # ... and the same launch continues into the next block's conv1 (layer 1's first block)
+                        x_am, y1_am = amax[slot[0]:slot[0] + 1], amax[slot[0] + 2:slot[0] + 3]
+                        r = ops.bottleneck_chain_dual(out, oam, e["c3"], identity, am, e["ds"], e["dual"]["ratio"],
+                                                      e["dual"]["bias"], nxt["c1"], x_am, y1_am)
+                        if r is not None:
+                            slot[0] += 3                  # conv3's and the branch's slots, and the next conv1's
+                            x, am, x_pooled, y1_next = r[0], x_am, None, (r[1], y1_am)
+                            continue
                     if "dual" in e and track and _FUSE_DS:
                         # out = relu(bn3(conv3(out)) + bn_d(conv_d(identity))) in one launch: the branch
                         # output is never materialised

@@ -46,6 +46,10 @@ struct ChainP {
     float* y1; float* y1_absmax;                            // [M][P]
     int M, N;
     int Ho, Wo;                                             // POOL: map of the M = B * Ho * Wo pixels
+    // DUAL (first block of a stage, clip/model.py:36-38,52): instead of adding a residual the block adds its
+    // downsample branch bn_d(conv_d(a2)).  Like dbmm_gemm_dual_bn_act_x2 the branch's K2 = 64 chunk is accumulated
+    // first, the accumulators are multiplied by ratio[n] * 2^(s - s2) and the main pair continues in them.
+    const float* a2; const float* a2_absmax; const u16* wd; const float* ratio;     // a2 [M][64], wd [N][64] fp16 plane
 };
 
 __device__ __forceinline__ int scale_exp(float amax) {      // s with amax * 2^s in [2^13, 2^14)
@@ -101,18 +105,20 @@ __device__ __forceinline__ int row_pixel(const ChainP& p, int m) {
     return (n * p.Ho + 2 * hp + (q >> 1)) * p.Wo + 2 * (rem - hp * wp2) + (q & 1);
 }
 
-template <int K, int P, int POOL>
+template <int K, int P, int POOL, int DUAL = 0>
 __global__ __launch_bounds__(256, 2) void bottleneck_chain_kernel(const ChainP p) {
+    static_assert(!DUAL || K == 64, "dual-source variant: layer-1 geometry (K = K2 = 64)");
     static_assert(K == 64 || K == 128, "conv3 reduction depth: 64 (layer 1) or 128 (layer 2)");
     static_assert(P == 64 || P == 128, "conv1' width");
     using G = ChainGeo<K, P>;
     constexpr int BNS = G::BNS, SLROW = G::SLROW;
     constexpr int KS = K / 16, TN3 = BNS / 32, TN1 = P / 32;
-    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[G::LDS_BYTES];
+    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[G::LDS_BYTES + (DUAL ? BNS * 64 * 2 : 0)];
     u16* Ay = (u16*)lds_raw;                                       // [2 planes][128][64] (prologue only)
     float* slab = (float*)lds_raw;                                 // [4 waves][32][SLROW]   (aliases Ay)
     u16* W3b = (u16*)(lds_raw + G::R1_BYTES);                      // [BNS][K]
     u16* W1b = (u16*)(lds_raw + G::R1_BYTES + G::W3_BYTES);        // [P][BNS]
+    u16* Wdb = (u16*)(lds_raw + G::R1_BYTES + G::W3_BYTES + G::W1_BYTES);   // DUAL: [BNS][64]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 31, fh = lane >> 5;
@@ -123,7 +129,8 @@ __global__ __launch_bounds__(256, 2) void bottleneck_chain_kernel(const ChainP p
     const int g0 = row_pixel<POOL>(p, m0);
     const long long Mll = p.M;
     const __amdgpu_buffer_rsrc_t rsA = desc(p.a, Mll * K * 4, (long long)g0 * K * 4);
-    const __amdgpu_buffer_rsrc_t rsR = desc(p.res, Mll * p.N * 4, (long long)g0 * p.N * 4);
+    const __amdgpu_buffer_rsrc_t rsR = DUAL ? desc(p.a2, Mll * 64 * 4, (long long)g0 * 64 * 4)      // DUAL: the branch input
+                                            : desc(p.res, Mll * p.N * 4, (long long)g0 * p.N * 4);
     const __amdgpu_buffer_rsrc_t rsX = desc(p.x, Mll * p.N * 4, (long long)g0 * p.N * 4);
     const __amdgpu_buffer_rsrc_t rsY = desc(p.y1, Mll * P * 4, (long long)g0 * P * 4);
     __amdgpu_buffer_rsrc_t rsXP = rsX;
@@ -149,11 +156,13 @@ __global__ __launch_bounds__(256, 2) void bottleneck_chain_kernel(const ChainP p
     constexpr int CPR1 = BNS / 8, RPP1 = 256 / CPR1, W1LD = P * CPR1 / 256;
     static_assert(W3LD >= 1 && W1LD >= 1, "weight slabs smaller than one pass of the workgroup");
     const int wc3 = tid % CPR3, wr3 = tid / CPR3, wc1 = tid % CPR1, wr1 = tid / CPR1;
-    u32x4 w3r[W3LD], w1r[W1LD];
+    u32x4 w3r[W3LD], w1r[W1LD], wdr[DUAL ? W3LD : 1];
     auto load_w = [&](int nt) {
 #pragma unroll
-        for (int j = 0; j < W3LD; ++j)
+        for (int j = 0; j < W3LD; ++j) {
             w3r[j] = *(const u32x4*)(p.w3 + (size_t)(nt * BNS + wr3 + RPP3 * j) * K + wc3 * 8);
+            if constexpr (DUAL) wdr[j] = *(const u32x4*)(p.wd + (size_t)(nt * BNS + wr3 + RPP3 * j) * 64 + wc3 * 8);
+        }
 #pragma unroll
         for (int j = 0; j < W1LD; ++j)
             w1r[j] = *(const u32x4*)(p.w1 + (size_t)(wr1 + RPP1 * j) * p.N + nt * BNS + wc1 * 8);
@@ -163,6 +172,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck_chain_kernel(const ChainP p
         for (int j = 0; j < W3LD; ++j) {
             const int row = wr3 + RPP3 * j;
             *(u32x4*)(W3b + row * K + ((wc3 ^ swz<K>(row)) << 3)) = w3r[j];
+            if constexpr (DUAL) *(u32x4*)(Wdb + row * 64 + ((wc3 ^ swz<64>(row)) << 3)) = wdr[j];
         }
 #pragma unroll
         for (int j = 0; j < W1LD; ++j) {
@@ -172,8 +182,9 @@ __global__ __launch_bounds__(256, 2) void bottleneck_chain_kernel(const ChainP p
     };
     load_w(0);
     // residual slab nt: this lane's 16 rows x TN3 column blocks, element (row r, col j*32 + fr)
-    float rr[TN3][16];
+    float rr[DUAL ? 1 : TN3][16];
     auto load_res = [&](int nt) {
+        if constexpr (DUAL) return;
 #pragma unroll
         for (int j = 0; j < TN3; ++j)
 #pragma unroll
@@ -185,43 +196,53 @@ __global__ __launch_bounds__(256, 2) void bottleneck_chain_kernel(const ChainP p
     // y2, 64 k at a time: 128 rows x 16 quads, thread (lc = tid & 15, lr = tid >> 4) loads rows lr + 16 i, splits them
     // into (hi, lo) fp16 planes in LDS; then every wave reads the A fragments of its 32 rows into registers, where they
     // stay for the whole tile: lane (row fr, k half fh) holds 8 k values per 16-deep step
-    const float a_sc = pow2f(scale_exp(*p.a_absmax));
-    u32x4 af[KS][2];
-#pragma unroll
-    for (int kp = 0; kp < K / 64; ++kp) {
+    u32x4 af[KS][2], af2[DUAL ? 4 : 1][2];
+    bool first_pass = true;
+    // one 64-wide k pass of an A operand (row pitch `ldk` floats, k offset `k0`) -> 4 fragment steps
+    auto stage_pass = [&](const __amdgpu_buffer_rsrc_t& rs, int ldk, int k0, float sc, u32x4 (*dst)[2]) {
         const int lc = tid & 15, lr = tid >> 4;
         f32x4 q[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int row = lr + 16 * i, m = m0 + row;
-            const unsigned off = m < p.M ? (unsigned)(row_pixel<POOL>(p, m) - g0) * (unsigned)(K * 4) + lc * 16u : OOR;
-            q[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, off, (unsigned)(kp * 256), 0));
+            const unsigned off = m < p.M ? (unsigned)(row_pixel<POOL>(p, m) - g0) * (unsigned)(ldk * 4) + lc * 16u : OOR;
+            q[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, (unsigned)(k0 * 4), 0));
         }
-        if (kp) __syncthreads();                          // the previous pass's fragments have been read
+        if (!first_pass) __syncthreads();                 // the previous pass's fragments have been read
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int row = lr + 16 * i;
             unsigned hp[2], lp[2];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) split2h_pair(q[i][2 * j], q[i][2 * j + 1], a_sc, hp[j], lp[j]);
+            for (int j = 0; j < 2; ++j) split2h_pair(q[i][2 * j], q[i][2 * j + 1], sc, hp[j], lp[j]);
             const int off = row * 64 + (((lc >> 1) ^ swz<64>(row)) << 3) + ((lc & 1) << 2);
             *(u32x2*)(Ay + off) = (u32x2){hp[0], hp[1]};
             *(u32x2*)(Ay + BM * 64 + off) = (u32x2){lp[0], lp[1]};
         }
-        if (kp == 0) store_w();
+        if (first_pass) store_w();
+        first_pass = false;
         __syncthreads();
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             const int row = wave * 32 + fr;
             const int off = row * 64 + (((2 * ks + fh) ^ swz<64>(row)) << 3);
-            af[kp * 4 + ks][0] = *(const u32x4*)(Ay + off);
-            af[kp * 4 + ks][1] = *(const u32x4*)(Ay + BM * 64 + off);
+            dst[ks][0] = *(const u32x4*)(Ay + off);
+            dst[ks][1] = *(const u32x4*)(Ay + BM * 64 + off);
         }
+    };
+    const int s_a = scale_exp(*p.a_absmax);
+#pragma unroll
+    for (int kp = 0; kp < K / 64; ++kp) stage_pass(rsA, K, kp * 64, pow2f(s_a), af + kp * 4);
+    float dual_dyn = 1.f;
+    if constexpr (DUAL) {
+        const int s_a2 = scale_exp(*p.a2_absmax);
+        stage_pass(rsR, 64, 0, pow2f(s_a2), af2);
+        dual_dyn = pow2f(s_a - s_a2);
     }
     __syncthreads();                                    // the y2 planes are dead: the region becomes the slab
 
     float* Ls = slab + wave * (32 * SLROW);
-    const float acc3_scale = pow2f(-scale_exp(*p.a_absmax) - p.w3_exp);
+    const float acc3_scale = pow2f(-s_a - p.w3_exp);
     f32x16 acc1[TN1];
 #pragma unroll
     for (int j = 0; j < TN1; ++j)
@@ -239,6 +260,29 @@ __global__ __launch_bounds__(256, 2) void bottleneck_chain_kernel(const ChainP p
         for (int j = 0; j < TN3; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc3[j][r] = 0.f;
+        if constexpr (DUAL) {                            // downsample branch first, then into the main pair's units
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                u32x4 wf[TN3];
+#pragma unroll
+                for (int j = 0; j < TN3; ++j) {
+                    const int row = j * 32 + fr;
+                    wf[j] = *(const u32x4*)(Wdb + row * 64 + (((2 * ks + fh) ^ swz<64>(row)) << 3));
+                }
+#pragma unroll
+                for (int pl = 1; pl >= 0; --pl)
+#pragma unroll
+                    for (int j = 0; j < TN3; ++j)
+                        acc3[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af2[ks][pl]),
+                                                                         __builtin_bit_cast(f16x8, wf[j]), acc3[j], 0, 0, 0);
+            }
+#pragma unroll
+            for (int j = 0; j < TN3; ++j) {
+                const float rt = p.ratio[n0 + j * 32 + fr] * dual_dyn;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc3[j][r] *= rt;
+            }
+        }
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             u32x4 wf[TN3];
@@ -262,7 +306,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck_chain_kernel(const ChainP p
             const float sv = p.sc3[n] * acc3_scale, bv = p.b3[n];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                float v = fmaxf(fmaf(acc3[j][r], sv, bv) + rr[j][r], 0.f);
+                float v = fmaxf(fmaf(acc3[j][r], sv, bv) + (DUAL ? 0.f : rr[j][r]), 0.f);
                 if (gx[r >> 2] == OOR) v = 0.f;          // rows past M: keep the slab clean (their stores are dropped)
                 acc3[j][r] = v;
                 tmax = fmaxf(tmax, v);
@@ -358,6 +402,37 @@ __global__ __launch_bounds__(256, 2) void bottleneck_chain_kernel(const ChainP p
 }  // namespace
 
 // see include/dbmm.h
+extern "C" int dbmm_bottleneck_chain_dual_x2(const float* y2, const float* y2_absmax, const void* w3_plane_f16, int w3_exp,
+                                             const float* scale3, const float* bias, const float* a2, const float* a2_absmax,
+                                             const void* wd_plane_f16, const float* ratio, float* x_out, float* x_absmax,
+                                             const void* w1_plane_f16, int w1_exp, const float* scale1, const float* bias1,
+                                             float* y1_out, float* y1_absmax, int64_t M, int64_t K, int64_t K2, int64_t N,
+                                             int64_t P, void* stream) {
+    if (!y2 || !y2_absmax || !w3_plane_f16 || !scale3 || !bias || !a2 || !a2_absmax || !wd_plane_f16 || !ratio || !x_out ||
+        !w1_plane_f16 || !scale1 || !bias1 || !y1_out)
+        return DBMM_E_ARG;
+    if (M <= 0 || K <= 0 || K2 <= 0 || N <= 0 || P <= 0 || M > (INT32_MAX >> 1)) return DBMM_E_SHAPE;
+    if (K != 64 || K2 != 64 || (N % 64) != 0 || (P != 64 && P != 128) || (M & 3)) return DBMM_E_UNSUPPORTED;
+    if (w3_exp < -40 || w3_exp > 40 || w1_exp < -40 || w1_exp > 40) return DBMM_E_UNSUPPORTED;
+    if (!dbmm_aligned16(y2) || !dbmm_aligned16(a2) || !dbmm_aligned16(w3_plane_f16) || !dbmm_aligned16(wd_plane_f16) ||
+        !dbmm_aligned16(w1_plane_f16) || !dbmm_aligned16(x_out) || !dbmm_aligned16(y1_out))
+        return DBMM_E_ALIGN;
+    ChainP p{};
+    p.a = y2; p.a_absmax = y2_absmax;
+    p.w3 = (const u16*)w3_plane_f16; p.w3_exp = w3_exp; p.sc3 = scale3; p.b3 = bias;
+    p.a2 = a2; p.a2_absmax = a2_absmax; p.wd = (const u16*)wd_plane_f16; p.ratio = ratio;
+    p.x = x_out; p.x_absmax = x_absmax;
+    p.w1 = (const u16*)w1_plane_f16; p.w1_exp = w1_exp; p.sc1 = scale1; p.b1 = bias1;
+    p.y1 = y1_out; p.y1_absmax = y1_absmax;
+    p.M = (int)M; p.N = (int)N; p.Ho = 1; p.Wo = (int)M;
+    const dim3 grid((unsigned)((M + BM - 1) / BM));
+    hipStream_t s = (hipStream_t)stream;
+    if (P == 64) hipLaunchKernelGGL((bottleneck_chain_kernel<64, 64, 0, 1>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((bottleneck_chain_kernel<64, 128, 0, 1>), grid, dim3(256), 0, s, p);
+    DBMM_CHECK_LAUNCH();
+    return DBMM_OK;
+}
+
 extern "C" int dbmm_bottleneck_chain_x2(const float* y2, const float* y2_absmax, const void* w3_plane_f16, int w3_exp,
                                         const float* scale3, const float* bias3, const float* residual, float* x_out,
                                         float* x_pooled, float* x_absmax, const void* w1_plane_f16, int w1_exp,

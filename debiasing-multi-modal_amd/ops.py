@@ -304,7 +304,7 @@ def bottleneck_chain(y2, y2_absmax, c3, residual, c1, x_absmax=None, y1_absmax=N
     M = B * H * W
     # tagged like an igemm launch for bench.py's per-kernel table: FLOPs of both GEMMs, algorithmic bytes
     global _chain_tag
-    _chain_tag = f"bottleneck_chain_kernel<{K}, {P}, {int(pooled)}>"
+    _chain_tag = f"bottleneck_chain_kernel<{K}, {P}, {int(pooled)}, 0>"
     t = _Timed(M, N, K + P, -1, 0, 4 * (M * K + 2 * M * N + M * P + (M // 4 * N if pooled else 0)) + 2 * (N * K + P * N))
     t.__enter__()
     rc = _lib.lib().dbmm_bottleneck_chain_x2(ptr(y2), ptr(y2_absmax), ptr(c3["ph"]), int(c3["we"]), ptr(c3["sc"]), ptr(c3["b"]),
@@ -318,6 +318,34 @@ def bottleneck_chain(y2, y2_absmax, c3, residual, c1, x_absmax=None, y1_absmax=N
 
 
 _chain_tag = None
+
+
+def bottleneck_chain_dual(y2, y2_absmax, c3, a2, a2_absmax, ds, ratio, bias, c1, x_absmax=None, y1_absmax=None):
+    """first block of a stage at unchanged resolution: x' = relu(bn3(conv3(y2)) + bn_d(conv_d(a2))), then the next
+    block's y1' = relu(bn1'(conv1'(x'))), one launch (dbmm_bottleneck_chain_dual_x2).  Returns (x', y1') or None."""
+    require_cuda(y2, a2)
+    _f32c(y2); _f32c(a2)
+    K, K2 = y2.shape[-1], a2.shape[-1]
+    N, P = c3["ph"].shape[1], c1["ph"].shape[1]
+    M = y2.numel() // K
+    if (c3["ph"].shape[0] != 1 or ds["ph"].shape[0] != 1 or c1["ph"].shape[0] != 1 or a2.numel() // K2 != M
+            or K != 64 or K2 != 64 or N % 64 or P not in (64, 128) or M % 4):
+        return None
+    x = torch.empty(tuple(y2.shape[:-1]) + (N,), device=y2.device, dtype=torch.float32)
+    y1 = torch.empty(tuple(y2.shape[:-1]) + (P,), device=y2.device, dtype=torch.float32)
+    global _chain_tag
+    _chain_tag = f"bottleneck_chain_kernel<{K}, {P}, 0, 1>"
+    t = _Timed(M, N, K + K2 + P, -1, 0, 4 * (M * K + M * K2 + M * N + M * P) + 2 * (N * K + N * K2 + P * N))
+    t.__enter__()
+    rc = _lib.lib().dbmm_bottleneck_chain_dual_x2(ptr(y2), ptr(y2_absmax), ptr(c3["ph"]), int(c3["we"]), ptr(c3["sc"]), ptr(bias),
+                                                 ptr(a2), ptr(a2_absmax), ptr(ds["ph"]), ptr(ratio), ptr(x), ptr(x_absmax),
+                                                 ptr(c1["ph"]), int(c1["we"]), ptr(c1["sc"]), ptr(c1["b"]), ptr(y1),
+                                                 ptr(y1_absmax), M, K, K2, N, P, stream())
+    if rc == _lib.E_UNSUPPORTED:
+        return None
+    check(rc, "bottleneck_chain_dual_x2")
+    t.__exit__(None, None, None)
+    return x, y1
 
 
 def conv_stem_s2(x_nchw, w, bias, y_absmax=None):

@@ -193,6 +193,19 @@ int dbmm_bottleneck_chain_x2(const float* y2, const float* y2_absmax, const void
                              const float* scale1, const float* bias1, float* y1_out, float* y1_absmax,
                              int64_t B, int64_t Ho, int64_t Wo, int64_t K, int64_t N, int64_t P, void* stream);
 
+/* The same chain for the FIRST block of a stage whose input has the output's resolution (layer 1): the block adds
+ * its downsample branch instead of a residual (clip/model.py:36-38,52), as in dbmm_gemm_dual_bn_act_x2:
+ *   x_out  = relu((y2 @ w3^T) * scale3 + (a2 @ wd^T) * scale_d + bias)   with ratio[n] = scale_d[n] / scale3[n] * 2^(w3_exp - wd_exp),
+ *   y1_out = relu((x_out @ w1^T) * scale1 + bias1).
+ * y2 [M][K], a2 [M][K2] (the block input) with device scalars; bias = both BatchNorm biases added.  Served: K = K2 = 64,
+ * N % 64 == 0, P in {64, 128}, M % 4 == 0; DBMM_E_UNSUPPORTED otherwise. */
+int dbmm_bottleneck_chain_dual_x2(const float* y2, const float* y2_absmax, const void* w3_plane_f16, int w3_exp,
+                                  const float* scale3, const float* bias, const float* a2, const float* a2_absmax,
+                                  const void* wd_plane_f16, const float* ratio, float* x_out, float* x_absmax,
+                                  const void* w1_plane_f16, int w1_exp, const float* scale1, const float* bias1,
+                                  float* y1_out, float* y1_absmax, int64_t M, int64_t K, int64_t K2, int64_t N,
+                                  int64_t P, void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * Device-side preprocessing (clip/clip.py:79-86: Resize(BICUBIC) -> CenterCrop -> ToTensor ->
  * Normalize) of one decoded RGB uint8 image [H][W][3] resident on the device.  Integer

@@ -886,3 +886,32 @@ def test_bottleneck_chain_reports_unsupported_shapes():
     assert ops.bottleneck_chain(y, y.max().reshape(1), entry(mk(256, 64)), res, entry(mk(256, 256))) is None        # P = 256
     y = torch.rand((1, 3, 3, 64), device=DEV); res = torch.rand((1, 3, 3, 256), device=DEV)
     assert ops.bottleneck_chain(y, y.max().reshape(1), entry(mk(256, 64)), res, entry(mk(64, 256))) is None         # M % 4 != 0
+
+
+@pytest.mark.parametrize("M,N,P", [(25088, 256, 64), (25088, 256, 128), (300, 128, 64)])
+def test_bottleneck_chain_dual_first_block(M, N, P):
+    """first block of layer 1: relu(bn3(conv3(y2)) + bn_d(conv_d(x))) and the next block's conv1 as one launch == fp64
+    and == the dual-source GEMM followed by the separate conv1."""
+    K = K2 = 64
+    g = torch.Generator(device=DEV); g.manual_seed(M + N + P)
+    y2 = torch.relu(torch.randn((M, K), device=DEV, generator=g)); a2 = torch.relu(torch.randn((M, K2), device=DEV, generator=g) * 4.0)
+    mkw = lambda n, k: (torch.randn((n, k), device=DEV, generator=g) * k ** -0.5).half().float()
+    w3, wd, w1 = mkw(N, K), mkw(N, K2), mkw(P, N)
+    mk = lambda n: (0.5 + torch.rand((n,), device=DEV, generator=g), torch.randn((n,), device=DEV, generator=g) * 0.1)
+    (s3, b3), (sd, bd), (s1, b1) = mk(N), mk(N), mk(P)
+    p3, e3, _ = ops.split_planes_f16(w3, allow_single=True); pd, ed, _ = ops.split_planes_f16(wd, allow_single=True)
+    p1, e1, _ = ops.split_planes_f16(w1, allow_single=True)
+    ratio = (sd.double() / s3.double() * 2.0 ** (e3 - ed)).float()
+    c3 = dict(ph=p3, we=e3, sc=s3, b=b3); ds = dict(ph=pd, we=ed, sc=sd, b=bd); c1 = dict(ph=p1, we=e1, sc=s1, b=b1)
+    ya, xa = y2.abs().max().reshape(1), (a2.abs().max() * 1.9).reshape(1)
+    xam, yam = torch.zeros(1, device=DEV), torch.zeros(1, device=DEV)
+    r = ops.bottleneck_chain_dual(y2, ya, c3, a2, xa, ds, ratio, b3 + bd, c1, xam, yam)
+    assert r is not None
+    x, y1 = r
+    xr = torch.relu(y2.double() @ w3.double().t() * s3.double() + a2.double() @ wd.double().t() * sd.double() + (b3 + bd).double())
+    yr = torch.relu(xr @ w1.double().t() * s1.double() + b1.double())
+    assert relerr(x.double().cpu(), xr.cpu()) < 5e-6 and relerr(y1.double().cpu(), yr.cpu()) < 5e-6
+    assert xam.item() == x.abs().max().item() and yam.item() == y1.abs().max().item()
+    if M >= 24576:                                      # the dual-source GEMM serves grids of >= 192 tiles
+        xu = ops.gemm_dual(y2, ya, p3, e3, s3, a2, xa, pd, ratio, b3 + bd, ops.ACT_RELU)
+        assert xu is not None and relerr(x.cpu(), xu.cpu()) < 2e-6
