@@ -53,8 +53,11 @@ HBM_PEAK_GBS = 8000.0                  # HBM3E spec, same table (measured copy c
 
 
 def kernel_products(tag):
-    """16-bit partial products per fp32 product of an igemm instantiation name (1 = fp32-input MFMA)."""
-    if tag.startswith("igemm_halo_kernel<") or tag.startswith("bottleneck_fused_kernel<"):
+    """16-bit partial products per fp32 product of a kernel name (1 = fp32-input MFMA; 0 = fp16-mode kernel: one fp16
+    product per product, priced against the full 2500 TFLOP/s)."""
+    if tag.startswith(("gemm_f16_kernel", "mha_f16_kernel")):
+        return 0
+    if tag.startswith("igemm_halo_kernel<") or tag.startswith("bottleneck_chain_kernel<"):
         return 2                                                  # fp16 pair x one exact weight plane
     if tag.startswith("igemm_x3_kernel<"):
         a = [v.strip() for v in tag[tag.index("<") + 1:tag.rindex(">")].split(",")]
@@ -69,7 +72,7 @@ def kernel_rows(prof, steps, step_ms, pmc):
         if ms <= 0:
             continue
         nprod = kernel_products(tag)
-        mfma_peak = F16_MFMA_PEAK_TFLOPS / nprod if nprod > 1 else FP32_MFMA_PEAK_TFLOPS
+        mfma_peak = F16_MFMA_PEAK_TFLOPS / max(nprod, 1) if nprod != 1 else FP32_MFMA_PEAK_TFLOPS
         tf, gbs = fl / (ms * 1e-3) / 1e12, by / (ms * 1e-3) / 1e9
         t_mfma, t_hbm = fl / (mfma_peak * 1e12), by / (HBM_PEAK_GBS * 1e9)
         hbm = t_hbm >= t_mfma
@@ -151,9 +154,12 @@ def cpu_baseline(sd, D, paths_unused, bs=32, iters=3):
             "sample": f"oracle (torch-CPU fp32) RN50 encode_image + adapter step, bs={bs}, median of {iters}"}
 
 
-def build_step(arch, dev, world, rank, Bl, D_hidden=128):
+def build_step(arch, dev, world, rank, Bl, D_hidden=128, dtype="f32"):
     sd = synth.clip_state_dict(2, arch)
     model = build_model(sd).to(dev)
+    if dtype == "f16":
+        from dbmm_amd.clip.model import convert_weights
+        convert_weights(model)                          # the reference's GPU path: fp16 weights and activations
     D, R = model.visual.output_dim, model.visual.input_resolution
     paths = write_text_jsons(D)
     ad = adapter.Adapter(D, D_hidden); ad.load_state_dict(synth.adapter_state_dict(3, D, D_hidden))
@@ -171,6 +177,9 @@ def main():
     ap.add_argument("--batch-per-gpu", type=int, default=0,
                     help="default: 1024 at one GPU (the metric's bs=1024), 512 per GPU otherwise (BASELINE configs[2])")
     ap.add_argument("--arch", default="RN50")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "f16"],
+                    help="f32 = parity mode (the headline); f16 = the reference's GPU-path arithmetic, transformer towers only "
+                         "(BASELINE configs[4]: --arch 'ViT-L/14@336px' --dtype f16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fp32-mfma-leg", action="store_true")
     args = ap.parse_args()
@@ -191,10 +200,12 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
-    default_bl = {"RN50": 1024 if world == 1 else 512, "ViT-B/32": 512, "ViT-L/14@336px": 128}
+    if args.dtype == "f16" and args.arch.startswith("RN"):
+        raise SystemExit("--dtype f16 serves the transformer towers (ViT-B/32, ViT-L/14@336px)")
+    default_bl = {"RN50": 1024 if world == 1 else 512, "ViT-B/32": 512, "ViT-L/14@336px": 1024 if args.dtype == "f16" else 128}
     Bl = args.batch_per_gpu or default_bl.get(args.arch, 512)
     B = Bl * world
-    sd, model, D, R, paths, stepper = build_step(args.arch, dev, world, rank, Bl)
+    sd, model, D, R, paths, stepper = build_step(args.arch, dev, world, rank, Bl, dtype=args.dtype)
     # this rank's shard of the global synthetic batch (rows [rank*Bl, (rank+1)*Bl))
     base = synth.images(1000 + rank, min(Bl, 64), R)
     reps = (Bl + base.shape[0] - 1) // base.shape[0]
@@ -240,7 +251,7 @@ def main():
         pmc = None
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc.json")))
-            if pmc.get("arch") != args.arch or pmc.get("batch_per_gpu") != Bl:
+            if pmc.get("arch") != args.arch or pmc.get("batch_per_gpu") != Bl or pmc.get("dtype", "f32") != args.dtype:
                 pmc = None
         except (OSError, ValueError):
             pass
@@ -263,14 +274,20 @@ def main():
         roof["end_to_end_over_fp32_mfma_peak"] = round(
             value / world * GFLOP_PER_IMG.get(args.arch, float("nan")) * 1e9 / (FP32_MFMA_PEAK_TFLOPS * 1e12), 4)
         cfgs = {("RN50", 1, 1024): "the metric's configuration, CLIP-RN50 224px bs=1024 on one GPU",
-                ("RN50", 1, 512): "BASELINE configs[1]", ("RN50", 2, 512): "BASELINE configs[2]"}
+                ("RN50", 1, 512): "BASELINE configs[1]", ("RN50", 2, 512): "BASELINE configs[2]",
+                ("ViT-B/32", 8, 512): "BASELINE configs[3]", ("ViT-L/14@336px", 8, 1024): "BASELINE configs[4]",
+                ("ViT-L/14@336px", 1, 1024): "one GPU's share of BASELINE configs[4]"}
         line = {
             "metric": f"images/sec (embed+adapter step), CLIP-{args.arch} {R}px bs={B}", "value": round(value, 2),
             "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(step_ms, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32",
-            "dtype_detail": "fp32 activations/accumulators; products on 16-bit MFMA as fp16 hi+lo pair (22-bit mantissa, "
-                            "exact per-tensor power-of-two scale) x fp16-exact checkpoint weight; parity suite at 1e-3 logits",
+            "vs_baseline": None, "dtype": args.dtype,
+            "dtype_detail": ("fp16 weights and activations in HBM, one fp16 MFMA per product, fp32 accumulate, fp32 LayerNorm / "
+                             "softmax statistics (the reference's GPU path); adapter step in fp32 on the .float() embeddings; "
+                             "parity unpinned vs the reference's fp16 path, pinned to the fp32 goldens at 1e-2"
+                             if args.dtype == "f16" else
+                             "fp32 activations/accumulators; products on 16-bit MFMA as fp16 hi+lo pair (22-bit mantissa, "
+                             "exact per-tensor power-of-two scale) x fp16-exact checkpoint weight; parity suite at 1e-3 logits"),
             "data": "synthetic",
             "config": {"workload": f"CLIP-{args.arch} {R}px encode_image + adapter({D}-128-{D}) CE/SGD step, {Bl} images/GPU, "
                                    f"global batch {B}" + (f" ({cfgs[(args.arch, world, Bl)]})" if (args.arch, world, Bl) in cfgs else ""),
@@ -278,7 +295,7 @@ def main():
                        "collective": "all_gather(embeddings+labels) per step" if world > 1 else "none"},
             "roofline": roof,
         }
-        if world == 1 and not args.no_fp32_mfma_leg and args.arch.startswith("RN"):
+        if world == 1 and not args.no_fp32_mfma_leg and args.arch.startswith("RN") and args.dtype == "f32":
             line["fp32_input_mfma"] = fp32_mfma_leg(args.arch, dev, Bl, images, y_l, g_l)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(sd, D, paths)

@@ -79,6 +79,14 @@ _SIGS = {
     "dbmm_gemm_dual_bn_act_x2": [_P, _L, _P, _P, _I, _L, _L, _P, _P, _L, _P, _P, _L, _L, _P, _P, _P, _L, _P, _L, _L, _I, _P, _Z, _P],
     "dbmm_bottleneck_chain_x2": [_P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _L, _L, _L, _L, _L, _L, _P],
     "dbmm_bottleneck_chain_dual_x2": [_P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _L, _L, _L, _L, _L, _P],
+    "dbmm_gemm_f16": [_P, _L, _P, _L, _P, _P, _L, _P, _L, _L, _L, _L, _I, _P],
+    "dbmm_mha_core_f16": [_P, _P, _L, _L, _L, _L, _I, _P],
+    "dbmm_layernorm_f16": [_P, _L, _P, _P, _P, _L, _L, _L, _F, _P],
+    "dbmm_im2col_patch_f16": [_P, _I, _P, _L, _L, _L, _L, _P],
+    "dbmm_vit_tokens_f16": [_P, _P, _P, _P, _L, _L, _L, _P],
+    "dbmm_embed_gather_f16": [_P, _P, _P, _P, _L, _L, _L, _L, _P],
+    "dbmm_gather_eot_f16": [_P, _P, _P, _L, _L, _L, _P],
+    "dbmm_cast_f32_f16": [_P, _P, _L, _P],
     "dbmm_gemm_bias_act_x3": [_P, _L, _P, _P, _L, _P, _P, _L, _P, _L, _L, _L, _L, _F, _I, _P, _Z, _P],
     "dbmm_gemm_batched": [_P, _L, _L, _I, _P, _L, _L, _I, _P, _L, _P, _L, _L, _L, _L, _L, _L, _F, _I, _P],
     "dbmm_conv_stem_s2": [_P, _P, _P, _P, _P, _L, _L, _L, _L, _P],

@@ -3,15 +3,25 @@
 What is kept: the OpenAI state-dict key names, `build_model`
 inferring the architecture from key shapes (clip/model.py:399-436), `CLIP.encode_image`,
 `CLIP.encode_text`, `CLIP.forward`, `.dtype`, `.visual.input_resolution`, `.logit_scale`
-(clip/model.py:336-372), and the nn.Module protocol (`.cuda()`, `.eval()`, `state_dict()`).
+(clip/model.py:336-372), `convert_weights`, and the nn.Module protocol (`.cuda()`, `.eval()`,
+`state_dict()`).
 
 What is different: modules here are *parameter holders*; there is no per-layer forward.
-Each tower compiles an execution plan on first use -- BatchNorm folded into the conv
-weights in fp64, conv weights repacked to [Cout][kh][kw][Cin] for the NHWC implicit-GEMM
-kernel, k/v projection weights concatenated -- and `forward` walks that plan calling the
-C ABI (ops.py).  Activations are fp32 NHWC / batch-first tokens.  Compute dtype is fp32
-(fp32-input MFMA), which is what the 1e-3 logit parity against the reference's CPU path
-needs; there is no fp16 cast of the weights, `.dtype` reports float32.
+Each tower compiles an execution plan on first use and `forward` walks that plan calling the C ABI
+(ops.py).  Two arithmetic modes:
+
+  * fp32 parity mode (default; `model.dtype == float32`, what `build_model` returns): activations are fp32
+    NHWC / batch-first tokens in HBM.  Convolutions and GEMMs run on the 16-bit matrix cores with every
+    activation split into an fp16 (hi, lo) pair under an exact per-tensor power-of-two scale and the
+    checkpoint's fp16-exact weight as ONE fp16 plane (two partial products, fp32 accumulate): fp32-level
+    accuracy, which the 1e-3 logit parity against the reference's CPU path needs.  Eval-mode BatchNorm is a
+    per-channel scale / bias in the conv epilogue; ReLU, residual adds and the 2x2 average pools are fused
+    there too; in layers 1-2 conv3 + residual and the next block's conv1 are one launch.
+    DBMM_CONV_SPLIT=bf16 / off select the bf16-triple / fp32-input-MFMA variants of the same arithmetic.
+  * fp16 throughput mode (`convert_weights(model)` or `model.half()`, the reference's GPU path,
+    clip/model.py:375-396): the transformer towers keep fp16 activations in HBM, one fp16 MFMA per product,
+    fp32 accumulation, fp32 LayerNorm / softmax statistics (csrc/f16_ops.hip).  RN towers still compute
+    fp32-accurately in this mode and round their output to fp16.
 """
 import os
 import re
@@ -198,7 +208,7 @@ class ModifiedResNet(nn.Module):
     @torch.no_grad()
     def _compile(self):
         P = {}
-        w, b = _fold_bn(self.conv1.weight, self.bn1)
+        w, b = _fold_bn(self.conv1.weight.float(), self.bn1)
         P["stem1"] = (w.permute(2, 3, 1, 0).contiguous().float(), b.float().contiguous())   # [kh][kw][cin][cout]
         for i in (2, 3):
             P[f"stem{i}"] = _conv_bn(getattr(self, f"conv{i}"), getattr(self, f"bn{i}"))
@@ -234,6 +244,10 @@ class ModifiedResNet(nn.Module):
 
     @torch.no_grad()
     def forward(self, x, return_stages=False):
+        if self.conv1.weight.dtype == torch.float16 and not return_stages:
+            # fp16 mode reaches the RN towers as fp16-stored weights only: the plan computes fp32-accurately from them
+            # (they are fp16-exact, like every checkpoint weight) and the embedding is rounded to the model dtype
+            return self.forward(x, return_stages=True)[0].to(torch.float16)
         if self._plan is not None and self._plan_key != self._param_key():
             self._plan = None
         P = self._plan or self._compile()
@@ -386,6 +400,39 @@ class Transformer(nn.Module):
         return self._planes
 
     @torch.no_grad()
+    def _f16_plan(self):
+        """fp16 mode: projection weights as contiguous fp16 [N][K] (already fp16 after convert_weights), biases and
+        LayerNorm parameters in fp32; rebuilt when a parameter is replaced or edited."""
+        key = tuple((t.data_ptr(), t._version, t.dtype) for t in self.parameters())
+        if getattr(self, "_f16", None) is None or self._f16[0] != key:
+            h = lambda t: t.detach().to(torch.float16).contiguous()
+            f = lambda t: t.detach().float().contiguous()
+            plan = []
+            for b in self.resblocks:
+                plan.append(dict(ln1=(f(b.ln_1.weight), f(b.ln_1.bias)), ln2=(f(b.ln_2.weight), f(b.ln_2.bias)),
+                                 w_in=h(b.attn.in_proj_weight), b_in=f(b.attn.in_proj_bias),
+                                 w_out=h(b.attn.out_proj.weight), b_out=f(b.attn.out_proj.bias),
+                                 w_fc=h(b.mlp.c_fc.weight), b_fc=f(b.mlp.c_fc.bias),
+                                 w_proj=h(b.mlp.c_proj.weight), b_proj=f(b.mlp.c_proj.bias)))
+            self._f16 = (key, plan)
+        return self._f16[1]
+
+    @torch.no_grad()
+    def run_f16(self, x, B, L):
+        """fp16 mode (clip/model.py:185-192 with fp16 activations): x f16 [B*L, E]; bias / QuickGELU / residual adds in
+        the GEMM epilogues, LayerNorm statistics and softmax in fp32."""
+        E = self.width
+        for e in self._f16_plan():
+            h = ops.layernorm_f16(x, *e["ln1"])
+            qkv = ops.gemm_f16(h, e["w_in"], e["b_in"])
+            o = ops.mha_core_f16(qkv, B, L, E, self.heads, self.causal)
+            x = ops.gemm_f16(o, e["w_out"], e["b_out"], residual=x)
+            h = ops.layernorm_f16(x, *e["ln2"])
+            h = ops.gemm_f16(h, e["w_fc"], e["b_fc"], act=ops.ACT_QUICKGELU)
+            x = ops.gemm_f16(h, e["w_proj"], e["b_proj"], residual=x)
+        return x
+
+    @torch.no_grad()
     def run(self, x, B, L):
         """x [B*L, E] batch-first rows.  Pre-LN blocks (clip/model.py:189-192): the residual
         adds and QuickGELU are GEMM epilogues.  Every GEMM input carries a device scalar with (a
@@ -425,7 +472,38 @@ class VisionTransformer(nn.Module):
         self.proj = nn.Parameter(scale * torch.randn(width, output_dim))
 
     @torch.no_grad()
+    def forward_f16(self, x):
+        """fp16 mode: patch GEMM (K zero-padded to a multiple of 64), fp16 token stream, fp16 output [B, D]."""
+        x = x.contiguous()
+        if x.dtype not in (torch.float16, torch.float32):
+            x = x.float()
+        B = x.shape[0]
+        W = self.conv1.weight.shape[0]
+        L = self.positional_embedding.shape[0]
+        K = 3 * self.patch_size ** 2
+        Kp = (K + 63) // 64 * 64
+        key = tuple((t.data_ptr(), t._version, t.dtype) for t in (self.conv1.weight, self.proj, self.class_embedding,
+                                                                    self.positional_embedding, self.ln_pre.weight, self.ln_post.weight))
+        if getattr(self, "_f16", None) is None or self._f16[0] != key:
+            w1 = torch.zeros((W, Kp), device=x.device, dtype=torch.float16)
+            w1[:, :K] = self.conv1.weight.detach().reshape(W, K).to(torch.float16)
+            f = lambda t: t.detach().float().contiguous()
+            self._f16 = (key, dict(w1=w1, proj_t=self.proj.detach().t().to(torch.float16).contiguous(), cls=f(self.class_embedding),
+                                   pos=f(self.positional_embedding), ln_pre=(f(self.ln_pre.weight), f(self.ln_pre.bias)),
+                                   ln_post=(f(self.ln_post.weight), f(self.ln_post.bias))))
+        e = self._f16[1]
+        cols = ops.im2col_patch_f16(x, self.patch_size, Kp)                       # [B*g*g, Kp]
+        patches = ops.gemm_f16(cols, e["w1"])                                      # conv1 has no bias
+        t = ops.vit_tokens_f16(patches, e["cls"], e["pos"], B)
+        t = ops.layernorm_f16(t, *e["ln_pre"])
+        t = self.transformer.run_f16(t, B, L)
+        c = ops.layernorm_f16(t, *e["ln_post"], rows=B, ldx=L * W)                 # token 0 only
+        return ops.gemm_f16(c, e["proj_t"])
+
+    @torch.no_grad()
     def forward(self, x):
+        if self.conv1.weight.dtype == torch.float16:
+            return self.forward_f16(x)
         x = x.float().contiguous()
         B = x.shape[0]
         W = self.conv1.weight.shape[0]
@@ -478,6 +556,13 @@ class CLIP(nn.Module):
 
     @torch.no_grad()
     def encode_text(self, text):
+        if self.dtype == torch.float16:                 # fp16 mode (clip/model.py:343-356 with fp16 activations)
+            x, tok = ops.embed_gather_f16(text, self.token_embedding.weight.float(), self.positional_embedding.float())
+            n, L, W = x.shape
+            x = self.transformer.run_f16(x.view(n * L, W), n, L)
+            e = ops.gather_eot_f16(tok, x.view(n, L, W))
+            e = ops.layernorm_f16(e, self.ln_final.weight.float().contiguous(), self.ln_final.bias.float().contiguous())
+            return ops.gemm_f16(e, self.text_projection.detach().t().to(torch.float16).contiguous())
         x, tok = ops.embed_gather(text, self.token_embedding.weight, self.positional_embedding)
         n, L, W = x.shape
         x = self.transformer.run(x.view(n * L, W), n, L)
@@ -497,8 +582,21 @@ class CLIP(nn.Module):
 
 
 def convert_weights(model: nn.Module):
-    """No-op kept for API compatibility: this build computes in fp32 (see module docstring);
-    the reference's fp16 weight cast (clip/model.py:375-396) is not applied."""
+    """clip/model.py:375-396: conv / linear / attention-projection weights and biases, `text_projection` and `proj` to
+    fp16 in place (BatchNorm, LayerNorm, embeddings stay fp32).  `model.dtype` becomes float16 and the transformer
+    towers switch to the fp16 throughput mode (module docstring); `model.float()` switches back."""
+    def _half(t):
+        if t is not None and t.is_floating_point():
+            t.data = t.data.half()
+
+    for m in model.modules():
+        if isinstance(m, (_ConvW, _LinearW)):
+            _half(m.weight); _half(getattr(m, "bias", None))
+        if isinstance(m, _AttnParams):
+            _half(m.in_proj_weight); _half(m.in_proj_bias)
+        for name in ("text_projection", "proj"):
+            if isinstance(getattr(m, name, None), nn.Parameter):
+                _half(getattr(m, name))
     return model
 
 

@@ -1,0 +1,569 @@
+// fp16 mode of the transformer towers (the reference's GPU path: convert_weights, clip/model.py:375-396, and
+// `model.half()` semantics, clip/clip.py:139-141): activations are fp16 in HBM, every product is ONE fp16 MFMA
+// (v_mfma_f32_32x32x16_f16) with fp32 accumulation, LayerNorm statistics / softmax / bias / QuickGELU / residual adds
+// are computed in fp32 and rounded to fp16 once when stored (the reference's LayerNorm subclass also computes in
+// fp32, clip/model.py:157-163).  This is the throughput mode BASELINE configs[4] names; the fp32-accurate path
+// (igemm_f32.hip) stays the parity mode.
+//
+//   gemm_f16_kernel      C = act(A . W^T + bias) + R          128x128x64 tiles, register-staged double buffer
+//   mha_f16_kernel       softmax(Q K^T / 8) V, head_dim 64     flash style, S^T = K Q^T so a query is a lane
+//   layernorm_f16_kernel wave per row, fp32 statistics
+//   im2col / tokens / embedding gather / EOT gather            layout kernels with fp16 output
+//
+// Bounds: GEMM and attention MFMA (2500 TFLOP/s dense fp16), the rest HBM.
+#include <stdlib.h>
+#include "common.h"
+
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u16;
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr unsigned OOR = 0x80000000u;
+constexpr long long EXT_LIM = 0x7FFFFFF0LL;
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t desc(const void* base, long long total, long long shift) {
+    long long ext = total - shift;
+    ext = ext < 0 ? 0 : (ext > EXT_LIM ? EXT_LIM : ext);
+    return __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)base + shift), 0, (int)ext, 0x00020000);
+}
+// 128-B LDS rows (64 halves): XOR of the 16-B chunk index, two rows per 256-B bank sweep
+__device__ __forceinline__ int swz64(int row) { return (row >> 1) & 7; }
+
+__device__ __forceinline__ unsigned pack2(float a, float b) {
+    const f16x2 v = {(_Float16)a, (_Float16)b};
+    return __builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ float act_f(float v, int act) {
+    if (act == DBMM_ACT_RELU) return fmaxf(v, 0.f);
+    if (act == DBMM_ACT_QUICKGELU) return v / (1.f + expf(-1.702f * v));
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// GEMM
+// ---------------------------------------------------------------------------------------------------------------
+struct GemmHP {
+    const u16* a; const u16* w; const float* bias; const u16* res; u16* c;
+    long long lda, ldw, ldr, ldc, a_total, w_total;
+    int M, N, K, act, tiles_n, n_tiles;
+};
+
+constexpr int GBM = 128, GBN = 128, GBK = 64;
+constexpr int G_LROW = 64 + 4;                                   // epilogue staging pitch (floats) of a wave's 32 x 64 block
+constexpr int G_STAGE = (GBM + GBN) * GBK;                       // halves per stage
+
+__global__ __launch_bounds__(256, 2) void gemm_f16_kernel(const GemmHP p) {
+    __shared__ __attribute__((aligned(16))) u16 lds[2 * G_STAGE];                 // 64 KB; the epilogue staging aliases it
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 31, fh = lane >> 5;
+    const int tile = xcd_remap(blockIdx.x, p.n_tiles);
+    const int m0 = (tile / p.tiles_n) * GBM, n0 = (tile % p.tiles_n) * GBN;
+    const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
+
+    const __amdgpu_buffer_rsrc_t rsA = desc(p.a, p.a_total, (long long)m0 * p.lda * 2);
+    const __amdgpu_buffer_rsrc_t rsW = desc(p.w, p.w_total, (long long)n0 * p.ldw * 2);
+    // loader: 16-B chunk lc of rows lr + 32 i of both operands
+    const int lc = tid & 7, lr = tid >> 3;
+    unsigned a_off[4], w_off[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = lr + 32 * i;
+        a_off[i] = m0 + r < p.M ? (unsigned)r * (unsigned)(p.lda * 2) + lc * 16u : OOR;
+        w_off[i] = n0 + r < p.N ? (unsigned)r * (unsigned)(p.ldw * 2) + lc * 16u : OOR;
+    }
+    u32x4 a_r[4], w_r[4];
+    auto load_chunk = [&](int kc) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a_r[i] = __builtin_amdgcn_raw_buffer_load_b128(rsA, a_off[i], (unsigned)(kc * GBK * 2), 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) w_r[i] = __builtin_amdgcn_raw_buffer_load_b128(rsW, w_off[i], (unsigned)(kc * GBK * 2), 0);
+    };
+    auto store_chunk = [&](int stage) {
+        u16* Ab = lds + stage * G_STAGE;
+        u16* Wb = Ab + GBM * GBK;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = lr + 32 * i;
+            const int off = r * GBK + ((lc ^ swz64(r)) << 3);
+            *(u32x4*)(Ab + off) = a_r[i];
+            *(u32x4*)(Wb + off) = w_r[i];
+        }
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = p.K / GBK;
+    load_chunk(0);
+    store_chunk(0);
+    __syncthreads();
+    for (int kc = 0; kc < nk; ++kc) {
+        const int st = kc & 1;
+        if (kc + 1 < nk) load_chunk(kc + 1);
+        const u16* Ab = lds + st * G_STAGE;
+        const u16* Wb = Ab + GBM * GBK;
+#pragma unroll
+        for (int ks = 0; ks < GBK / 16; ++ks) {
+            u32x4 af[2], wf[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int r = wm0 + 32 * i + fr;
+                af[i] = *(const u32x4*)(Ab + r * GBK + (((2 * ks + fh) ^ swz64(r)) << 3));
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int r = wn0 + 32 * j + fr;
+                wf[j] = *(const u32x4*)(Wb + r * GBK + (((2 * ks + fh) ^ swz64(r)) << 3));
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[i]), __builtin_bit_cast(f16x8, wf[j]),
+                                                                       acc[i][j], 0, 0, 0);
+        }
+        if (kc + 1 < nk) store_chunk(st ^ 1);            // the other stage was last read before the previous barrier
+        __syncthreads();
+    }
+
+    // epilogue: a wave transposes its 64 x 64 block 32 rows at a time through LDS so that every lane owns 8 consecutive
+    // columns: bias / residual / store are 16 B per lane, whole 128-B row segments per 8 lanes
+    float* Ls = (float*)lds + wave * (32 * G_LROW);
+    const int ec = (lane & 7) * 8, er = lane >> 3;        // 8 lanes per row, 8 rows per wave instruction
+    const int n = n0 + wn0 + ec;
+    f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;
+    if (p.bias && n < p.N) { b0 = *(const f32x4*)(p.bias + n); b1 = *(const f32x4*)(p.bias + n + 4); }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) Ls[((r & 3) + 8 * (r >> 2) + 4 * fh) * G_LROW + j * 32 + fr] = acc[i][j][r];
+        __syncthreads();
+        u32x4 rv[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int m = m0 + wm0 + 32 * i + er + 8 * t;
+            rv[t] = (u32x4){0u, 0u, 0u, 0u};
+            if (p.res && m < p.M && n < p.N) rv[t] = *(const u32x4*)(p.res + (long long)m * p.ldr + n);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int row = er + 8 * t, m = m0 + wm0 + 32 * i + row;
+            const f32x4 v0 = *(const f32x4*)(Ls + row * G_LROW + ec) + b0, v1 = *(const f32x4*)(Ls + row * G_LROW + ec + 4) + b1;
+            const f16x8 rh = __builtin_bit_cast(f16x8, rv[t]);
+            float o[8];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { o[q] = act_f(v0[q], p.act) + (float)rh[q]; o[4 + q] = act_f(v1[q], p.act) + (float)rh[4 + q]; }
+            if (m < p.M && n < p.N)
+                *(u32x4*)(p.c + (long long)m * p.ldc + n) = (u32x4){pack2(o[0], o[1]), pack2(o[2], o[3]), pack2(o[4], o[5]), pack2(o[6], o[7])};
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Attention core.  One workgroup = 4 waves = 128 queries of one (image, head); each wave owns 32 queries.  K / V tiles of
+// 64 keys go through LDS: K row-major [key][64], V TRANSPOSED [d][key position] with the keys of every 16-group
+// permuted so that the 8 keys a lane needs for one MFMA step are one 16-B read.  S^T = K Q^T puts a query in a lane
+// column: row maximum / sum are register reductions plus one exchange with lane ^ 32, the O^T rescale is lane-local,
+// and the probabilities in their accumulator layout ARE the B operand of O^T += V^T P^T (keys permuted to match).
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int A_OROW = 72;                                       // O staging pitch in halves (144 B rows: conflict-free b64 writes)
+
+__global__ __launch_bounds__(256, 2) void mha_f16_kernel(const u16* __restrict__ qkv, u16* __restrict__ out, int L, int E,
+                                                         int heads, int causal, float scale_log2e) {
+    __shared__ __attribute__((aligned(16))) u16 Ks[64 * 64];
+    __shared__ __attribute__((aligned(16))) u16 Vt[64 * 64];
+    __shared__ __attribute__((aligned(16))) u16 Os[4 * 32 * A_OROW];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 31, fh = lane >> 5;
+    const int qb = blockIdx.x, head = blockIdx.y, b = blockIdx.z;
+    const long long row0 = (long long)b * L;
+    const long long ld = 3LL * E;
+    const int q_idx = qb * 128 + wave * 32 + fr;                 // this lane's query
+    const int q_ld = q_idx < L ? q_idx : L - 1;
+
+    // Q fragments (B operand of S^T): lane (query, k half fh) holds d = 16 s + 8 fh .. + 7
+    u32x4 qf[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qf[s] = *(const u32x4*)(qkv + (row0 + q_ld) * ld + head * 64 + 16 * s + 8 * fh);
+
+    f32x16 o_acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o_acc[j][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    // staging: thread loads 16 B (8 d) of key rows tid >> 3 and (tid >> 3) + 32 for K and V
+    const int lc = tid & 7, lk = tid >> 3;
+    u32x4 k_r[2], v_r[2];
+    const int q_hi = qb * 128 + 127 < L - 1 ? qb * 128 + 127 : L - 1;
+    const int n_keys = causal ? q_hi + 1 : L;                   // causal: keys past the block's last query never count
+    const int T = (n_keys + 63) / 64;
+    auto load_tile = [&](int t) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int key = t * 64 + lk + 32 * i;
+            key = key < L ? key : L - 1;
+            const u16* base = qkv + (row0 + key) * ld + head * 64 + lc * 8;
+            k_r[i] = *(const u32x4*)(base + E);
+            v_r[i] = *(const u32x4*)(base + 2 * E);
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int key = lk + 32 * i;
+            *(u32x4*)(Ks + key * 64 + ((lc ^ swz64(key)) << 3)) = k_r[i];
+            // V^T: key offset o = 8a + 4h + ii inside its 16-group goes to position 8h + 4a + ii
+            const int g16 = key >> 4, oo = key & 15, chunk = 2 * g16 + ((oo >> 2) & 1), within = 4 * (oo >> 3) + (oo & 3);
+            const f16x8 v = __builtin_bit_cast(f16x8, v_r[i]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int d = lc * 8 + j;
+                ((_Float16*)Vt)[d * 64 + ((chunk ^ swz64(d)) << 3) + within] = v[j];
+            }
+        }
+    };
+    load_tile(0);
+    store_tile();
+    __syncthreads();
+    for (int t = 0; t < T; ++t) {
+        if (t + 1 < T) load_tile(t + 1);
+        // ---- S^T[key][query] for the tile's two 32-key halves ------------------------------------------------------
+        f32x16 s_acc[2];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s_acc[kt][r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int row = kt * 32 + fr;
+                const u32x4 kf = *(const u32x4*)(Ks + row * 64 + (((2 * s + fh) ^ swz64(row)) << 3));
+                s_acc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, kf), __builtin_bit_cast(f16x8, qf[s]),
+                                                                   s_acc[kt], 0, 0, 0);
+            }
+        }
+        // ---- online softmax: this lane holds keys (r&3) + 8 (r>>2) + 4 fh of each half for ITS query ----------------
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = t * 64 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                float v = s_acc[kt][r] * scale_log2e;
+                if (key >= L || (causal && key > q_idx)) v = -INFINITY;
+                s_acc[kt][r] = v;
+                mx = fmaxf(mx, v);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float m_use = m_new == -INFINITY ? 0.f : m_new;   // a fully masked row so far: exp2(-inf - 0) = 0
+        const float alpha = exp2f(m_run - m_use);
+        float psum = 0.f;
+        u32x4 pf[2][2];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            float pv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { pv[r] = exp2f(s_acc[kt][r] - m_use); psum += pv[r]; }
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+                pf[kt][u] = (u32x4){pack2(pv[8 * u], pv[8 * u + 1]), pack2(pv[8 * u + 2], pv[8 * u + 3]),
+                                    pack2(pv[8 * u + 4], pv[8 * u + 5]), pack2(pv[8 * u + 6], pv[8 * u + 7])};
+        }
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o_acc[j][r] *= alpha;
+        // ---- O^T[d][query] += V^T[d][keys] P^T[keys][query] -----------------------------------------------------------
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int d = j * 32 + fr, chunk = 2 * (2 * kt + u) + fh;
+                    const u32x4 vf = *(const u32x4*)(Vt + d * 64 + ((chunk ^ swz64(d)) << 3));
+                    o_acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, vf), __builtin_bit_cast(f16x8, pf[kt][u]),
+                                                                      o_acc[j], 0, 0, 0);
+                }
+        __syncthreads();
+        if (t + 1 < T) store_tile();
+        __syncthreads();
+    }
+    // ---- normalise; O^T -> rows through LDS; 16-B stores ----------------------------------------------------------
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
+    u16* Ow = Os + wave * (32 * A_OROW);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int d = j * 32 + 8 * g + 4 * fh;
+            *(u32x2*)(Ow + fr * A_OROW + d) = (u32x2){pack2(o_acc[j][4 * g] * inv, o_acc[j][4 * g + 1] * inv),
+                                                       pack2(o_acc[j][4 * g + 2] * inv, o_acc[j][4 * g + 3] * inv)};
+        }
+    // (wave-private staging: the wave's own LDS writes are ordered before its reads)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (lane >> 3) + 8 * i, q = qb * 128 + wave * 32 + row;
+        if (q < L) *(u32x4*)(out + (row0 + q) * (long long)E + head * 64 + (lane & 7) * 8) = *(const u32x4*)(Ow + row * A_OROW + (lane & 7) * 8);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// LayerNorm, fp16 in / out, fp32 statistics (two pass, biased variance); wave per row, 8 halves per lane and pass
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void layernorm_f16_kernel(const u16* __restrict__ x, long long ldx, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, u16* __restrict__ y, long long ldy,
+                                                            int rows, int E8, float eps) {
+    const int lane = threadIdx.x & 63;
+    const float invE = 1.f / (float)(E8 * 8);
+    for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += gridDim.x * 4) {
+        const u32x4* xr = (const u32x4*)(x + (long long)row * ldx);
+        u32x4* yr = (u32x4*)(y + (long long)row * ldy);
+        constexpr int NV = 4;                                    // E <= 2048 held in registers; wider rows re-read
+        float v[NV][8];
+        float s = 0.f;
+        if (E8 <= 64 * NV) {
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                const int i = lane + 64 * j;
+                const f16x8 h = i < E8 ? __builtin_bit_cast(f16x8, xr[i]) : (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { v[j][q] = (float)h[q]; s += v[j][q]; }
+            }
+            const float mean = wave_sum(s) * invE;
+            float qq = 0.f;
+#pragma unroll
+            for (int j = 0; j < NV; ++j)
+                if (lane + 64 * j < E8)
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) { const float d = v[j][q] - mean; qq += d * d; }
+            const float rstd = rsqrtf(wave_sum(qq) * invE + eps);
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                const int i = lane + 64 * j;
+                if (i < E8) {
+                    const f32x4 g0 = ((const f32x4*)gamma)[2 * i], g1 = ((const f32x4*)gamma)[2 * i + 1];
+                    const f32x4 c0 = ((const f32x4*)beta)[2 * i], c1 = ((const f32x4*)beta)[2 * i + 1];
+                    float o[8];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        o[q] = (v[j][q] - mean) * rstd * g0[q] + c0[q];
+                        o[4 + q] = (v[j][4 + q] - mean) * rstd * g1[q] + c1[q];
+                    }
+                    yr[i] = (u32x4){pack2(o[0], o[1]), pack2(o[2], o[3]), pack2(o[4], o[5]), pack2(o[6], o[7])};
+                }
+            }
+        } else {
+            for (int i = lane; i < E8; i += 64) { const f16x8 h = __builtin_bit_cast(f16x8, xr[i]); for (int q = 0; q < 8; ++q) s += (float)h[q]; }
+            const float mean = wave_sum(s) * invE;
+            float qq = 0.f;
+            for (int i = lane; i < E8; i += 64) {
+                const f16x8 h = __builtin_bit_cast(f16x8, xr[i]);
+                for (int q = 0; q < 8; ++q) { const float d = (float)h[q] - mean; qq += d * d; }
+            }
+            const float rstd = rsqrtf(wave_sum(qq) * invE + eps);
+            for (int i = lane; i < E8; i += 64) {
+                const f16x8 h = __builtin_bit_cast(f16x8, xr[i]);
+                float o[8];
+                for (int q = 0; q < 8; ++q) o[q] = ((float)h[q] - mean) * rstd * gamma[8 * i + q] + beta[8 * i + q];
+                yr[i] = (u32x4){pack2(o[0], o[1]), pack2(o[2], o[3]), pack2(o[4], o[5]), pack2(o[6], o[7])};
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// layout kernels
+// ---------------------------------------------------------------------------------------------------------------
+// patch im2col: NCHW image (fp32 or fp16) -> [B * g * g][Kp] fp16, K = 3 * P * P zero-padded to Kp (a multiple of 64)
+template <typename TI>
+__global__ __launch_bounds__(256) void im2col_patch_f16_kernel(const TI* __restrict__ x, u16* __restrict__ out, int R, int P, int g,
+                                                               int Kp, long long total) {
+    const int K = 3 * P * P;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int k = (int)(i % Kp);
+        const long long m = i / Kp;
+        _Float16 v = (_Float16)0.f;
+        if (k < K) {
+            const int gx = (int)(m % g), gy = (int)((m / g) % g);
+            const long long b = m / ((long long)g * g);
+            const int kw = k % P, kh = (k / P) % P, c = k / (P * P);
+            v = (_Float16)(float)x[((b * 3 + c) * R + (long long)gy * P + kh) * R + (long long)gx * P + kw];
+        }
+        ((_Float16*)out)[i] = v;
+    }
+}
+
+// class token + patches + positional embedding -> tokens [B][L][W] fp16 (sum in fp32, one rounding)
+__global__ __launch_bounds__(256) void vit_tokens_f16_kernel(const u16* __restrict__ patches, const float* __restrict__ cls,
+                                                             const float* __restrict__ pos, u16* __restrict__ out, int L, int W,
+                                                             long long total) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % W);
+        const long long row = i / W;
+        const int l = (int)(row % L);
+        const long long b = row / L;
+        const float v = l == 0 ? cls[c] : (float)((const _Float16*)patches)[(b * (L - 1) + (l - 1)) * W + c];
+        ((_Float16*)out)[i] = (_Float16)(v + pos[(long long)l * W + c]);
+    }
+}
+
+__global__ __launch_bounds__(256) void embed_gather_f16_kernel(const int32_t* __restrict__ tokens, const float* __restrict__ table,
+                                                               const float* __restrict__ pos, u16* __restrict__ out, int L, int W,
+                                                               int vocab, long long total) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % W);
+        const long long row = i / W;
+        const int l = (int)(row % L);
+        int t = tokens[row];
+        t = t < 0 ? 0 : (t >= vocab ? vocab - 1 : t);
+        ((_Float16*)out)[i] = (_Float16)(table[(long long)t * W + c] + pos[(long long)l * W + c]);
+    }
+}
+
+__global__ __launch_bounds__(64) void gather_eot_f16_kernel(const int32_t* __restrict__ tokens, const u16* __restrict__ x,
+                                                            u16* __restrict__ out, int L, int W) {
+    const int n = blockIdx.x, lane = threadIdx.x;
+    int best = INT32_MIN, bi = 0;                               // first index of the maximum token id (torch.argmax tie rule)
+    for (int l = lane; l < L; l += 64) {
+        const int t = tokens[(long long)n * L + l];
+        if (t > best) { best = t; bi = l; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const int ob = __shfl_xor(best, o, 64), oi = __shfl_xor(bi, o, 64);
+        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    for (int c = lane; c < W; c += 64) out[(long long)n * W + c] = x[((long long)n * L + bi) * W + c];
+}
+
+__global__ __launch_bounds__(256) void cast_f32_f16_kernel(const float* __restrict__ x, u16* __restrict__ y, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        ((_Float16*)y)[i] = (_Float16)x[i];
+}
+
+inline unsigned grid_for(long long total) {
+    const long long blocks = (total + 255) / 256;
+    return (unsigned)(blocks < 16384 ? (blocks > 0 ? blocks : 1) : 16384);
+}
+
+}  // namespace
+
+extern "C" int dbmm_gemm_f16(const void* a, int64_t lda, const void* w, int64_t ldw, const float* bias, const void* residual,
+                             int64_t ldr, void* c, int64_t ldc, int64_t M, int64_t N, int64_t K, int act, void* stream) {
+    if (!a || !w || !c) return DBMM_E_ARG;
+    if (M <= 0 || N <= 0 || K <= 0 || M > INT32_MAX || N > INT32_MAX || K > INT32_MAX) return DBMM_E_SHAPE;
+    if (act < 0 || act > 2) return DBMM_E_ARG;
+    if ((K % GBK) || (N & 7)) return DBMM_E_UNSUPPORTED;
+    if ((lda & 7) || (ldw & 7) || (ldc & 7) || (residual && (ldr & 7)) || !dbmm_aligned16(a) || !dbmm_aligned16(w) || !dbmm_aligned16(c) ||
+        (residual && !dbmm_aligned16(residual)) || (bias && !dbmm_aligned16(bias)))
+        return DBMM_E_ALIGN;
+    GemmHP p{};
+    p.a = (const u16*)a; p.w = (const u16*)w; p.bias = bias; p.res = (const u16*)residual; p.c = (u16*)c;
+    p.lda = lda; p.ldw = ldw; p.ldr = ldr; p.ldc = ldc;
+    p.a_total = ((M - 1) * lda + K) * 2; p.w_total = ((N - 1) * ldw + K) * 2;
+    p.M = (int)M; p.N = (int)N; p.K = (int)K; p.act = act;
+    p.tiles_n = (int)((N + GBN - 1) / GBN);
+    p.n_tiles = (int)((M + GBM - 1) / GBM) * p.tiles_n;
+    hipLaunchKernelGGL(gemm_f16_kernel, dim3(p.n_tiles), dim3(256), 0, (hipStream_t)stream, p);
+    DBMM_CHECK_LAUNCH();
+    return DBMM_OK;
+}
+
+extern "C" int dbmm_mha_core_f16(const void* qkv, void* out, int64_t B, int64_t L, int64_t E, int64_t heads, int causal,
+                                 void* stream) {
+    if (!qkv || !out) return DBMM_E_ARG;
+    if (B <= 0 || L <= 0 || E <= 0 || heads <= 0 || B > 65535 || heads > 65535) return DBMM_E_SHAPE;
+    if (E != heads * 64) return DBMM_E_UNSUPPORTED;              // head_dim 64 (every CLIP tower)
+    if (!dbmm_aligned16(qkv) || !dbmm_aligned16(out)) return DBMM_E_ALIGN;
+    const dim3 grid((unsigned)((L + 127) / 128), (unsigned)heads, (unsigned)B);
+    hipLaunchKernelGGL(mha_f16_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const u16*)qkv, (u16*)out, (int)L, (int)E,
+                       (int)heads, causal ? 1 : 0, 0.125f * 1.4426950408889634f);
+    DBMM_CHECK_LAUNCH();
+    return DBMM_OK;
+}
+
+extern "C" int dbmm_layernorm_f16(const void* x, int64_t ldx, const float* gamma, const float* beta, void* y, int64_t ldy,
+                                  int64_t rows, int64_t E, float eps, void* stream) {
+    if (!x || !gamma || !beta || !y) return DBMM_E_ARG;
+    if (rows <= 0 || E <= 0 || rows > INT32_MAX) return DBMM_E_SHAPE;
+    if ((E & 7) || (ldx & 7) || (ldy & 7)) return DBMM_E_SHAPE;
+    if (!dbmm_aligned16(x) || !dbmm_aligned16(y) || !dbmm_aligned16(gamma) || !dbmm_aligned16(beta)) return DBMM_E_ALIGN;
+    const long long blocks = (rows + 3) / 4;
+    hipLaunchKernelGGL(layernorm_f16_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, (hipStream_t)stream,
+                       (const u16*)x, (long long)ldx, gamma, beta, (u16*)y, (long long)ldy, (int)rows, (int)(E / 8), eps);
+    DBMM_CHECK_LAUNCH();
+    return DBMM_OK;
+}
+
+extern "C" int dbmm_im2col_patch_f16(const void* x_nchw, int x_is_f16, void* out, int64_t B, int64_t R, int64_t P, int64_t Kp,
+                                     void* stream) {
+    if (!x_nchw || !out) return DBMM_E_ARG;
+    if (B <= 0 || R <= 0 || P <= 0 || R % P || Kp < 3 * P * P) return DBMM_E_SHAPE;
+    const int g = (int)(R / P);
+    const long long total = (long long)B * g * g * Kp;
+    if (x_is_f16)
+        hipLaunchKernelGGL((im2col_patch_f16_kernel<_Float16>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+                           (const _Float16*)x_nchw, (u16*)out, (int)R, (int)P, g, (int)Kp, total);
+    else
+        hipLaunchKernelGGL((im2col_patch_f16_kernel<float>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+                           (const float*)x_nchw, (u16*)out, (int)R, (int)P, g, (int)Kp, total);
+    DBMM_CHECK_LAUNCH();
+    return DBMM_OK;
+}
+
+extern "C" int dbmm_vit_tokens_f16(const void* patches, const float* cls, const float* pos, void* out, int64_t B, int64_t L,
+                                   int64_t W, void* stream) {
+    if (!patches || !cls || !pos || !out) return DBMM_E_ARG;
+    if (B <= 0 || L <= 1 || W <= 0) return DBMM_E_SHAPE;
+    const long long total = (long long)B * L * W;
+    hipLaunchKernelGGL(vit_tokens_f16_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const u16*)patches, cls, pos,
+                       (u16*)out, (int)L, (int)W, total);
+    DBMM_CHECK_LAUNCH();
+    return DBMM_OK;
+}
+
+extern "C" int dbmm_embed_gather_f16(const int32_t* tokens, const float* table, const float* pos, void* out, int64_t n, int64_t L,
+                                     int64_t W, int64_t vocab, void* stream) {
+    if (!tokens || !table || !pos || !out) return DBMM_E_ARG;
+    if (n <= 0 || L <= 0 || W <= 0 || vocab <= 0) return DBMM_E_SHAPE;
+    const long long total = (long long)n * L * W;
+    hipLaunchKernelGGL(embed_gather_f16_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, tokens, table, pos, (u16*)out,
+                       (int)L, (int)W, (int)vocab, total);
+    DBMM_CHECK_LAUNCH();
+    return DBMM_OK;
+}
+
+extern "C" int dbmm_gather_eot_f16(const int32_t* tokens, const void* x, void* out, int64_t n, int64_t L, int64_t W, void* stream) {
+    if (!tokens || !x || !out) return DBMM_E_ARG;
+    if (n <= 0 || L <= 0 || W <= 0) return DBMM_E_SHAPE;
+    hipLaunchKernelGGL(gather_eot_f16_kernel, dim3((unsigned)n), dim3(64), 0, (hipStream_t)stream, tokens, (const u16*)x, (u16*)out, (int)L,
+                       (int)W);
+    DBMM_CHECK_LAUNCH();
+    return DBMM_OK;
+}
+
+extern "C" int dbmm_cast_f32_f16(const float* x, void* y, int64_t n, void* stream) {
+    if (!x || !y) return DBMM_E_ARG;
+    if (n <= 0) return DBMM_E_SHAPE;
+    hipLaunchKernelGGL(cast_f32_f16_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, (u16*)y, (long long)n);
+    DBMM_CHECK_LAUNCH();
+    return DBMM_OK;
+}

@@ -66,6 +66,8 @@ class EmbedAdapterStep:
     def step(self, images_local, y_local, g_local, use_group=False):
         emb_local = self.encode_fn(images_local)
         emb, y, g = self.gather(emb_local, y_local, g_local)
+        if emb.dtype != torch.float32:                 # fp16 mode: the adapter consumes .float() embeddings, like the
+            emb = emb.float()                          # reference's readers do (data/celeba_embeddings_reg.py:74)
         labels = g if use_group else y
         if self.fused and emb.is_cuda and hasattr(self.classifier, "train_step"):
             # the whole step body as one C call (bit-identical to the autograd path below,

@@ -585,3 +585,108 @@ def gather_rows(table, idx):
     check(_lib.lib().dbmm_gather_rows(ptr(table), ptr(idx), ptr(out), table.shape[0], idx.numel(), table.shape[1],
                                       stream()), "gather_rows")
     return out
+
+
+# ---- fp16 mode of the transformer towers (csrc/f16_ops.hip) -------------------------------------------------------
+
+def _f16c(t):
+    if t.dtype != torch.float16 or not t.is_contiguous():
+        raise _lib.DbmmError(f"expected a contiguous float16 tensor, got {t.dtype} contiguous={t.is_contiguous()}")
+    return t
+
+
+def gemm_f16(a, w, bias=None, residual=None, act=ACT_NONE, M=None, lda=None):
+    """c f16 = act(a @ w^T + bias) + residual; a f16 [M][K] (row pitch lda), w f16 [N][K], bias f32, residual f16."""
+    require_cuda(a, w)
+    _f16c(w)
+    if a.dtype != torch.float16:
+        raise _lib.DbmmError("gemm_f16 needs float16 activations")
+    N, K = w.shape
+    if lda is None:
+        _f16c(a)
+        lda = a.shape[-1]
+    if M is None:
+        M = a.numel() // a.shape[-1]
+    c = torch.empty((M, N), device=a.device, dtype=torch.float16)
+    with _TimedTag("gemm_f16_kernel", 2.0 * M * N * K, 2 * (M * K + N * K + M * N * (2 if residual is not None else 1))):
+        check(_lib.lib().dbmm_gemm_f16(ptr(a), lda, ptr(w), K, ptr(bias), ptr(residual), N if residual is not None else 0, ptr(c), N,
+                                       M, N, K, act, stream()), "gemm_f16")
+    return c
+
+
+def mha_core_f16(qkv, B, L, E, heads, causal):
+    require_cuda(qkv)
+    _f16c(qkv)
+    out = torch.empty((B * L, E), device=qkv.device, dtype=torch.float16)
+    with _TimedTag("mha_f16_kernel", 4.0 * B * heads * L * L * 64, 2 * (B * L * 4 * E)):
+        check(_lib.lib().dbmm_mha_core_f16(ptr(qkv), ptr(out), B, L, E, heads, int(causal), stream()), "mha_core_f16")
+    return out
+
+
+def layernorm_f16(x, gamma, beta, rows=None, ldx=None, eps=1e-5):
+    require_cuda(x)
+    E = gamma.numel()
+    if rows is None:
+        rows = x.numel() // E
+    if ldx is None:
+        ldx = E
+    y = torch.empty((rows, E), device=x.device, dtype=torch.float16)
+    check(_lib.lib().dbmm_layernorm_f16(ptr(x), ldx, ptr(gamma), ptr(beta), ptr(y), E, rows, E, eps, stream()), "layernorm_f16")
+    return y
+
+
+def im2col_patch_f16(x_nchw, P, Kp):
+    require_cuda(x_nchw)
+    if x_nchw.dtype not in (torch.float16, torch.float32) or not x_nchw.is_contiguous():
+        raise _lib.DbmmError("im2col_patch_f16 needs a contiguous float16 / float32 image batch")
+    B, C, R, _ = x_nchw.shape
+    g = R // P
+    out = torch.empty((B * g * g, Kp), device=x_nchw.device, dtype=torch.float16)
+    check(_lib.lib().dbmm_im2col_patch_f16(ptr(x_nchw), int(x_nchw.dtype == torch.float16), ptr(out), B, R, P, Kp, stream()),
+          "im2col_patch_f16")
+    return out
+
+
+def vit_tokens_f16(patches, cls, pos, B):
+    L, W = pos.shape
+    out = torch.empty((B, L, W), device=patches.device, dtype=torch.float16)
+    check(_lib.lib().dbmm_vit_tokens_f16(ptr(patches), ptr(cls), ptr(pos), ptr(out), B, L, W, stream()), "vit_tokens_f16")
+    return out
+
+
+def embed_gather_f16(tokens, table, pos):
+    require_cuda(tokens, table)
+    if tokens.dtype != torch.int32:
+        tokens = tokens.to(torch.int32)
+    tokens = tokens.contiguous()
+    n, L = tokens.shape
+    W = table.shape[1]
+    out = torch.empty((n, L, W), device=table.device, dtype=torch.float16)
+    check(_lib.lib().dbmm_embed_gather_f16(ptr(tokens), ptr(table), ptr(pos), ptr(out), n, L, W, table.shape[0], stream()),
+          "embed_gather_f16")
+    return out, tokens
+
+
+def gather_eot_f16(tokens_i32, x):
+    n, L, W = x.shape
+    out = torch.empty((n, W), device=x.device, dtype=torch.float16)
+    check(_lib.lib().dbmm_gather_eot_f16(ptr(tokens_i32), ptr(x), ptr(out), n, L, W, stream()), "gather_eot_f16")
+    return out
+
+
+class _TimedTag:
+    """profile hook for kernels outside the igemm family: fixed tag, caller-supplied FLOPs and algorithmic bytes"""
+    def __init__(self, tag, flops, nbytes):
+        self.tag, self.flops, self.nbytes = tag, float(flops), float(nbytes)
+
+    def __enter__(self):
+        self.on = _prof is not None and not _prof_conv_only
+        if self.on:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+
+    def __exit__(self, *exc):
+        if self.on and _prof is not None and exc[0] is None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            _prof.append((self.tag, self.flops, self.nbytes, self.e0, e1))

@@ -207,6 +207,33 @@ int dbmm_bottleneck_chain_dual_x2(const float* y2, const float* y2_absmax, const
                                   int64_t P, void* stream);
 
 /* ---------------------------------------------------------------------------------------
+ * fp16 mode of the transformer towers -- the reference's GPU path (convert_weights, clip/model.py:375-396; fp16
+ * activations, fp32 LayerNorm statistics, clip/model.py:157-163).  Tensors marked f16 are IEEE half in HBM; every
+ * product is one fp16 MFMA with fp32 accumulation; bias / QuickGELU / residual / softmax run in fp32 and the result
+ * is rounded to fp16 once.  Throughput mode (BASELINE configs[4]); the fp32-accurate entry points above stay the
+ * parity mode.
+ * --------------------------------------------------------------------------------------- */
+/* c f16 [M][ldc] = act(a f16 [M][lda] @ w f16 [N][ldw]^T + bias f32 [N]) + residual f16 [M][ldr].  K % 64 == 0, N % 8 == 0. */
+int dbmm_gemm_f16(const void* a, int64_t lda, const void* w, int64_t ldw, const float* bias, const void* residual,
+                  int64_t ldr, void* c, int64_t ldc, int64_t M, int64_t N, int64_t K, int act, void* stream);
+/* softmax(q k^T / sqrt(64)) v per (image, head), head_dim 64; qkv f16 [B*L][3E] (q | k | v), out f16 [B*L][E]. */
+int dbmm_mha_core_f16(const void* qkv, void* out, int64_t B, int64_t L, int64_t E, int64_t heads, int causal, void* stream);
+/* y f16 [rows][ldy] = LayerNorm(x f16 [rows][ldx]) with f32 gamma / beta [E], statistics in fp32.  E % 8 == 0. */
+int dbmm_layernorm_f16(const void* x, int64_t ldx, const float* gamma, const float* beta, void* y, int64_t ldy,
+                       int64_t rows, int64_t E, float eps, void* stream);
+/* NCHW image (f32, or f16 when x_is_f16) -> patch rows f16 [B*(R/P)^2][Kp], K = 3*P*P zero-padded to Kp. */
+int dbmm_im2col_patch_f16(const void* x_nchw, int x_is_f16, void* out, int64_t B, int64_t R, int64_t P, int64_t Kp,
+                          void* stream);
+/* tokens f16 [B][L][W] = (class token | patches f16 [B*(L-1)][W]) + positional embedding (cls, pos f32). */
+int dbmm_vit_tokens_f16(const void* patches, const float* cls, const float* pos, void* out, int64_t B, int64_t L,
+                        int64_t W, void* stream);
+/* out f16 [n][L][W] = table f32 [vocab][W][tokens] + pos f32 [L][W];  out f16 [n][W] = x f16 [n][L][W] at argmax(tokens). */
+int dbmm_embed_gather_f16(const int32_t* tokens, const float* table, const float* pos, void* out, int64_t n, int64_t L,
+                          int64_t W, int64_t vocab, void* stream);
+int dbmm_gather_eot_f16(const int32_t* tokens, const void* x, void* out, int64_t n, int64_t L, int64_t W, void* stream);
+int dbmm_cast_f32_f16(const float* x, void* y, int64_t n, void* stream);
+
+/* ---------------------------------------------------------------------------------------
  * Device-side preprocessing (clip/clip.py:79-86: Resize(BICUBIC) -> CenterCrop -> ToTensor ->
  * Normalize) of one decoded RGB uint8 image [H][W][3] resident on the device.  Integer
  * resampling exactly as Pillow's 8-bit resampler (22-bit fixed-point coefficients, horizontal

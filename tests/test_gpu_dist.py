@@ -1,0 +1,103 @@
+"""Two ranks on ONE MI355X (gloo rendezvous, embeddings staged through the host -- dp.all_gather_rows' rehearsal
+path; RCCL needs one GPU per rank and is exercised by the driver's multi-GPU bench only): the REAL step --
+model.encode_image -> gather of embeddings + packed (y, g) -> adapter.CustomCLIP.train_step (the fused C step) with
+optim.SGD -- must leave bit-identical parameters, momentum buffers, BatchNorm statistics, group counters and loss on
+both ranks, equal to a single process that runs the adapter step on the whole batch.
+The single-process reference encodes the two shards separately as the ranks do: kernel tile schedules, and therefore
+fp32 summation order, depend on the batch a launch sees (tests/test_gpu_clip.py::test_large_batch_property_rn50)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+ARCH, B, STEPS = "tiny-RN", 16, 3
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _setup(tmp):
+    import json
+    import sys
+    for p in (ROOT, os.path.join(ROOT, "oracle")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import dbmm_amd  # noqa: F401
+    from types import SimpleNamespace
+    from dbmm_amd import adapter, optim, synth
+    from dbmm_amd.clip.model import build_model
+    torch.cuda.set_device(0)
+    model = build_model(synth.clip_state_dict(3, ARCH)).cuda()
+    D, R = model.visual.output_dim, model.visual.input_resolution
+    paths = []
+    for nm, C in (("c", 2), ("s", 2), ("g", 4)):
+        p = os.path.join(tmp, f"{nm}.json")
+        if not os.path.exists(p):
+            m = synth.text_matrix(1, D, C, nm)
+            with open(p, "w") as f:
+                json.dump({f"{nm}{i}": m[:, i].tolist() for i in range(C)}, f)
+        paths.append(p)
+    ad = adapter.Adapter(D, 32); ad.load_state_dict(synth.adapter_state_dict(3, D, 32))
+    clf = adapter.CustomCLIP(ad, *paths, temperature=0.01).cuda().train()
+    opt = optim.set_optimizer(SimpleNamespace(learning_rate=0.1, momentum=0.9, weight_decay=5e-5), clf)
+    images = synth.images(7, B, R).cuda()
+    y, c, g = synth.labels(6, B)
+    return model, clf, opt, images, y.cuda(), g.cuda()
+
+
+def _state_bytes(clf, opt, step, loss):
+    parts = [v.detach().float().flatten() for v in clf.state_dict().values()]
+    parts += [opt.state[p]["momentum_buffer"].flatten() for p in clf.parameters()]
+    parts += [step.counts.float().flatten(), loss.detach().reshape(1)]
+    return torch.cat([t.cpu() for t in parts]).numpy().tobytes()
+
+
+def _worker(rank, world, port, tmp, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from dbmm_amd import dp
+        model, clf, opt, images, y, g = _setup(tmp)
+        lo, hi = dp.shard_rows(B, world, rank)
+        step = dp.EmbedAdapterStep(model.encode_image, clf, opt)
+        for _ in range(STEPS):
+            loss, logits, emb = step.step(images[lo:hi].contiguous(), y[lo:hi], g[lo:hi])
+        torch.cuda.synchronize()
+        q.put((rank, tuple(emb.shape), _state_bytes(clf, opt, step, loss)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_one_gpu_equal_single_process(tmp_path):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, str(tmp_path), q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][1] == res[1][1] and res[0][1][0] == B            # every rank holds the gathered global batch
+    assert res[0][2] == res[1][2]                                   # replicated state is bit-identical
+    # single process, whole batch (shards encoded separately like the ranks do), same fused step
+    from dbmm_amd import dp
+    model, clf, opt, images, y, g = _setup(str(tmp_path))
+    encode = lambda x: torch.cat([model.encode_image(x[:B // 2].contiguous()), model.encode_image(x[B // 2:].contiguous())])
+    step = dp.EmbedAdapterStep(encode, clf, opt)
+    for _ in range(STEPS):
+        loss, _, _ = step.step(images, y, g)
+    torch.cuda.synchronize()
+    assert _state_bytes(clf, opt, step, loss) == res[0][2]
+    assert int(step.counts[:, 0].sum()) == B * STEPS

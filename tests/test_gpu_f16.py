@@ -1,0 +1,123 @@
+"""fp16 throughput mode of the transformer towers (csrc/f16_ops.hip; the reference's GPU path, convert_weights +
+fp16 activations, clip/model.py:157-163, 375-396).
+
+PARITY UNPINNED vs the reference's fp16 path: that path only runs on a GPU the reference never had here, so no fixture
+of it exists.  What is pinned instead:
+  * every fp16 kernel against an fp64 evaluation of the same op on the SAME fp16-rounded inputs -- the only differences
+    are fp32 accumulation order and the single fp16 rounding of the stored result (2^-11 relative);
+  * whole towers against the reference-generated fp32 goldens at a tolerance that follows from fp16 storage of the
+    activations: about 2^-11 relative per stored tensor, accumulating over 2 x layers residual updates; measured
+    1-3e-3 of the embedding maximum, bound set at 1e-2, cosine to the fp32 embedding > 0.9999."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import relerr
+from dbmm_amd import ops, synth
+from dbmm_amd.clip.model import build_model, convert_weights
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def gname(arch):
+    return "clip_" + arch.replace("/", "-").replace("@", "-") + ".npz"
+
+
+@pytest.mark.parametrize("M,N,K,res,act", [(300, 256, 128, False, 0), (1000, 768, 768, True, 0), (577 * 3, 3072, 1024, False, 2),
+                                           (128, 64, 64, True, 1), (4, 512, 768, False, 0), (25600, 2304, 768, False, 0)])
+def test_gemm_f16(M, N, K, res, act):
+    g = torch.Generator(device=DEV); g.manual_seed(M + N + K)
+    a = torch.randn((M, K), device=DEV, generator=g).half(); w = (torch.randn((N, K), device=DEV, generator=g) * K ** -0.5).half()
+    b = torch.randn((N,), device=DEV, generator=g); r = torch.randn((M, N), device=DEV, generator=g).half() if res else None
+    v = a.double() @ w.double().t() + b.double()
+    v = {0: v, 1: torch.relu(v), 2: v * torch.sigmoid(1.702 * v)}[act]
+    if res:
+        v = v + r.double()
+    out = ops.gemm_f16(a, w, b, residual=r, act=act)
+    assert out.dtype == torch.float16 and tuple(out.shape) == (M, N)
+    assert relerr(out.double().cpu(), v.cpu()) < 1.5e-3           # 2^-11 output rounding + fp32 accumulation
+
+
+def test_gemm_f16_strided_rows_and_rejects():
+    g = torch.Generator(device=DEV); g.manual_seed(5)
+    t = torch.randn((9, 7, 64), device=DEV, generator=g).half(); w = torch.randn((32, 64), device=DEV, generator=g).half()
+    out = ops.gemm_f16(t, w, M=9, lda=7 * 64)                                      # token 0 of every image (ln_post -> proj)
+    assert relerr(out.double().cpu(), (t[:, 0].double() @ w.double().t()).cpu()) < 1.5e-3
+    from dbmm_amd import _lib
+    with pytest.raises(_lib.DbmmError):
+        ops.gemm_f16(torch.zeros((8, 40), device=DEV, dtype=torch.float16), torch.zeros((16, 40), device=DEV, dtype=torch.float16))   # K % 64
+    with pytest.raises(_lib.DbmmError):
+        ops.gemm_f16(torch.zeros((8, 64), device=DEV), torch.zeros((16, 64), device=DEV, dtype=torch.float16))                        # f32 input
+
+
+@pytest.mark.parametrize("B,L,heads,causal", [(3, 50, 2, False), (2, 77, 8, True), (2, 130, 1, False), (1, 577, 4, False),
+                                              (2, 1, 1, False), (1, 128, 2, True), (2, 129, 1, True)])
+def test_mha_core_f16(B, L, heads, causal):
+    E = heads * 64
+    g = torch.Generator(device=DEV); g.manual_seed(L + heads)
+    qkv = (torch.randn((B * L, 3 * E), device=DEV, generator=g) * 1.5).half()
+    out = ops.mha_core_f16(qkv, B, L, E, heads, causal)
+    q, k, v = (t.view(B, L, heads, 64).permute(0, 2, 1, 3).double() for t in qkv.view(B, L, 3, E).unbind(2))
+    s = q @ k.transpose(-1, -2) / 8.0
+    if causal:
+        s = s + torch.full((L, L), float("-inf"), device=DEV, dtype=torch.float64).triu(1)
+    ref = (torch.softmax(s, -1) @ v).permute(0, 2, 1, 3).reshape(B * L, E)
+    assert out.dtype == torch.float16 and relerr(out.double().cpu(), ref.cpu()) < 3e-3   # P is rounded to fp16 before P V
+
+
+def test_mha_core_f16_spiked_scores():
+    B, L, heads, E = 1, 200, 2, 128
+    g = torch.Generator(device=DEV); g.manual_seed(1)
+    qkv = torch.randn((B * L, 3 * E), device=DEV, generator=g)
+    qkv[:, :E] *= 12.0                                                             # softmax close to one-hot
+    qkv = qkv.half()
+    out = ops.mha_core_f16(qkv, B, L, E, heads, False)
+    q, k, v = (t.view(B, L, heads, 64).permute(0, 2, 1, 3).double() for t in qkv.view(B, L, 3, E).unbind(2))
+    ref = (torch.softmax(q @ k.transpose(-1, -2) / 8.0, -1) @ v).permute(0, 2, 1, 3).reshape(B * L, E)
+    assert torch.isfinite(out).all() and relerr(out.double().cpu(), ref.cpu()) < 3e-3
+
+
+@pytest.mark.parametrize("rows,E", [(7, 64), (100, 768), (33, 1024), (5, 2048), (3, 4096)])
+def test_layernorm_f16(rows, E):
+    g = torch.Generator(device=DEV); g.manual_seed(rows + E)
+    x = (torch.randn((rows, E), device=DEV, generator=g) * 3 + 0.5).half()
+    ga, be = torch.randn((E,), device=DEV, generator=g), torch.randn((E,), device=DEV, generator=g)
+    out = ops.layernorm_f16(x, ga, be)
+    ref = F.layer_norm(x.double(), (E,), ga.double(), be.double(), 1e-5)
+    assert out.dtype == torch.float16 and relerr(out.double().cpu(), ref.cpu()) < 1e-3
+    strided = ops.layernorm_f16(x.view(-1), ga[:64].contiguous(), be[:64].contiguous(), rows=rows, ldx=E) if E >= 64 else None
+    if strided is not None:
+        assert relerr(strided.double().cpu(), F.layer_norm(x[:, :64].double(), (64,), ga[:64].double(), be[:64].double(), 1e-5).cpu()) < 1e-3
+
+
+@pytest.mark.parametrize("arch", ["tiny-ViT", "ViT-B/32", "ViT-L/14@336px"])
+def test_fp16_mode_towers_vs_fp32_goldens(arch, golden):
+    g = golden(gname(arch))
+    seed, B, res = int(g["seed"]), int(g["batch"]), int(g["res"])
+    model = convert_weights(build_model(synth.clip_state_dict(seed, arch)).cuda())
+    assert model.dtype == torch.float16
+    img = synth.images(seed + 100, B, res).cuda()
+    out = model.encode_image(img)
+    assert out.dtype == torch.float16 and tuple(out.shape) == g["embedding"].shape
+    ref = torch.from_numpy(g["embedding"])
+    assert relerr(out.float().cpu(), ref) < 1e-2
+    assert F.cosine_similarity(out.float().cpu(), ref, dim=1).min() > 0.9999
+    txt = model.encode_text(torch.from_numpy(g["tokens"]).cuda())
+    tref = torch.from_numpy(g["text_embedding"])
+    assert txt.dtype == torch.float16 and relerr(txt.float().cpu(), tref) < 1e-2
+    assert F.cosine_similarity(txt.float().cpu(), tref, dim=1).min() > 0.9999
+    # back to the parity mode
+    model.float()
+    assert model.dtype == torch.float32 and relerr(model.encode_image(img).cpu(), ref) < 5e-5
+
+
+def test_fp16_mode_rn_tower_rounds_its_fp32_accurate_output():
+    sd = synth.clip_state_dict(3, "tiny-RN")
+    model = build_model(sd).cuda()
+    img = synth.images(103, 2, 64).cuda()
+    ref = model.encode_image(img)
+    convert_weights(model)
+    out = model.encode_image(img)
+    assert out.dtype == torch.float16 and relerr(out.float().cpu(), ref.cpu()) < 1e-3
