@@ -76,14 +76,23 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(const GemmHP p) {
         a_off[i] = m0 + r < p.M ? (unsigned)r * (unsigned)(p.lda * 2) + lc * 16u : OOR;
         w_off[i] = n0 + r < p.N ? (unsigned)r * (unsigned)(p.ldw * 2) + lc * 16u : OOR;
     }
-    u32x4 a_r[4], w_r[4];
-    auto load_chunk = [&](int kc) {
+    // zero-extent twins: chunk loads past the end of K go through them (hardware returns zeros, no memory access), so
+    // the loop body has no branches and an odd chunk count costs one phantom chunk of zeros
+    const __amdgpu_buffer_rsrc_t rsA0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.a, 0, 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsW0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, 0, 0x00020000);
+    // two register sets: the loads of chunk k+2 are issued while chunk k computes and chunk k+1 (landed) is written to
+    // LDS -- one chunk of lead (16 MFMAs = 0.25 us) does not cover an L2 / HBM round trip
+    u32x4 a_r0[4], w_r0[4], a_r1[4], w_r1[4];
+    const int nk = p.K / GBK;
+    auto load_chunk = [&](int kc, u32x4 (&a_r)[4], u32x4 (&w_r)[4]) {
+        const bool valid = kc < nk;
+        const __amdgpu_buffer_rsrc_t ra = valid ? rsA : rsA0, rw = valid ? rsW : rsW0;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) a_r[i] = __builtin_amdgcn_raw_buffer_load_b128(rsA, a_off[i], (unsigned)(kc * GBK * 2), 0);
+        for (int i = 0; i < 4; ++i) a_r[i] = __builtin_amdgcn_raw_buffer_load_b128(ra, a_off[i], (unsigned)(kc * GBK * 2), 0);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) w_r[i] = __builtin_amdgcn_raw_buffer_load_b128(rsW, w_off[i], (unsigned)(kc * GBK * 2), 0);
+        for (int i = 0; i < 4; ++i) w_r[i] = __builtin_amdgcn_raw_buffer_load_b128(rw, w_off[i], (unsigned)(kc * GBK * 2), 0);
     };
-    auto store_chunk = [&](int stage) {
+    auto store_chunk = [&](int stage, const u32x4 (&a_r)[4], const u32x4 (&w_r)[4]) {
         u16* Ab = lds + stage * G_STAGE;
         u16* Wb = Ab + GBM * GBK;
 #pragma unroll
@@ -101,14 +110,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(const GemmHP p) {
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    const int nk = p.K / GBK;
-    load_chunk(0);
-    store_chunk(0);
-    __syncthreads();
-    for (int kc = 0; kc < nk; ++kc) {
-        const int st = kc & 1;
-        if (kc + 1 < nk) load_chunk(kc + 1);
+    auto compute = [&](int st) {
         const u16* Ab = lds + st * G_STAGE;
         const u16* Wb = Ab + GBM * GBK;
 #pragma unroll
@@ -131,7 +133,21 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(const GemmHP p) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[i]), __builtin_bit_cast(f16x8, wf[j]),
                                                                        acc[i][j], 0, 0, 0);
         }
-        if (kc + 1 < nk) store_chunk(st ^ 1);            // the other stage was last read before the previous barrier
+    };
+
+    load_chunk(0, a_r0, w_r0);
+    load_chunk(1, a_r1, w_r1);
+    store_chunk(0, a_r0, w_r0);
+    __syncthreads();
+    // chunk kc lives in stage kc & 1; set r1 holds chunk kc+1 on even steps, r0 on odd ones
+    for (int kc = 0; kc < nk; kc += 2) {
+        load_chunk(kc + 2, a_r0, w_r0);
+        compute(0);
+        store_chunk(1, a_r1, w_r1);
+        __syncthreads();
+        load_chunk(kc + 3, a_r1, w_r1);
+        compute(1);                                       // (kc + 1 == nk: a chunk of zeros)
+        store_chunk(0, a_r0, w_r0);
         __syncthreads();
     }
 
