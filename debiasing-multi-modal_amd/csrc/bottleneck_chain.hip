@@ -25,6 +25,11 @@
 // into hi / lo when the conv1' A fragments are read.
 //
 // Bound: HBM.  Algorithmic bytes per pixel row: 4 * (K + 2 N + P) (+ N for the pooled copy).
+//
+// Tried and dropped (same-box A/B, B = 1024): the layer-3 shapes (K = 256, P = 256: 128 registers of A fragments + 128
+// of conv1' accumulators = the whole 512-register file, one workgroup per CU) ran 1.15 ms against 0.68 ms for the two
+// separate launches, and the layer 2 -> 3 seam (K = 128, P = 256) 1.71 against 1.37: with one wave per SIMD nothing
+// hides the slab's residual round trip.  The chain serves the shapes that fit 2 workgroups per CU.
 #include <stdlib.h>
 #include "common.h"
 
