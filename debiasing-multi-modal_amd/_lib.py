@@ -87,6 +87,7 @@ _SIGS = {
     "dbmm_embed_gather_f16": [_P, _P, _P, _P, _L, _L, _L, _L, _P],
     "dbmm_gather_eot_f16": [_P, _P, _P, _L, _L, _L, _P],
     "dbmm_cast_f32_f16": [_P, _P, _L, _P],
+    "dbmm_conv3x3_c32_bn_relu_x2": [_P, _P, _P, _I, _P, _P, _P, _P, _L, _L, _L, _L, _L, _I, _P],
     "dbmm_gemm_bias_act_x3": [_P, _L, _P, _P, _L, _P, _P, _L, _P, _L, _L, _L, _L, _F, _I, _P, _Z, _P],
     "dbmm_gemm_batched": [_P, _L, _L, _I, _P, _L, _L, _I, _P, _L, _P, _L, _L, _L, _L, _L, _L, _F, _I, _P],
     "dbmm_conv_stem_s2": [_P, _P, _P, _P, _P, _L, _L, _L, _L, _P],

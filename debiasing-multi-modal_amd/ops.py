@@ -4,6 +4,7 @@ Every function requires HIP tensors -- there is no CPU path here.
 """
 import ctypes
 import math
+import os
 
 import torch
 
@@ -217,6 +218,19 @@ def conv_bn_act(x, w, bias, residual, kh, kw, stride, pad, act, w_layout=WL_TAP_
     oel = B * Ho * Wo * Cout
     nby_pool = 4 * (x.numel() + (residual.numel() if residual is not None else 0) + oel // 4 + (oel if keep_full else 0)) + wby
     nby = 4 * (x.numel() + (residual.numel() if residual is not None else 0) + oel) + wby
+    # the 32-channel stem convs: persistent patch kernel (csrc/conv_patch.hip); DBMM_CONV_PATCH=0 disables (read per call)
+    if (Cin == 32 and kh == 3 and kw == 3 and stride == 1 and pad == 1 and act == ACT_RELU and residual is None and not keep_full
+            and w_planes_f16 is not None and w_planes_f16.shape[0] == 1 and out_scale is not None and x_absmax is not None
+            and Cout in (32, 64) and H % 4 == 0 and W % 28 == 0 and (pool == 1 or (H % 2 == 0 and W % 2 == 0))
+            and w_layout in (WL_TAP_MAJOR, WL_CHUNK32_MAJOR) and os.environ.get("DBMM_CONV_PATCH", "1") != "0"):
+        y = torch.empty((B, H // pool, W // pool, Cout), device=x.device, dtype=torch.float32)
+        global _chain_tag
+        _chain_tag = f"conv3x3_c32_kernel<{Cout}, {int(pool == 2)}>"
+        with _Timed(B * H * W, Cout, 9 * Cin, -1, 0, 4 * (x.numel() + y.numel()) + 2 * Cout * 9 * Cin):
+            rc = _lib.lib().dbmm_conv3x3_c32_bn_relu_x2(ptr(x), ptr(x_absmax), ptr(w_planes_f16), int(w_exp), ptr(out_scale), ptr(bias),
+                                                       ptr(y), ptr(y_absmax), B, H, W, Cin, Cout, 2 if pool == 2 else 0, stream())
+            check(rc, "conv3x3_c32_bn_relu_x2")
+        return y
     if pool == 2 and split and Ho % 2 == 0 and Wo % 2 == 0:
         y = torch.empty((B, Ho // 2, Wo // 2, Cout), device=x.device, dtype=torch.float32)
         yf = torch.empty((B, Ho, Wo, Cout), device=x.device, dtype=torch.float32) if keep_full else None

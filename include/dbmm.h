@@ -176,6 +176,17 @@ int dbmm_gemm_dual_bn_act_x2(const float* a, int64_t lda, const float* a_absmax,
                              float* c_absmax, int64_t M, int64_t N, int act, void* workspace,
                              size_t workspace_bytes, void* stream);
 
+/* The two wide stem convolutions of ModifiedResNet (clip/model.py:108-116): 3x3 / stride 1 / pad 1 over Cin = 32
+ * channels, eval-mode BatchNorm scale / bias, ReLU, optional AvgPool2d(2) (pool = 2), one launch of a persistent kernel
+ * that keeps the whole weight in LDS and forms the nine taps from one 6 x 30 input patch per 4 x 28 output tile.
+ * x NHWC [B][H][W][32] with device scalar x_absmax; w_plane_f16 [Cout][kh][kw][32] = stored weight * 2^w_exp as one
+ * exact fp16 plane; y NHWC [B][H][W][Cout] or, pooled, [B][H/2][W/2][Cout]; y_absmax optional.  Same fp16-pair
+ * arithmetic as dbmm_conv_bn_act_x2.  Served: Cin = 32, Cout in {32, 64}, H % 4 == 0, W % 28 == 0; DBMM_E_UNSUPPORTED
+ * otherwise (nothing launched). */
+int dbmm_conv3x3_c32_bn_relu_x2(const float* x, const float* x_absmax, const void* w_plane_f16, int w_exp,
+                                const float* scale, const float* bias, float* y, float* y_absmax, int64_t B, int64_t H,
+                                int64_t W, int64_t Cin, int64_t Cout, int pool, void* stream);
+
 /* conv3 + residual of one bottleneck block chained with conv1 of the NEXT block (clip/model.py:42-55, two
  * consecutive Bottleneck.forward bodies) in one launch:
  *   x_out  = relu((y2 @ w3^T) * scale3 + bias3 + residual)        [B*Ho*Wo][N]

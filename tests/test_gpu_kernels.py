@@ -915,3 +915,33 @@ def test_bottleneck_chain_dual_first_block(M, N, P):
     if M >= 24576:                                      # the dual-source GEMM serves grids of >= 192 tiles
         xu = ops.gemm_dual(y2, ya, p3, e3, s3, a2, xa, pd, ratio, b3 + bd, ops.ACT_RELU)
         assert xu is not None and relerr(x.cpu(), xu.cpu()) < 2e-6
+
+
+@pytest.mark.parametrize("B,H,W,Cout,pool", [(2, 112, 112, 32, 1), (2, 112, 112, 64, 2), (3, 8, 28, 64, 1), (5, 4, 56, 32, 2),
+                                             (1, 12, 84, 64, 2), (300, 16, 28, 32, 1)])
+def test_conv3x3_c32_patch_kernel(B, H, W, Cout, pool, monkeypatch):
+    """the stem's 32-channel 3x3 convs on the persistent patch kernel == fp64 and == the implicit-GEMM kernels
+    (DBMM_CONV_PATCH=0), un-pooled and with the fused 2x2 average pool; image borders, several tiles per row, more tiles
+    than resident workgroups (B = 300: 1200 tiles over 768 slots)."""
+    g = torch.Generator(device=DEV); g.manual_seed(B + H + W + Cout)
+    x = torch.relu(torch.randn((B, H, W, 32), device=DEV, generator=g) * 2.0)
+    w = (torch.randn((Cout, 32, 3, 3), device=DEV, generator=g) * 288 ** -0.5).half().float()
+    sc = 0.5 + torch.rand((Cout,), device=DEV, generator=g); b = torch.randn((Cout,), device=DEV, generator=g) * 0.1
+    wp, wl = ops.pack_conv_weight(w, chunk_major=32)
+    ph, we, n = ops.split_planes_f16(wp, allow_single=True)
+    assert n == 1
+    xa = (x.abs().max() * 1.5).reshape(1)
+    kw = dict(w_planes_f16=ph, w_exp=we, x_absmax=xa, out_scale=sc, pool=pool)
+    am = torch.zeros(1, device=DEV)
+    monkeypatch.setenv("DBMM_CONV_PATCH", "1")
+    y = ops.conv_bn_act(x, wp, b, None, 3, 3, 1, 1, ops.ACT_RELU, wl, y_absmax=am, **kw)
+    ref = torch.relu(F.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), None, padding=1) * sc.double().view(1, -1, 1, 1)
+                     + b.double().view(1, -1, 1, 1))
+    assert am.item() >= y.abs().max().item() and am.item() <= ref.max().item() * (1 + 1e-5)
+    if pool == 2:
+        ref = F.avg_pool2d(ref, 2)
+    ref = ref.permute(0, 2, 3, 1)
+    assert tuple(y.shape) == tuple(ref.shape) and relerr(y.double().cpu(), ref.cpu()) < 5e-6
+    monkeypatch.setenv("DBMM_CONV_PATCH", "0")
+    y0 = ops.conv_bn_act(x, wp, b, None, 3, 3, 1, 1, ops.ACT_RELU, wl, **kw)
+    assert relerr(y.cpu(), y0.cpu()) < 2e-6
