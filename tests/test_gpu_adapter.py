@@ -214,3 +214,28 @@ def test_training_trajectory_matches_oracle(text_paths):
     oev = AO.custom_clip_logits(osd, x, tcls, 0.01, train=False)
     cnt = adapter.group_counts(ev, yd, grp.cuda(), 4).cpu().numpy()
     assert (cnt == AO.group_counts(oev, y, grp)).all()
+
+
+@pytest.mark.parametrize("D,C,B", [(1024, 2, 256), (512, 4, 100), (768, 2, 7)])
+def test_linear_classifier_forward_backward_vs_torch(D, C, B):
+    """LinearClassifier (final_main.py:43-49: linear probing head) forward and all three gradients against torch's
+    nn.Linear in fp64 on the same parameters."""
+    torch.manual_seed(0)
+    ref = torch.nn.Linear(D, C).double()
+    clf = adapter.LinearClassifier(D, C).cuda()
+    clf.fc.load_state_dict({k: v.float() for k, v in ref.state_dict().items()})
+    x = synth.normal(3, f"lin{D}", (B, D), 0.7)
+    y = synth.integers(4, f"liny{D}", (B,), C)
+    xd = x.cuda().requires_grad_(True)
+    out = clf(xd)
+    loss = torch.nn.functional.cross_entropy(out, y.cuda())
+    loss.backward()
+    xr = x.double().requires_grad_(True)
+    outr = ref(xr)
+    lossr = torch.nn.functional.cross_entropy(outr, y)
+    lossr.backward()
+    assert relerr(out.detach().cpu(), outr.detach()) < 1e-5 and abs(loss.item() - lossr.item()) < 1e-5
+    assert relerr(clf.fc.weight.grad.cpu(), ref.weight.grad) < 1e-5
+    assert relerr(clf.fc.bias.grad.cpu(), ref.bias.grad) < 1e-5
+    assert relerr(xd.grad.cpu(), xr.grad) < 1e-5
+    assert list(clf.state_dict().keys()) == ["fc.weight", "fc.bias"]

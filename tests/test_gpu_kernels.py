@@ -699,6 +699,7 @@ def test_conv3x3_halo_kernel(B, H, W, Cin, Cout, res, monkeypatch):
     kw = dict(w_planes_f16=ph, w_exp=we, x_absmax=xd.abs().max().reshape(1), out_scale=sc.to(DEV))
     am = torch.zeros(1, device=DEV)
     monkeypatch.setenv("DBMM_IGEMM_HALO", "1")
+    monkeypatch.setenv("DBMM_CONV_PATCH", "0")          # (the 32-channel stem shape would otherwise take the patch kernel)
     o = ops.conv_bn_act(xd, wp, b.to(DEV), rd, 3, 3, 1, 1, ops.ACT_RELU, wl, y_absmax=am, **kw)
     tag = ops._last_igemm_tag()
     assert tag.startswith("igemm_halo_kernel<"), tag
