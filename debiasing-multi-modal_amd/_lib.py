@@ -96,6 +96,7 @@ _SIGS = {
     "dbmm_attnpool": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _L, _L, _L, _L, _P, _Z, _P],
     "dbmm_layernorm": [_P, _L, _P, _P, _P, _L, _L, _L, _F, _P, _P],
     "dbmm_mha_core": [_P, _P, _L, _L, _L, _L, _I, _P],
+    "dbmm_mha_core_x2": [_P, _P, _P, _L, _L, _L, _L, _I, _P],
     "dbmm_embed_gather": [_P, _P, _P, _P, _L, _L, _L, _L, _P],
     "dbmm_im2col_patch": [_P, _P, _L, _L, _L, _P],
     "dbmm_vit_tokens": [_P, _P, _P, _P, _L, _L, _L, _P],

@@ -450,7 +450,7 @@ class Transformer(nn.Module):
             sc = (lambda am: dict(a_absmax=am)) if f16 else (lambda am: {})
             h = ops.layernorm(x, blk.ln_1.weight, blk.ln_1.bias, y_absmax=a[0])
             qkv = ops.gemm(h, blk.attn.in_proj_weight, blk.attn.in_proj_bias, c_absmax=a[1], **sc(a[0]), **p_in)
-            o = ops.mha_core(qkv, B, L, E, self.heads, self.causal)
+            o = ops.mha_core(qkv, B, L, E, self.heads, self.causal, qkv_absmax=a[1])
             x = ops.gemm(o, blk.attn.out_proj.weight, blk.attn.out_proj.bias, residual=x, **sc(a[1]), **p_out)
             h = ops.layernorm(x, blk.ln_2.weight, blk.ln_2.bias, y_absmax=a[2])
             h = ops.gemm(h, blk.mlp.c_fc.weight, blk.mlp.c_fc.bias, act=ops.ACT_QUICKGELU, c_absmax=a[3], **sc(a[2]), **p_fc)

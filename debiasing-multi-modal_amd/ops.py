@@ -412,10 +412,19 @@ def layernorm(x, gamma, beta, rows=None, ldx=None, eps=1e-5, y_absmax=None):
     return y
 
 
-def mha_core(qkv, B, L, E, heads, causal):
+def mha_core(qkv, B, L, E, heads, causal, qkv_absmax=None):
+    """softmax(q k^T / 8) v per (image, head).  With qkv_absmax (device scalar >= max|qkv|, the qkv GEMM's c_absmax) the
+    fp16-pair kernel runs (16-bit matrix cores, three partial products, fp32 accuracy); without it, or with
+    DBMM_MHA_X2=0, the fp32-input-MFMA kernel."""
     require_cuda(qkv)
     out = torch.empty((B * L, E), device=qkv.device, dtype=torch.float32)
-    check(_lib.lib().dbmm_mha_core(ptr(qkv), ptr(out), B, L, E, heads, int(causal), stream()), "mha_core")
+    if qkv_absmax is not None and os.environ.get("DBMM_MHA_X2", "1") != "0":
+        with _TimedTag("mha_pair_kernel", 4.0 * B * heads * L * L * 64, 4 * (B * L * 4 * E)):
+            check(_lib.lib().dbmm_mha_core_x2(ptr(qkv), ptr(qkv_absmax), ptr(out), B, L, E, heads, int(causal), stream()),
+                  "mha_core_x2")
+        return out
+    with _TimedTag("mha_mfma_kernel", 4.0 * B * heads * L * L * 64, 4 * (B * L * 4 * E)):
+        check(_lib.lib().dbmm_mha_core(ptr(qkv), ptr(out), B, L, E, heads, int(causal), stream()), "mha_core")
     return out
 
 

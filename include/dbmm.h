@@ -314,6 +314,13 @@ int dbmm_layernorm(const float* x, int64_t ldx, const float* gamma, const float*
 int dbmm_mha_core(const float* qkv, float* out, int64_t B, int64_t L, int64_t E, int64_t heads,
                   int causal, void* stream);
 
+/* The same attention core on the 16-bit matrix cores at fp32 accuracy: q, k, v as fp16 (hi, lo) pairs under the exact
+ * power-of-two scale derived from qkv_absmax (device scalar >= max|qkv|, the qkv GEMM's c_absmax), p as a pair under
+ * 2^13, three partial products per fp32 product, fp32 accumulation (csrc/mha_pair.hip).  Same layouts as
+ * dbmm_mha_core. */
+int dbmm_mha_core_x2(const float* qkv, const float* qkv_absmax, float* out, int64_t B, int64_t L, int64_t E,
+                     int64_t heads, int causal, void* stream);
+
 /* x[n][L][W] = table[tokens[n][l]] + pos[l]  (clip/model.py:344-346).  tokens int32. */
 int dbmm_embed_gather(const int32_t* tokens, const float* table, const float* pos, float* out,
                       int64_t n, int64_t L, int64_t W, int64_t vocab, void* stream);

@@ -946,3 +946,36 @@ def test_conv3x3_c32_patch_kernel(B, H, W, Cout, pool, monkeypatch):
     monkeypatch.setenv("DBMM_CONV_PATCH", "0")
     y0 = ops.conv_bn_act(x, wp, b, None, 3, 3, 1, 1, ops.ACT_RELU, wl, **kw)
     assert relerr(y.cpu(), y0.cpu()) < 2e-6
+
+
+@pytest.mark.parametrize("B,L,heads,causal", [(3, 50, 2, False), (2, 77, 8, True), (2, 130, 1, False), (1, 577, 2, False),
+                                              (2, 1, 1, False), (1, 128, 2, True), (2, 129, 1, True), (2, 300, 2, True)])
+@pytest.mark.parametrize("bound", [1.0, 37.0])
+def test_mha_core_fp16_pair_kernel(B, L, heads, causal, bound):
+    """parity-mode attention core on fp16-pair products (three partial products, scale from a bound of max|qkv|) against
+    fp64 softmax attention, and no worse than the fp32-input-MFMA kernel; exact and loose bounds."""
+    E = heads * 64
+    qkv = rnd(1, "qkv", (B, L, 3 * E)) * 1.7
+    q, k, v = qkv.double().split(E, dim=-1)
+    sh = lambda t: t.reshape(B, L, heads, 64).transpose(1, 2)
+    s = (sh(q) * 0.125) @ sh(k).transpose(-1, -2)
+    if causal:
+        s = s + torch.full((L, L), float("-inf"), dtype=torch.float64).triu_(1)
+    ref = (torch.softmax(s, -1) @ sh(v)).transpose(1, 2).reshape(B * L, E)
+    qd = qkv.to(DEV).view(B * L, 3 * E)
+    out = ops.mha_core(qd, B, L, E, heads, causal, qkv_absmax=(qd.abs().max() * bound).reshape(1))
+    base = ops.mha_core(qd, B, L, E, heads, causal)
+    e_pair, e_f32 = relerr(out.double().cpu(), ref), relerr(base.double().cpu(), ref)
+    assert e_pair < 5e-6 and e_pair < 4 * e_f32 + 1e-6, (e_pair, e_f32)
+
+
+def test_mha_core_fp16_pair_spiked_scores():
+    B, L, E = 1, 200, 64
+    qkv = rnd(1, "qkv", (B, L, 3 * E))
+    qkv[0, :, E:2 * E][37] *= 40.0
+    qkv[0, :, E:2 * E][150] *= -60.0
+    q, k, v = qkv.double().split(E, dim=-1)
+    ref = torch.softmax((q * 0.125) @ k.transpose(-1, -2), -1) @ v
+    qd = qkv.to(DEV).view(L, 3 * E)
+    out = ops.mha_core(qd, B, L, E, 1, False, qkv_absmax=qd.abs().max().reshape(1))
+    assert torch.isfinite(out).all() and relerr(out.double().cpu(), ref.reshape(L, E)) < 5e-6
