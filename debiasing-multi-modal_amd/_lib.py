@@ -98,7 +98,7 @@ _SIGS = {
     "dbmm_mha_core": [_P, _P, _L, _L, _L, _L, _I, _P],
     "dbmm_mha_core_x2": [_P, _P, _P, _L, _L, _L, _L, _I, _P],
     "dbmm_embed_gather": [_P, _P, _P, _P, _L, _L, _L, _L, _P],
-    "dbmm_im2col_patch": [_P, _P, _L, _L, _L, _P],
+    "dbmm_im2col_patch": [_P, _P, _P, _L, _L, _L, _P],
     "dbmm_vit_tokens": [_P, _P, _P, _P, _L, _L, _L, _P],
     "dbmm_gather_eot": [_P, _P, _P, _L, _L, _L, _P],
     "dbmm_bn1d_stats": [_P, _L, _L, _F, _F, _P, _P, _P, _P, _P, _P],

@@ -508,15 +508,17 @@ class VisionTransformer(nn.Module):
         B = x.shape[0]
         W = self.conv1.weight.shape[0]
         L = self.positional_embedding.shape[0]
-        cols = ops.im2col_patch(x, self.patch_size)                       # [B*g*g, 3*P*P]
         w1 = self.conv1.weight.reshape(W, -1)
         kw = {}
+        x_am = None
         if CONV_SPLIT == "f16" and w1.shape[1] % 16 == 0:                 # fp16-pair GEMM: planes cached per weight
             key = (w1.data_ptr(), w1._version)
             if getattr(self, "_conv1_planes", (None,))[0] != key:
                 ph, we, _ = ops.split_planes_f16(w1.detach().contiguous(), allow_single=True)
                 self._conv1_planes = (key, ph, we)
-            kw = dict(w_planes_f16=self._conv1_planes[1], w_exp=self._conv1_planes[2], a_absmax=x.abs().amax().reshape(1))
+            x_am = torch.zeros(1, device=x.device, dtype=torch.float32)   # max|x|, left there by the im2col kernel
+            kw = dict(w_planes_f16=self._conv1_planes[1], w_exp=self._conv1_planes[2], a_absmax=x_am)
+        cols = ops.im2col_patch(x, self.patch_size, out_absmax=x_am)      # [B*g*g, 3*P*P]
         patches = ops.gemm(cols, w1, **kw)                                # conv1 has no bias
         t = ops.vit_tokens(patches, self.class_embedding, self.positional_embedding, B)
         t = ops.layernorm(t, self.ln_pre.weight, self.ln_pre.bias)        # [B*L, W]

@@ -926,7 +926,7 @@ __global__ __launch_bounds__(256, MINB) void igemm_x3_kernel(const IgemmP p) {
 // ---------------------------------------------------------------------------------------------
 template <int BN>
 struct GeoHalo {
-    static constexpr int AR = 132;                        // LDS rows per A plane: 130 used + zero rows 130, 131
+    static constexpr int AR = 136;                        // LDS rows per A plane (8704 B = 34 x 256): 130 used + a 256-B zero line in rows 132..135
     static constexpr int A_STAGE = 2 * AR * 32;           // u16: [2 planes][AR][32]
     static constexpr int W_STAGE = BN * 32;               // u16: [BN][32]
     static constexpr int TILE_FLOATS = (2 * A_STAGE + 2 * W_STAGE) / 2;
@@ -938,7 +938,11 @@ __device__ __forceinline__ void igemm_tile_halo(const IgemmP& p, float* lds, int
     using G = Geo<BM, BN, WAVES_M, WAVES_N, BK>;
     using H = GeoHalo<BN>;
     constexpr int TM = G::TM, TN = G::TN, WTN = G::WTN, LROW = G::LROW;
-    constexpr int AR = H::AR, ZR = 131;
+    // Masked taps read zeros from the 256-B line at rows 132..135, at the SAME offset modulo 256 B as the address they
+    // replace: a redirected lane then sits on the bank quad it would have used anyway, so the redirect adds no bank
+    // conflict (one shared zero row did: PMC showed 18 % conflict cycles on the 14x14 / 7x7 maps, where most 16-lane
+    // groups hold a border pixel)
+    constexpr int AR = H::AR, ZB = 132 * 32;
     constexpr int ALD = 5;                                // 130 rows x 8 k-quads / 256 threads, passes of 32 rows
     constexpr int RPW = 64, WLD = (BN + RPW - 1) / RPW;   // W: 4 chunks per row, 64 rows per pass
     u16* As = (u16*)lds;                                  // [2 stages][2 planes][AR][32]
@@ -1062,7 +1066,7 @@ __device__ __forceinline__ void igemm_tile_halo(const IgemmP& p, float* lds, int
         for (int i = 0; i < TM; ++i) {
             const bool ok = (fmask[i] >> tap) & 1u;
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) aoff[i][ks] = ok ? faddr[i][kw][ks] : ZR * 32;
+            for (int ks = 0; ks < 2; ++ks) aoff[i][ks] = ok ? faddr[i][kw][ks] : ZB + (faddr[i][kw][ks] & 127);
         }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -1089,9 +1093,9 @@ __device__ __forceinline__ void igemm_tile_halo(const IgemmP& p, float* lds, int
     const int nk_all = p.K / 32;
     const int t_end = ue * 6 < nk_all ? ue * 6 : nk_all, g_end = ue * 2 < nk_all / 3 ? ue * 2 : nk_all / 3;
     __syncthreads();                                      // a previous tile of this workgroup may still use the LDS
-    // zero rows 130, 131 of both planes of both A stages (never written by the loader)
-    if (tid < 2 * 2 * 2 * 4) {                            // 2 stages x 2 planes x 2 rows x 4 chunks of 16 B
-        const int ch = tid & 3, row = 130 + ((tid >> 2) & 1), pl = (tid >> 3) & 1, st = tid >> 4;
+    // the 256-B zero line (rows 132..135) of both planes of both A stages (never written by the loader)
+    if (tid < 2 * 2 * 4 * 4) {                            // 2 stages x 2 planes x 4 rows x 4 chunks of 16 B
+        const int ch = tid & 3, row = 132 + ((tid >> 2) & 3), pl = (tid >> 4) & 1, st = tid >> 5;
         *(u32x4*)(As + st * H::A_STAGE + pl * AR * 32 + row * 32 + ch * 8) = (u32x4){0u, 0u, 0u, 0u};
     }
     load_a(2 * ub, true);

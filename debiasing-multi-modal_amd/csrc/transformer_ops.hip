@@ -388,8 +388,10 @@ __global__ __launch_bounds__(256) void embed_gather_kernel(const int32_t* __rest
 }
 
 __global__ __launch_bounds__(256) void im2col_patch_kernel(const float* __restrict__ x, float* __restrict__ out,
-                                                           int R, int P, int g, long long total) {
+                                                           int R, int P, int g, long long total,
+                                                           float* __restrict__ out_absmax) {
     const int K = 3 * P * P;
+    float amax = 0.f;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (long long)gridDim.x * blockDim.x) {
         const int k = (int)(i % K);
@@ -397,7 +399,19 @@ __global__ __launch_bounds__(256) void im2col_patch_kernel(const float* __restri
         const int gx = (int)(m % g), gy = (int)((m / g) % g);
         const long long b = m / ((long long)g * g);
         const int kw = k % P, kh = (k / P) % P, c = k / (P * P);
-        out[i] = x[((b * 3 + c) * R + (long long)gy * P + kh) * R + (long long)gx * P + kw];
+        const float v = x[((b * 3 + c) * R + (long long)gy * P + kh) * R + (long long)gx * P + kw];
+        out[i] = v;
+        amax = fmaxf(amax, fabsf(v));
+    }
+    if (out_absmax) {          // scale source of the fp16-pair patch GEMM: one filtered atomic per workgroup
+        __shared__ float wmax[4];
+        amax = wave_max(amax);
+        if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = amax;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            amax = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+            if (amax > *(volatile const float*)out_absmax) atomicMax((unsigned*)out_absmax, __float_as_uint(amax));
+        }
     }
 }
 
@@ -498,13 +512,14 @@ extern "C" int dbmm_embed_gather(const int32_t* tokens, const float* table, cons
     return DBMM_OK;
 }
 
-extern "C" int dbmm_im2col_patch(const float* x_nchw, float* out, int64_t B, int64_t R, int64_t P, void* stream) {
+extern "C" int dbmm_im2col_patch(const float* x_nchw, float* out, float* out_absmax, int64_t B, int64_t R, int64_t P,
+                                 void* stream) {
     if (!x_nchw || !out) return DBMM_E_ARG;
     if (B <= 0 || R <= 0 || P <= 0 || R % P) return DBMM_E_SHAPE;
     const int64_t g = R / P;
     const long long total = (long long)B * g * g * 3 * P * P;
     hipLaunchKernelGGL(im2col_patch_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x_nchw, out,
-                       (int)R, (int)P, (int)g, total);
+                       (int)R, (int)P, (int)g, total, out_absmax);
     DBMM_CHECK_LAUNCH();
     return DBMM_OK;
 }

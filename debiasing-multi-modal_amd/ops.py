@@ -441,13 +441,14 @@ def embed_gather(tokens, table, pos):
     return out, tokens
 
 
-def im2col_patch(x_nchw, P):
+def im2col_patch(x_nchw, P, out_absmax=None):
+    """[B,3,R,R] -> patch rows [B*g*g, 3*P*P]; out_absmax (1-element device tensor, zeroed by the caller) receives max|x|"""
     require_cuda(x_nchw)
     _f32c(x_nchw)
     B, C, R, _ = x_nchw.shape
     g = R // P
     out = torch.empty((B * g * g, 3 * P * P), device=x_nchw.device, dtype=torch.float32)
-    check(_lib.lib().dbmm_im2col_patch(ptr(x_nchw), ptr(out), B, R, P, stream()), "im2col_patch")
+    check(_lib.lib().dbmm_im2col_patch(ptr(x_nchw), ptr(out), ptr(out_absmax), B, R, P, stream()), "im2col_patch")
     return out
 
 

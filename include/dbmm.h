@@ -327,7 +327,8 @@ int dbmm_embed_gather(const int32_t* tokens, const float* table, const float* po
 
 /* patch im2col for the ViT stem conv (kernel = stride = P, clip/model.py:211,224):
  * out[B*g*g][3*P*P] in (cin, kh, kw) order = the flattened conv weight's K order. */
-int dbmm_im2col_patch(const float* x_nchw, float* out, int64_t B, int64_t R, int64_t P, void* stream);
+/* (out_absmax: optional device scalar, zeroed by the caller, receives max|out| = max|x| for the fp16-pair patch GEMM) */
+int dbmm_im2col_patch(const float* x_nchw, float* out, float* out_absmax, int64_t B, int64_t R, int64_t P, void* stream);
 
 /* tokens[B][g*g+1][W] = concat(class_embedding, patches[B][g*g][W]) + pos (clip/model.py:227-228) */
 int dbmm_vit_tokens(const float* patches, const float* cls, const float* pos, float* out,

@@ -248,7 +248,9 @@ def test_im2col_patch_and_tokens(R, P):
     B, W = 2, 64
     x = rnd(1, "x", (B, 3, R, R))
     g = R // P
-    cols = ops.im2col_patch(x.to(DEV), P)
+    am = torch.zeros(1, device=DEV)
+    cols = ops.im2col_patch(x.to(DEV), P, out_absmax=am)
+    assert am.item() == x.abs().max().item()
     ref = F.unfold(x, P, stride=P).transpose(1, 2).reshape(B * g * g, 3 * P * P)
     assert torch.equal(cols.cpu(), ref)
     patches = rnd(2, "pt", (B * g * g, W)); cls = rnd(3, "c", (W,)); pos = rnd(4, "pos", (g * g + 1, W))
