@@ -53,12 +53,19 @@ struct GemmHP {
     int M, N, K, act, tiles_n, n_tiles;
 };
 
-constexpr int GBM = 128, GBN = 128, GBK = 64;
+constexpr int GBM = 128, GBN = 128;
 constexpr int G_LROW = 64 + 4;                                   // epilogue staging pitch (floats) of a wave's 32 x 64 block
-constexpr int G_STAGE = (GBM + GBN) * GBK;                       // halves per stage
 
-__global__ __launch_bounds__(256, 2) void gemm_f16_kernel(const GemmHP p) {
-    __shared__ __attribute__((aligned(16))) u16 lds[2 * G_STAGE];                 // 64 KB; the epilogue staging aliases it
+// GBK = K depth of a chunk: 64 (128-B LDS rows, 64 KB for two stages, 2 workgroups per CU) or 32 (64-B rows, 32 KB, 3 per CU)
+template <int GBK>
+__device__ __forceinline__ int gswz(int row) { return GBK == 64 ? ((row >> 1) & 7) : ((row >> 2) & 3); }
+
+template <int GBK, int MINB>
+__global__ __launch_bounds__(256, MINB) void gemm_f16_kernel(const GemmHP p) {
+    constexpr int G_STAGE = (GBM + GBN) * GBK;                    // halves per stage
+    constexpr int EPI_HALVES = 4 * 32 * G_LROW * 2;               // the epilogue staging (fp32) aliases the stages
+    constexpr int CPR = GBK / 8, RPP = 256 / CPR, NLD = GBM / RPP;   // 16-B chunks per row, rows per pass, loads per operand
+    __shared__ __attribute__((aligned(16))) u16 lds[2 * G_STAGE > EPI_HALVES ? 2 * G_STAGE : EPI_HALVES];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 31, fh = lane >> 5;
     const int tile = xcd_remap(blockIdx.x, p.n_tiles);
@@ -67,12 +74,12 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(const GemmHP p) {
 
     const __amdgpu_buffer_rsrc_t rsA = desc(p.a, p.a_total, (long long)m0 * p.lda * 2);
     const __amdgpu_buffer_rsrc_t rsW = desc(p.w, p.w_total, (long long)n0 * p.ldw * 2);
-    // loader: 16-B chunk lc of rows lr + 32 i of both operands
-    const int lc = tid & 7, lr = tid >> 3;
-    unsigned a_off[4], w_off[4];
+    // loader: 16-B chunk lc of rows lr + RPP i of both operands
+    const int lc = tid % CPR, lr = tid / CPR;
+    unsigned a_off[NLD], w_off[NLD];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int r = lr + 32 * i;
+    for (int i = 0; i < NLD; ++i) {
+        const int r = lr + RPP * i;
         a_off[i] = m0 + r < p.M ? (unsigned)r * (unsigned)(p.lda * 2) + lc * 16u : OOR;
         w_off[i] = n0 + r < p.N ? (unsigned)r * (unsigned)(p.ldw * 2) + lc * 16u : OOR;
     }
@@ -82,23 +89,23 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(const GemmHP p) {
     const __amdgpu_buffer_rsrc_t rsW0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, 0, 0x00020000);
     // two register sets: the loads of chunk k+2 are issued while chunk k computes and chunk k+1 (landed) is written to
     // LDS -- one chunk of lead (16 MFMAs = 0.25 us) does not cover an L2 / HBM round trip
-    u32x4 a_r0[4], w_r0[4], a_r1[4], w_r1[4];
+    u32x4 a_r0[NLD], w_r0[NLD], a_r1[NLD], w_r1[NLD];
     const int nk = p.K / GBK;
-    auto load_chunk = [&](int kc, u32x4 (&a_r)[4], u32x4 (&w_r)[4]) {
+    auto load_chunk = [&](int kc, u32x4 (&a_r)[NLD], u32x4 (&w_r)[NLD]) {
         const bool valid = kc < nk;
         const __amdgpu_buffer_rsrc_t ra = valid ? rsA : rsA0, rw = valid ? rsW : rsW0;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) a_r[i] = __builtin_amdgcn_raw_buffer_load_b128(ra, a_off[i], (unsigned)(kc * GBK * 2), 0);
+        for (int i = 0; i < NLD; ++i) a_r[i] = __builtin_amdgcn_raw_buffer_load_b128(ra, a_off[i], (unsigned)(kc * GBK * 2), 0);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) w_r[i] = __builtin_amdgcn_raw_buffer_load_b128(rw, w_off[i], (unsigned)(kc * GBK * 2), 0);
+        for (int i = 0; i < NLD; ++i) w_r[i] = __builtin_amdgcn_raw_buffer_load_b128(rw, w_off[i], (unsigned)(kc * GBK * 2), 0);
     };
-    auto store_chunk = [&](int stage, const u32x4 (&a_r)[4], const u32x4 (&w_r)[4]) {
+    auto store_chunk = [&](int stage, const u32x4 (&a_r)[NLD], const u32x4 (&w_r)[NLD]) {
         u16* Ab = lds + stage * G_STAGE;
         u16* Wb = Ab + GBM * GBK;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = lr + 32 * i;
-            const int off = r * GBK + ((lc ^ swz64(r)) << 3);
+        for (int i = 0; i < NLD; ++i) {
+            const int r = lr + RPP * i;
+            const int off = r * GBK + ((lc ^ gswz<GBK>(r)) << 3);
             *(u32x4*)(Ab + off) = a_r[i];
             *(u32x4*)(Wb + off) = w_r[i];
         }
@@ -119,12 +126,12 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(const GemmHP p) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int r = wm0 + 32 * i + fr;
-                af[i] = *(const u32x4*)(Ab + r * GBK + (((2 * ks + fh) ^ swz64(r)) << 3));
+                af[i] = *(const u32x4*)(Ab + r * GBK + (((2 * ks + fh) ^ gswz<GBK>(r)) << 3));
             }
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int r = wn0 + 32 * j + fr;
-                wf[j] = *(const u32x4*)(Wb + r * GBK + (((2 * ks + fh) ^ swz64(r)) << 3));
+                wf[j] = *(const u32x4*)(Wb + r * GBK + (((2 * ks + fh) ^ gswz<GBK>(r)) << 3));
             }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -487,7 +494,7 @@ extern "C" int dbmm_gemm_f16(const void* a, int64_t lda, const void* w, int64_t 
     if (!a || !w || !c) return DBMM_E_ARG;
     if (M <= 0 || N <= 0 || K <= 0 || M > INT32_MAX || N > INT32_MAX || K > INT32_MAX) return DBMM_E_SHAPE;
     if (act < 0 || act > 2) return DBMM_E_ARG;
-    if ((K % GBK) || (N & 7)) return DBMM_E_UNSUPPORTED;
+    if ((K % 64) || (N & 7)) return DBMM_E_UNSUPPORTED;
     if ((lda & 7) || (ldw & 7) || (ldc & 7) || (residual && (ldr & 7)) || !dbmm_aligned16(a) || !dbmm_aligned16(w) || !dbmm_aligned16(c) ||
         (residual && !dbmm_aligned16(residual)) || (bias && !dbmm_aligned16(bias)))
         return DBMM_E_ALIGN;
@@ -498,7 +505,9 @@ extern "C" int dbmm_gemm_f16(const void* a, int64_t lda, const void* w, int64_t 
     p.M = (int)M; p.N = (int)N; p.K = (int)K; p.act = act;
     p.tiles_n = (int)((N + GBN - 1) / GBN);
     p.n_tiles = (int)((M + GBM - 1) / GBM) * p.tiles_n;
-    hipLaunchKernelGGL(gemm_f16_kernel, dim3(p.n_tiles), dim3(256), 0, (hipStream_t)stream, p);
+    static const int bk = [] { const char* e = getenv("DBMM_F16_BK"); return e ? atoi(e) : 64; }();   // developer A/B knob
+    if (bk == 32) hipLaunchKernelGGL((gemm_f16_kernel<32, 4>), dim3(p.n_tiles), dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((gemm_f16_kernel<64, 2>), dim3(p.n_tiles), dim3(256), 0, (hipStream_t)stream, p);
     DBMM_CHECK_LAUNCH();
     return DBMM_OK;
 }
