@@ -88,6 +88,8 @@ _SIGS = {
     "dbmm_gather_eot_f16": [_P, _P, _P, _L, _L, _L, _P],
     "dbmm_cast_f32_f16": [_P, _P, _L, _P],
     "dbmm_conv3x3_c32_bn_relu_x2": [_P, _P, _P, _I, _P, _P, _P, _P, _L, _L, _L, _L, _L, _I, _P],
+    "dbmm_bottleneck_block_chain_x2": [_P, _P, _P, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P,
+                                       _L, _L, _L, _L, _L, _L, _P],
     "dbmm_gemm_bias_act_x3": [_P, _L, _P, _P, _L, _P, _P, _L, _P, _L, _L, _L, _L, _F, _I, _P, _Z, _P],
     "dbmm_gemm_batched": [_P, _L, _L, _I, _P, _L, _L, _I, _P, _L, _P, _L, _L, _L, _L, _L, _L, _F, _I, _P],
     "dbmm_conv_stem_s2": [_P, _P, _P, _P, _P, _L, _L, _L, _L, _P],

@@ -141,6 +141,8 @@ _K_ORDER = False if os.environ.get("DBMM_CONV_K_ORDER", "chunk32") == "tap" else
 _FUSE_DS = os.environ.get("DBMM_FUSE_DS", "1") != "0"
 # conv3 + residual chained with the next block's conv1 in one launch (layer 1; DBMM_FUSE_CHAIN=0: separate launches)
 _FUSE_CHAIN = os.environ.get("DBMM_FUSE_CHAIN", "1") != "0"
+# ... and the block's own 3x3 conv2 inside that launch too (DBMM_FUSE_CONV2=0: conv2 as its own launch)
+_FUSE_CONV2 = os.environ.get("DBMM_FUSE_CONV2", "1") != "0"
 
 
 def _pack_conv(w64, bias, raw=None, scale=None):
@@ -281,6 +283,20 @@ class ModifiedResNet(nn.Module):
                     (out, oam), y1_next = y1_next, None
                 else:
                     out, oam = conv(x, am, e["c1"], None, 1, 0, ops.ACT_RELU)
+                nxt = blocks[bi] if bi < len(blocks) else None
+                if (e["stride"] == 1 and track and _FUSE_CHAIN and _FUSE_CONV2 and nxt is not None and nxt["stride"] == 1
+                        and all(c["sc"] is not None and c["ph"] is not None for c in (e["c2"], e["c3"], nxt["c1"]))
+                        and ("ds" not in e or ("dual" in e and _FUSE_DS))):
+                    # conv2 -> conv3 + residual (or downsample branch) -> next conv1: the whole rest of the block in ONE launch
+                    ndsl = 3 if "ds" in e else 2                # slots the separate launches would use after conv2's
+                    x_am, y1_am = amax[slot[0] + 1:slot[0] + 2], amax[slot[0] + ndsl:slot[0] + ndsl + 1]
+                    dual = dict(a2=x, a2_absmax=am, ds=e["ds"], ratio=e["dual"]["ratio"], bias=e["dual"]["bias"]) if "ds" in e else None
+                    r = ops.bottleneck_block_chain(out, oam, e["c2"], e["c3"], nxt["c1"], residual=None if dual else x, dual=dual,
+                                                   x_absmax=x_am, y1n_absmax=y1_am)
+                    if r is not None:
+                        slot[0] += ndsl + 1
+                        x, am, x_pooled, y1_next = r[0], x_am, None, (r[1], y1_am)
+                        continue
                 if e["stride"] == 2:      # conv2 + bn2 + ReLU + AvgPool2d(2) in one epilogue
                     out, oam = conv(out, oam, e["c2"], None, 3, 1, ops.ACT_RELU, pool=2)
                 else:

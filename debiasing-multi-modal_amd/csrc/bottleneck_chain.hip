@@ -55,6 +55,10 @@ struct ChainP {
     // downsample branch bn_d(conv_d(a2)).  Like dbmm_gemm_dual_bn_act_x2 the branch's K2 = 64 chunk is accumulated
     // first, the accumulators are multiplied by ratio[n] * 2^(s - s2) and the main pair continues in them.
     const float* a2; const float* a2_absmax; const u16* wd; const float* ratio;     // a2 [M][64], wd [N][64] fp16 plane
+    // CONV2: the launch starts one conv earlier -- `a` is y1 [M][K] (conv2's input, NHWC, M = B * H * W pixels in standard
+    // order) and the y2 tile is computed here by the 3x3 / pad 1 conv2 + BatchNorm + ReLU instead of being read from HBM.
+    const u16* w2; int w2_exp; const float* sc2; const float* b2;      // [K][(cin/32, kh, kw, 32)] fp16 plane of W2 * 2^w2_exp
+    int H, W;
 };
 
 __device__ __forceinline__ int scale_exp(float amax) {      // s with amax * 2^s in [2^13, 2^14)
@@ -110,15 +114,30 @@ __device__ __forceinline__ int row_pixel(const ChainP& p, int m) {
     return (n * p.Ho + 2 * hp + (q >> 1)) * p.Wo + 2 * (rem - hp * wp2) + (q & 1);
 }
 
-template <int K, int P, int POOL, int DUAL = 0>
+// CONV2 phase geometry: the activation strip of one (32-channel slab, kh) group -- 130 pixels [m0 - 1, m0 + 128] shifted by
+// (kh - 1) image rows, as fp16 (hi, lo) planes -- and the group's three kw taps of W2
+constexpr int C2_SROWS = 132, C2_PLANE = C2_SROWS * 32;          // strip rows (130 used), halves per plane (8448 B = 33 x 256)
+constexpr int C2_W2P = 104;                                      // LDS pitch of a W2 group row in halves (96 used; 208 B rows: conflict-free)
+template <int K>
+struct Conv2Geo {
+    static constexpr int W2_OFF = 2 * C2_PLANE;                   // halves
+    static constexpr int Z_OFF = (2 * C2_PLANE * 2 + K * C2_W2P * 2 + 255) / 256 * 256;   // bytes: 256-B zero line
+    static constexpr int BYTES = Z_OFF + 256;
+    static constexpr int STAGE_BYTES = BM * 68 * 4;               // y2 staging, 64 channels at a time
+};
+constexpr int cmax(int a, int b) { return a > b ? a : b; }
+
+template <int K, int P, int POOL, int DUAL = 0, int CONV2 = 0>
 __global__ __launch_bounds__(256, 2) void bottleneck_chain_kernel(const ChainP p) {
     static_assert(!DUAL || K == 64, "dual-source variant: layer-1 geometry (K = K2 = 64)");
+    static_assert(!CONV2 || !POOL, "the conv2 phase walks pixels in standard order");
     static_assert(K == 64 || K == 128, "conv3 reduction depth: 64 (layer 1) or 128 (layer 2)");
     static_assert(P == 64 || P == 128, "conv1' width");
     using G = ChainGeo<K, P>;
     constexpr int BNS = G::BNS, SLROW = G::SLROW;
     constexpr int KS = K / 16, TN3 = BNS / 32, TN1 = P / 32;
-    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[G::LDS_BYTES + (DUAL ? BNS * 64 * 2 : 0)];
+    constexpr int LDS_TOTAL = cmax(G::LDS_BYTES + (DUAL ? BNS * 64 * 2 : 0), CONV2 ? cmax(Conv2Geo<K>::BYTES, Conv2Geo<K>::STAGE_BYTES) : 0);
+    __shared__ __attribute__((aligned(256))) unsigned char lds_raw[LDS_TOTAL];
     u16* Ay = (u16*)lds_raw;                                       // [2 planes][128][64] (prologue only)
     float* slab = (float*)lds_raw;                                 // [4 waves][32][SLROW]   (aliases Ay)
     u16* W3b = (u16*)(lds_raw + G::R1_BYTES);                      // [BNS][K]
@@ -235,9 +254,150 @@ __global__ __launch_bounds__(256, 2) void bottleneck_chain_kernel(const ChainP p
             dst[ks][1] = *(const u32x4*)(Ay + BM * 64 + off);
         }
     };
-    const int s_a = scale_exp(*p.a_absmax);
+    int s_a;                                            // exponent of the scale the A fragments carry
+    if constexpr (!CONV2) {
+        s_a = scale_exp(*p.a_absmax);
 #pragma unroll
-    for (int kp = 0; kp < K / 64; ++kp) stage_pass(rsA, K, kp * 64, pow2f(s_a), af + kp * 4);
+        for (int kp = 0; kp < K / 64; ++kp) stage_pass(rsA, K, kp * 64, pow2f(s_a), af + kp * 4);
+    } else {
+        // ---- conv2 (3x3, pad 1) + BatchNorm + ReLU of this tile: y2 never goes to HBM --------------------------------
+        // K-loop groups g = (32-channel slab, kh): the 130-pixel strip [m0 - 1, m0 + 128] + (kh - 1) * W serves the three
+        // kw taps by LDS row shifts (igemm_halo_kernel's idea), the group's W2 columns are 96 contiguous halves per output
+        // channel.  One LDS stage, the next group in flight in registers, two barriers per group.  Border taps read a
+        // 256-B zero line at their own offset modulo 256 B.
+        using C2 = Conv2Geo<K>;
+        constexpr int TN2 = K / 32, NG = (K / 32) * 3, W2LD = (K * 12 + 255) / 256;
+        u16* Sp = (u16*)lds_raw;                                     // [2 planes][132][32]
+        u16* W2b = Sp + C2::W2_OFF;                                  // [K][C2_W2P]
+        constexpr int ZLH = C2::Z_OFF / 2;                           // zero line, halves from the LDS base
+        if (tid < 16) *(u32x4*)(lds_raw + C2::Z_OFF + tid * 16) = (u32x4){0u, 0u, 0u, 0u};
+        const int s_y1 = scale_exp(*p.a_absmax);
+        const float y1_sc = pow2f(s_y1);
+        const int px0 = m0 - 1 - p.W > 0 ? m0 - 1 - p.W : 0;
+        const __amdgpu_buffer_rsrc_t rsS = desc(p.a, Mll * K * 4, (long long)px0 * K * 4);
+        const int lc = tid & 7, lr = tid >> 3;                       // strip: k-quad lc of rows lr + 32 i
+        unsigned s_off[5];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int j = lr + 32 * i;
+            s_off[i] = j < 130 ? (unsigned)((m0 - 1 + j - px0) * (K * 4)) + lc * 16u : OOR;
+        }
+        // this lane's output pixel (A-operand row 32 wave + fr): tap validity, bit kh * 3 + kw
+        unsigned fmask = 0;
+        {
+            const int m = m0 + wave * 32 + fr;
+            if (m < p.M) {
+                const int hw = p.H * p.W, rem = m - (m / hw) * hw, ho = rem / p.W, wo = rem - ho * p.W;
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw)
+                        if (ho + kh - 1 >= 0 && ho + kh - 1 < p.H && wo + kw - 1 >= 0 && wo + kw - 1 < p.W) fmask |= 1u << (kh * 3 + kw);
+            }
+        }
+        f32x4 sq[5];
+        u32x4 w2q[W2LD];
+        auto load_group = [&](int g) {
+            const int sl = g / 3, kh = g - sl * 3;
+            const unsigned delta = (unsigned)(((kh - 1) * p.W * K + sl * 32) * 4);
+#pragma unroll
+            for (int i = 0; i < 5; ++i)
+                sq[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsS, s_off[i] == OOR ? OOR : s_off[i] + delta, 0, 0));
+#pragma unroll
+            for (int i = 0; i < W2LD; ++i) {
+                const int idx = tid + 256 * i, row = idx / 12, c = idx - row * 12;
+                w2q[i] = idx < K * 12 ? *(const u32x4*)(p.w2 + (size_t)row * (9 * K) + (size_t)g * 96 + c * 8) : (u32x4){0u, 0u, 0u, 0u};
+            }
+        };
+        auto store_group = [&]() {
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                const int row = lr + 32 * i;
+                if (row < 130) {
+                    unsigned hp[2], lp[2];
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) split2h_pair(sq[i][2 * j], sq[i][2 * j + 1], y1_sc, hp[j], lp[j]);
+                    const int off = row * 32 + (((lc >> 1) ^ swz<32>(row)) << 3) + ((lc & 1) << 2);
+                    *(u32x2*)(Sp + off) = (u32x2){hp[0], hp[1]};
+                    *(u32x2*)(Sp + C2_PLANE + off) = (u32x2){lp[0], lp[1]};
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < W2LD; ++i) {
+                const int idx = tid + 256 * i, row = idx / 12, c = idx - row * 12;
+                if (idx < K * 12) *(u32x4*)(W2b + row * C2_W2P + c * 8) = w2q[i];
+            }
+        };
+        f32x16 acc2[TN2];
+#pragma unroll
+        for (int j = 0; j < TN2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc2[j][r] = 0.f;
+        load_group(0);
+        for (int g = 0; g < NG; ++g) {
+            store_group();
+            __syncthreads();
+            if (g + 1 < NG) load_group(g + 1);
+            const int kh = g % 3;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const bool ok = (fmask >> (kh * 3 + kw)) & 1u;
+                const int row = wave * 32 + fr + kw;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const int addr = row * 32 + (((2 * ks + fh) ^ swz<32>(row)) << 3);
+                    const int a0 = ok ? addr : ZLH + (addr & 127), a1 = ok ? addr + C2_PLANE : ZLH + (addr & 127);
+                    const u32x4 ah = *(const u32x4*)(Sp + a0), al = *(const u32x4*)(Sp + a1);
+                    u32x4 wf[TN2];
+#pragma unroll
+                    for (int j = 0; j < TN2; ++j) wf[j] = *(const u32x4*)(W2b + (j * 32 + fr) * C2_W2P + kw * 32 + (2 * ks + fh) * 8);
+#pragma unroll
+                    for (int j = 0; j < TN2; ++j)
+                        acc2[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, al), __builtin_bit_cast(f16x8, wf[j]), acc2[j], 0, 0, 0);
+#pragma unroll
+                    for (int j = 0; j < TN2; ++j)
+                        acc2[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah), __builtin_bit_cast(f16x8, wf[j]), acc2[j], 0, 0, 0);
+                }
+            }
+            __syncthreads();
+        }
+        // y2 = relu(bn2(.)) in the accumulator layout; its fp16 scale is the wave's own maximum (the wave's 32 rows feed only
+        // this wave's conv3); through a wave-private fp32 staging block, 64 channels at a time, into A fragments
+        const float c2_scale = pow2f(-s_y1 - p.w2_exp);
+        float ymax = 0.f;
+#pragma unroll
+        for (int j = 0; j < TN2; ++j) {
+            const float sv = p.sc2[j * 32 + fr] * c2_scale, bv = p.b2[j * 32 + fr];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = fmaxf(fmaf(acc2[j][r], sv, bv), 0.f);
+                if (gx[r >> 2] == OOR) v = 0.f;
+                acc2[j][r] = v;
+                ymax = fmaxf(ymax, v);
+            }
+        }
+        s_a = scale_exp(wave_max(ymax));
+        const float y2_sc = pow2f(s_a);
+        float* St = (float*)lds_raw + wave * (32 * 68);
+#pragma unroll
+        for (int h = 0; h < K / 64; ++h) {
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) St[((r & 3) + 8 * (r >> 2) + 4 * fh) * 68 + jj * 32 + fr] = acc2[2 * h + jj][r];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const f32x4 x0 = *(const f32x4*)(St + fr * 68 + 16 * ks + 8 * fh), x1 = *(const f32x4*)(St + fr * 68 + 16 * ks + 8 * fh + 4);
+                unsigned hh[4], ll[4];
+                split2h_pair(x0[0], x0[1], y2_sc, hh[0], ll[0]); split2h_pair(x0[2], x0[3], y2_sc, hh[1], ll[1]);
+                split2h_pair(x1[0], x1[1], y2_sc, hh[2], ll[2]); split2h_pair(x1[2], x1[3], y2_sc, hh[3], ll[3]);
+                af[4 * h + ks][0] = (u32x4){hh[0], hh[1], hh[2], hh[3]};
+                af[4 * h + ks][1] = (u32x4){ll[0], ll[1], ll[2], ll[3]};
+            }
+        }
+        __syncthreads();                                // staging done in every wave: the chain's buffers may be filled
+        if constexpr (!DUAL) store_w();
+    }
     float dual_dyn = 1.f;
     if constexpr (DUAL) {
         const int s_a2 = scale_exp(*p.a2_absmax);
@@ -407,6 +567,46 @@ __global__ __launch_bounds__(256, 2) void bottleneck_chain_kernel(const ChainP p
 }  // namespace
 
 // see include/dbmm.h
+extern "C" int dbmm_bottleneck_block_chain_x2(const float* y1, const float* y1_absmax, const void* w2_plane_f16, int w2_exp,
+                                              const float* scale2, const float* bias2, const void* w3_plane_f16, int w3_exp,
+                                              const float* scale3, const float* bias3, const float* residual, const float* a2,
+                                              const float* a2_absmax, const void* wd_plane_f16, const float* ratio, float* x_out,
+                                              float* x_absmax, const void* w1_plane_f16, int w1_exp, const float* scale1,
+                                              const float* bias1, float* y1_out, float* y1_out_absmax, int64_t B, int64_t H,
+                                              int64_t W, int64_t K, int64_t N, int64_t P, void* stream) {
+    const bool dual = a2 != nullptr;
+    if (!y1 || !y1_absmax || !w2_plane_f16 || !scale2 || !bias2 || !w3_plane_f16 || !scale3 || !bias3 || !x_out || !w1_plane_f16 ||
+        !scale1 || !bias1 || !y1_out)
+        return DBMM_E_ARG;
+    if (dual ? (!a2_absmax || !wd_plane_f16 || !ratio || residual) : (!residual || a2_absmax || wd_plane_f16 || ratio)) return DBMM_E_ARG;
+    if (B <= 0 || H <= 0 || W <= 0 || K <= 0 || N <= 0 || P <= 0) return DBMM_E_SHAPE;
+    const int64_t M = B * H * W;
+    if (M > (INT32_MAX >> 1)) return DBMM_E_SHAPE;
+    const bool served = dual ? (K == 64 && P == 64) : ((K == 64 && P == 64) || (K == 128 && P == 128));
+    if (!served || (N % 64) != 0 || (M & 3)) return DBMM_E_UNSUPPORTED;
+    if (w2_exp < -40 || w2_exp > 40 || w3_exp < -40 || w3_exp > 40 || w1_exp < -40 || w1_exp > 40) return DBMM_E_UNSUPPORTED;
+    if (!dbmm_aligned16(y1) || !dbmm_aligned16(w2_plane_f16) || !dbmm_aligned16(w3_plane_f16) || !dbmm_aligned16(w1_plane_f16) ||
+        !dbmm_aligned16(x_out) || !dbmm_aligned16(y1_out) || (residual && !dbmm_aligned16(residual)) || (a2 && !dbmm_aligned16(a2)) ||
+        (wd_plane_f16 && !dbmm_aligned16(wd_plane_f16)))
+        return DBMM_E_ALIGN;
+    ChainP p{};
+    p.a = y1; p.a_absmax = y1_absmax;
+    p.w2 = (const u16*)w2_plane_f16; p.w2_exp = w2_exp; p.sc2 = scale2; p.b2 = bias2; p.H = (int)H; p.W = (int)W;
+    p.w3 = (const u16*)w3_plane_f16; p.w3_exp = w3_exp; p.sc3 = scale3; p.b3 = bias3;
+    p.res = residual; p.a2 = a2; p.a2_absmax = a2_absmax; p.wd = (const u16*)wd_plane_f16; p.ratio = ratio;
+    p.x = x_out; p.x_absmax = x_absmax;
+    p.w1 = (const u16*)w1_plane_f16; p.w1_exp = w1_exp; p.sc1 = scale1; p.b1 = bias1;
+    p.y1 = y1_out; p.y1_absmax = y1_out_absmax;
+    p.M = (int)M; p.N = (int)N; p.Ho = (int)H; p.Wo = (int)W;
+    const dim3 grid((unsigned)((M + BM - 1) / BM));
+    hipStream_t s = (hipStream_t)stream;
+    if (dual) hipLaunchKernelGGL((bottleneck_chain_kernel<64, 64, 0, 1, 1>), grid, dim3(256), 0, s, p);
+    else if (K == 64) hipLaunchKernelGGL((bottleneck_chain_kernel<64, 64, 0, 0, 1>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((bottleneck_chain_kernel<128, 128, 0, 0, 1>), grid, dim3(256), 0, s, p);
+    DBMM_CHECK_LAUNCH();
+    return DBMM_OK;
+}
+
 extern "C" int dbmm_bottleneck_chain_dual_x2(const float* y2, const float* y2_absmax, const void* w3_plane_f16, int w3_exp,
                                              const float* scale3, const float* bias, const float* a2, const float* a2_absmax,
                                              const void* wd_plane_f16, const float* ratio, float* x_out, float* x_absmax,

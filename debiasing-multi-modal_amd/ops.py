@@ -334,6 +334,46 @@ def bottleneck_chain(y2, y2_absmax, c3, residual, c1, x_absmax=None, y1_absmax=N
 _chain_tag = None
 
 
+def bottleneck_block_chain(y1, y1_absmax, c2, c3, c1, residual=None, dual=None, x_absmax=None, y1n_absmax=None):
+    """one stride-1 bottleneck block from its conv1 output on, continued into the next block's conv1, ONE launch
+    (dbmm_bottleneck_block_chain_x2): y1 -> conv2 3x3 -> conv3 + residual (or, dual = dict(a2, a2_absmax, ds, ratio, bias):
+    + downsample branch) -> x' -> conv1' -> y1'.  c2 / c3 / c1 = plan entries (c2 in the chunk32-major K order).
+    Returns (x', y1') or None when the library has no kernel for the shape."""
+    require_cuda(y1)
+    _f32c(y1)
+    B, H, W, K = y1.shape
+    N, P = c3["ph"].shape[1], c1["ph"].shape[1]
+    M = B * H * W
+    if (c2["ph"] is None or c2["ph"].shape[0] != 1 or c2["wl"] != WL_CHUNK32_MAJOR or tuple(c2["ph"].shape[1:]) != (K, 9 * K)
+            or c3["ph"].shape[0] != 1 or c1["ph"].shape[0] != 1 or N % 64 or M % 4):
+        return None
+    if dual is None:
+        if (K, P) not in ((64, 64), (128, 128)) or residual is None or tuple(residual.shape) != (B, H, W, N):
+            return None
+    elif (K, P) != (64, 64) or dual["ds"]["ph"].shape[0] != 1 or tuple(dual["a2"].shape) != (B, H, W, 64):
+        return None
+    x = torch.empty((B, H, W, N), device=y1.device, dtype=torch.float32)
+    y1n = torch.empty((B, H, W, P), device=y1.device, dtype=torch.float32)
+    global _chain_tag
+    _chain_tag = f"bottleneck_chain_kernel<{K}, {P}, 0, {int(dual is not None)}, 1>"
+    K2 = 64 if dual is not None else 0
+    nby = 4 * (M * K + M * N * (1 if dual is not None else 2) + M * K2 + M * P) + 2 * (K * 9 * K + N * K + N * K2 + P * N)
+    t = _Timed(M, 1, 9 * K * K + N * (K + K2 + P), -1, 0, nby)
+    t.__enter__()
+    d = dual or {}
+    bias3 = d["bias"] if dual is not None else c3["b"]
+    rc = _lib.lib().dbmm_bottleneck_block_chain_x2(
+        ptr(y1), ptr(y1_absmax), ptr(c2["ph"]), int(c2["we"]), ptr(c2["sc"]), ptr(c2["b"]), ptr(c3["ph"]), int(c3["we"]),
+        ptr(c3["sc"]), ptr(bias3), ptr(residual) if dual is None else None, ptr(d.get("a2")), ptr(d.get("a2_absmax")),
+        ptr(d["ds"]["ph"]) if dual is not None else None, ptr(d.get("ratio")), ptr(x), ptr(x_absmax), ptr(c1["ph"]), int(c1["we"]),
+        ptr(c1["sc"]), ptr(c1["b"]), ptr(y1n), ptr(y1n_absmax), B, H, W, K, N, P, stream())
+    if rc == _lib.E_UNSUPPORTED:
+        return None
+    check(rc, "bottleneck_block_chain_x2")
+    t.__exit__(None, None, None)
+    return x, y1n
+
+
 def bottleneck_chain_dual(y2, y2_absmax, c3, a2, a2_absmax, ds, ratio, bias, c1, x_absmax=None, y1_absmax=None):
     """first block of a stage at unchanged resolution: x' = relu(bn3(conv3(y2)) + bn_d(conv_d(a2))), then the next
     block's y1' = relu(bn1'(conv1'(x'))), one launch (dbmm_bottleneck_chain_dual_x2).  Returns (x', y1') or None."""

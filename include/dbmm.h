@@ -217,6 +217,21 @@ int dbmm_bottleneck_chain_dual_x2(const float* y2, const float* y2_absmax, const
                                   float* y1_out, float* y1_absmax, int64_t M, int64_t K, int64_t K2, int64_t N,
                                   int64_t P, void* stream);
 
+/* The same chains started one conv earlier: conv2 (3x3, pad 1) + BatchNorm + ReLU of the block is computed inside the
+ * launch from the block's conv1 output y1 (NHWC [B][H][W][K], device scalar y1_absmax), so neither y2 nor -- for conv1' --
+ * x_out is read back from HBM:  y1 -> conv2 -> conv3 + (residual | downsample branch) -> x_out -> next conv1 -> y1_out.
+ * w2_plane_f16 [K][(cin/32, kh, kw, 32)] = the stored 3x3 weight times 2^w2_exp as one exact fp16 plane in the
+ * DBMM_WL_CHUNK32_MAJOR K order.  Pass `residual` for an ordinary block, or (a2, a2_absmax, wd_plane_f16, ratio) with
+ * residual = NULL for a stage's first block at unchanged resolution (see dbmm_bottleneck_chain_dual_x2).
+ * Served: (K, P) = (64, 64) or (128, 128); dual: (64, 64); N % 64 == 0; B*H*W % 4 == 0.  DBMM_E_UNSUPPORTED otherwise. */
+int dbmm_bottleneck_block_chain_x2(const float* y1, const float* y1_absmax, const void* w2_plane_f16, int w2_exp,
+                                   const float* scale2, const float* bias2, const void* w3_plane_f16, int w3_exp,
+                                   const float* scale3, const float* bias3, const float* residual, const float* a2,
+                                   const float* a2_absmax, const void* wd_plane_f16, const float* ratio, float* x_out,
+                                   float* x_absmax, const void* w1_plane_f16, int w1_exp, const float* scale1,
+                                   const float* bias1, float* y1_out, float* y1_out_absmax, int64_t B, int64_t H,
+                                   int64_t W, int64_t K, int64_t N, int64_t P, void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * fp16 mode of the transformer towers -- the reference's GPU path (convert_weights, clip/model.py:375-396; fp16
  * activations, fp32 LayerNorm statistics, clip/model.py:157-163).  Tensors marked f16 are IEEE half in HBM; every

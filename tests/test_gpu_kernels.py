@@ -981,3 +981,49 @@ def test_mha_core_fp16_pair_spiked_scores():
     qd = qkv.to(DEV).view(L, 3 * E)
     out = ops.mha_core(qd, B, L, E, 1, False, qkv_absmax=qd.abs().max().reshape(1))
     assert torch.isfinite(out).all() and relerr(out.double().cpu(), ref.reshape(L, E)) < 5e-6
+
+
+@pytest.mark.parametrize("B,H,W,K,N,P,dual", [(8, 56, 56, 64, 256, 64, False), (8, 56, 56, 64, 256, 64, True), (16, 28, 28, 128, 512, 128, False),
+                                              (3, 10, 14, 64, 128, 64, False), (5, 6, 6, 128, 256, 128, False), (3, 10, 14, 64, 128, 64, True),
+                                              (70, 7, 8, 64, 64, 64, False)])
+def test_bottleneck_block_chain_conv2_conv3_next_conv1(B, H, W, K, N, P, dual):
+    """conv2 3x3 + bn + relu -> conv3 + bn + (residual | downsample branch) + relu -> next block's conv1 + bn + relu as ONE
+    launch (clip/model.py:42-55) == fp64 and == the separate launches; image borders, images smaller than a tile (several
+    images and an M tail in one 128-pixel tile), layer-1 / layer-2 geometry."""
+    g = torch.Generator(device=DEV); g.manual_seed(B * 7 + H + K + N + int(dual))
+    rn = lambda *sh: torch.randn(sh, device=DEV, generator=g)
+    y1 = torch.relu(rn(B, H, W, K) * 1.5)
+    w2 = (rn(K, K, 3, 3) * (9 * K) ** -0.5).half().float(); w3 = (rn(N, K) * K ** -0.5).half().float(); w1 = (rn(P, N) * N ** -0.5).half().float()
+    mk = lambda n: (0.5 + torch.rand((n,), device=DEV, generator=g), rn(n) * 0.1)
+    (s2, b2), (s3, b3), (s1, b1) = mk(K), mk(N), mk(P)
+    w2p, wl = ops.pack_conv_weight(w2, chunk_major=32)
+    p2, e2, n2 = ops.split_planes_f16(w2p, allow_single=True); p3, e3, _ = ops.split_planes_f16(w3, allow_single=True)
+    p1, e1, _ = ops.split_planes_f16(w1, allow_single=True)
+    assert n2 == 1 and wl == ops.WL_CHUNK32_MAJOR
+    c2 = dict(w=w2p, wl=wl, ph=p2, we=e2, sc=s2, b=b2); c3 = dict(ph=p3, we=e3, sc=s3, b=b3); c1 = dict(ph=p1, we=e1, sc=s1, b=b1)
+    ya = (y1.abs().max() * 1.2).reshape(1)
+    xam, yam = torch.zeros(1, device=DEV), torch.zeros(1, device=DEV)
+    M = B * H * W
+    y2r = torch.relu(F.conv2d(y1.permute(0, 3, 1, 2).double(), w2.double(), None, padding=1) * s2.double().view(1, -1, 1, 1)
+                     + b2.double().view(1, -1, 1, 1)).permute(0, 2, 3, 1).reshape(M, K)
+    if dual:
+        a2 = torch.relu(rn(B, H, W, 64) * 3.0); wd = (rn(N, 64) * 0.125).half().float(); sd, bd = mk(N)
+        pd, ed, _ = ops.split_planes_f16(wd, allow_single=True)
+        ratio = (sd.double() / s3.double() * 2.0 ** (e3 - ed)).float()
+        dd = dict(a2=a2, a2_absmax=(a2.abs().max() * 1.4).reshape(1), ds=dict(ph=pd, we=ed, sc=sd, b=bd), ratio=ratio, bias=b3 + bd)
+        r = ops.bottleneck_block_chain(y1, ya, c2, c3, c1, dual=dd, x_absmax=xam, y1n_absmax=yam)
+        xr = torch.relu(y2r @ w3.double().t() * s3.double() + a2.view(M, 64).double() @ wd.double().t() * sd.double() + (b3 + bd).double())
+    else:
+        res = torch.relu(rn(B, H, W, N) * 2.0)
+        r = ops.bottleneck_block_chain(y1, ya, c2, c3, c1, residual=res, x_absmax=xam, y1n_absmax=yam)
+        xr = torch.relu(y2r @ w3.double().t() * s3.double() + b3.double() + res.view(M, N).double())
+    assert r is not None
+    x, y1n = r
+    yr = torch.relu(xr @ w1.double().t() * s1.double() + b1.double())
+    assert relerr(x.view(M, N).double().cpu(), xr.cpu()) < 5e-6
+    assert relerr(y1n.view(M, P).double().cpu(), yr.cpu()) < 5e-6
+    assert xam.item() == x.abs().max().item() and yam.item() == y1n.abs().max().item()
+    if not dual:            # the separate launches: halo / per-tap conv2, then the conv3 -> conv1 chain
+        y2 = ops.conv_bn_act(y1, w2p, b2, None, 3, 3, 1, 1, ops.ACT_RELU, wl, w_planes_f16=p2, w_exp=e2, x_absmax=ya, out_scale=s2)
+        xu = ops.conv_bn_act(y2, w3, b3, res, 1, 1, 1, 0, ops.ACT_RELU, w_planes_f16=p3, w_exp=e3, x_absmax=y2.abs().max().reshape(1), out_scale=s3)
+        assert relerr(x.cpu(), xu.cpu()) < 3e-6
