@@ -121,3 +121,35 @@ def test_fp16_mode_rn_tower_rounds_its_fp32_accurate_output():
     convert_weights(model)
     out = model.encode_image(img)
     assert out.dtype == torch.float16 and relerr(out.float().cpu(), ref.cpu()) < 1e-3
+
+
+def test_model_half_is_the_same_mode_as_convert_weights(golden):
+    """`model.half()` (every floating-point tensor fp16, LayerNorm / embeddings included) selects the same fp16 plan as
+    convert_weights; LayerNorm parameters and embeddings are widened back to fp32 at plan time, so the result may differ
+    from convert_weights' only by their fp16 rounding."""
+    arch = "tiny-ViT"
+    g = golden(gname(arch))
+    seed, B, res = int(g["seed"]), int(g["batch"]), int(g["res"])
+    sd = synth.clip_state_dict(seed, arch)
+    img = synth.images(seed + 100, B, res).cuda()
+    a = convert_weights(build_model(sd).cuda()).encode_image(img)
+    m = build_model(sd).cuda().half()
+    assert m.dtype == torch.float16
+    b = m.encode_image(img)
+    t = m.encode_text(torch.from_numpy(g["tokens"]).cuda())
+    assert b.dtype == torch.float16 and relerr(b.float().cpu(), a.float().cpu()) < 5e-3
+    assert relerr(t.float().cpu(), torch.from_numpy(g["text_embedding"])) < 1e-2
+    # fp16 input images are accepted as they are (the reference casts the image to model.dtype, clip/model.py:341)
+    c = m.encode_image(img.half())
+    assert relerr(c.float().cpu(), b.float().cpu()) < 5e-3
+
+
+def test_fp16_mode_large_batch_rows_are_independent():
+    """ViT-B/32 fp16 at a batch the goldens do not cover: any row of a big batch equals the same image encoded in a
+    small batch (tile schedules differ, so not bit-exact), and repeated runs are bit-identical."""
+    model = convert_weights(build_model(synth.clip_state_dict(2, "ViT-B/32")).cuda())
+    img = synth.images(9, 96, 224).cuda()
+    big = model.encode_image(img)
+    small = model.encode_image(img[40:43].contiguous())
+    assert torch.isfinite(big).all() and relerr(big[40:43].float().cpu(), small.float().cpu()) < 2e-3
+    assert torch.equal(big, model.encode_image(img))
