@@ -1560,7 +1560,23 @@ int gemm_impl(const float* a, int64_t lda, int trans_a, const float* w, int64_t 
     if (!trans_a && !trans_w) set_planes(p, sx, N, ldw);
     p.absmax_out = sx.absmax_out; p.oscale = sx.oscale;
     hipStream_t s = (hipStream_t)stream;
-    if (!trans_a && !trans_w) return launch_modes<0, 0>(p, s, 1, ws, wsb);
+    if (!trans_a && !trans_w) {
+        // wide GEMMs (transformer projections): a 128 x 256 tile halves the per-FLOP cost of fetching and splitting the fp32
+        // activations (the A tile is shared by twice as many output columns); 128 accumulator registers, 2 workgroups per CU.
+        // DBMM_IGEMM_BN256=0 disables.
+        static const int bn256 = [] { const char* e = getenv("DBMM_IGEMM_BN256"); return e ? atoi(e) : 1; }();
+        if (bn256 && p.wh && p.nw == 1 && p.a_absmax && p.a_bytes && (K % 32) == 0 && N >= 768 && (N % 256) == 0 && M >= 8192 &&
+            (ldc & 3) == 0 && (!residual || (ldr & 3) == 0)) {
+            p.tiles_n = (int)(N / 256);
+            p.n_tiles = (int)((M + 127) / 128) * p.tiles_n;
+            hipLaunchKernelGGL((igemm_x3_kernel<128, 256, 2, 2, 0, 2, 0, 2, 1, 32>), dim3(p.n_tiles), dim3(256), 0, s, p);
+            const int c[11] = {128, 256, 2, 2, 0, 0, 32, 2, 2, 0, 1};
+            for (int i = 0; i < 11; ++i) g_last_cfg[i] = c[i];
+            DBMM_CHECK_LAUNCH();
+            return DBMM_OK;
+        }
+        return launch_modes<0, 0>(p, s, 1, ws, wsb);
+    }
     if (!trans_a && trans_w) return launch_modes<0, 1>(p, s, 1, ws, wsb);
     if (trans_a && !trans_w) return launch_modes<2, 0>(p, s, 1, ws, wsb);
     return launch_modes<2, 1>(p, s, 1, ws, wsb);
