@@ -53,34 +53,40 @@ struct GemmHP {
     int M, N, K, act, tiles_n, n_tiles;
 };
 
-constexpr int GBM = 128, GBN = 128;
-constexpr int G_LROW = 64 + 4;                                   // epilogue staging pitch (floats) of a wave's 32 x 64 block
+constexpr int GBM = 128;
 
 // GBK = K depth of a chunk: 64 (128-B LDS rows, 64 KB for two stages, 2 workgroups per CU) or 32 (64-B rows, 32 KB, 3 per CU)
 template <int GBK>
 __device__ __forceinline__ int gswz(int row) { return GBK == 64 ? ((row >> 1) & 7) : ((row >> 2) & 3); }
 
-template <int GBK, int MINB>
+// GBN = tile width: 128 (wave tile 64 x 64) or 256 (64 x 128: three LDS fragment reads per four MFMAs instead of four)
+template <int GBK, int GBN, int MINB>
 __global__ __launch_bounds__(256, MINB) void gemm_f16_kernel(const GemmHP p) {
+    constexpr int WTN = GBN / 2, TN = WTN / 32;                   // wave tile width, 32-column MFMA tiles per wave
+    constexpr int G_LROW = WTN + 4;                               // epilogue staging pitch (floats) of a wave's 32 x WTN block
     constexpr int G_STAGE = (GBM + GBN) * GBK;                    // halves per stage
     constexpr int EPI_HALVES = 4 * 32 * G_LROW * 2;               // the epilogue staging (fp32) aliases the stages
-    constexpr int CPR = GBK / 8, RPP = 256 / CPR, NLD = GBM / RPP;   // 16-B chunks per row, rows per pass, loads per operand
+    constexpr int CPR = GBK / 8, RPP = 256 / CPR, NLD = GBM / RPP, NLW = GBN / RPP;   // 16-B chunks per row, rows per pass, loads per operand
     __shared__ __attribute__((aligned(16))) u16 lds[2 * G_STAGE > EPI_HALVES ? 2 * G_STAGE : EPI_HALVES];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 31, fh = lane >> 5;
     const int tile = xcd_remap(blockIdx.x, p.n_tiles);
     const int m0 = (tile / p.tiles_n) * GBM, n0 = (tile % p.tiles_n) * GBN;
-    const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
+    const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * WTN;
 
     const __amdgpu_buffer_rsrc_t rsA = desc(p.a, p.a_total, (long long)m0 * p.lda * 2);
     const __amdgpu_buffer_rsrc_t rsW = desc(p.w, p.w_total, (long long)n0 * p.ldw * 2);
     // loader: 16-B chunk lc of rows lr + RPP i of both operands
     const int lc = tid % CPR, lr = tid / CPR;
-    unsigned a_off[NLD], w_off[NLD];
+    unsigned a_off[NLD], w_off[NLW];
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
         const int r = lr + RPP * i;
         a_off[i] = m0 + r < p.M ? (unsigned)r * (unsigned)(p.lda * 2) + lc * 16u : OOR;
+    }
+#pragma unroll
+    for (int i = 0; i < NLW; ++i) {
+        const int r = lr + RPP * i;
         w_off[i] = n0 + r < p.N ? (unsigned)r * (unsigned)(p.ldw * 2) + lc * 16u : OOR;
     }
     // zero-extent twins: chunk loads past the end of K go through them (hardware returns zeros, no memory access), so
@@ -89,32 +95,35 @@ __global__ __launch_bounds__(256, MINB) void gemm_f16_kernel(const GemmHP p) {
     const __amdgpu_buffer_rsrc_t rsW0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, 0, 0x00020000);
     // two register sets: the loads of chunk k+2 are issued while chunk k computes and chunk k+1 (landed) is written to
     // LDS -- one chunk of lead (16 MFMAs = 0.25 us) does not cover an L2 / HBM round trip
-    u32x4 a_r0[NLD], w_r0[NLD], a_r1[NLD], w_r1[NLD];
+    u32x4 a_r0[NLD], w_r0[NLW], a_r1[NLD], w_r1[NLW];
     const int nk = p.K / GBK;
-    auto load_chunk = [&](int kc, u32x4 (&a_r)[NLD], u32x4 (&w_r)[NLD]) {
+    auto load_chunk = [&](int kc, u32x4 (&a_r)[NLD], u32x4 (&w_r)[NLW]) {
         const bool valid = kc < nk;
         const __amdgpu_buffer_rsrc_t ra = valid ? rsA : rsA0, rw = valid ? rsW : rsW0;
 #pragma unroll
         for (int i = 0; i < NLD; ++i) a_r[i] = __builtin_amdgcn_raw_buffer_load_b128(ra, a_off[i], (unsigned)(kc * GBK * 2), 0);
 #pragma unroll
-        for (int i = 0; i < NLD; ++i) w_r[i] = __builtin_amdgcn_raw_buffer_load_b128(rw, w_off[i], (unsigned)(kc * GBK * 2), 0);
+        for (int i = 0; i < NLW; ++i) w_r[i] = __builtin_amdgcn_raw_buffer_load_b128(rw, w_off[i], (unsigned)(kc * GBK * 2), 0);
     };
-    auto store_chunk = [&](int stage, const u32x4 (&a_r)[NLD], const u32x4 (&w_r)[NLD]) {
+    auto store_chunk = [&](int stage, const u32x4 (&a_r)[NLD], const u32x4 (&w_r)[NLW]) {
         u16* Ab = lds + stage * G_STAGE;
         u16* Wb = Ab + GBM * GBK;
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
             const int r = lr + RPP * i;
-            const int off = r * GBK + ((lc ^ gswz<GBK>(r)) << 3);
-            *(u32x4*)(Ab + off) = a_r[i];
-            *(u32x4*)(Wb + off) = w_r[i];
+            *(u32x4*)(Ab + r * GBK + ((lc ^ gswz<GBK>(r)) << 3)) = a_r[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NLW; ++i) {
+            const int r = lr + RPP * i;
+            *(u32x4*)(Wb + r * GBK + ((lc ^ gswz<GBK>(r)) << 3)) = w_r[i];
         }
     };
-    f32x16 acc[2][2];
+    f32x16 acc[2][TN];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     auto compute = [&](int st) {
@@ -122,21 +131,21 @@ __global__ __launch_bounds__(256, MINB) void gemm_f16_kernel(const GemmHP p) {
         const u16* Wb = Ab + GBM * GBK;
 #pragma unroll
         for (int ks = 0; ks < GBK / 16; ++ks) {
-            u32x4 af[2], wf[2];
+            u32x4 af[2], wf[TN];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int r = wm0 + 32 * i + fr;
                 af[i] = *(const u32x4*)(Ab + r * GBK + (((2 * ks + fh) ^ gswz<GBK>(r)) << 3));
             }
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
+            for (int j = 0; j < TN; ++j) {
                 const int r = wn0 + 32 * j + fr;
                 wf[j] = *(const u32x4*)(Wb + r * GBK + (((2 * ks + fh) ^ gswz<GBK>(r)) << 3));
             }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[i]), __builtin_bit_cast(f16x8, wf[j]),
                                                                        acc[i][j], 0, 0, 0);
         }
@@ -158,10 +167,11 @@ __global__ __launch_bounds__(256, MINB) void gemm_f16_kernel(const GemmHP p) {
         __syncthreads();
     }
 
-    // epilogue: a wave transposes its 64 x 64 block 32 rows at a time through LDS so that every lane owns 8 consecutive
-    // columns: bias / residual / store are 16 B per lane, whole 128-B row segments per 8 lanes
+    // epilogue: a wave transposes its 64 x WTN block 32 rows at a time through LDS so that every lane owns 8 consecutive
+    // columns: bias / residual / store are 16 B per lane, whole row segments per WTN / 8 lanes
+    constexpr int LPR = WTN / 8, RPI = 64 / LPR, NIT = 32 / RPI;   // lanes per row, rows per wave instruction, instructions per half
     float* Ls = (float*)lds + wave * (32 * G_LROW);
-    const int ec = (lane & 7) * 8, er = lane >> 3;        // 8 lanes per row, 8 rows per wave instruction
+    const int ec = (lane % LPR) * 8, er = lane / LPR;
     const int n = n0 + wn0 + ec;
     f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;
     if (p.bias && n < p.N) { b0 = *(const f32x4*)(p.bias + n); b1 = *(const f32x4*)(p.bias + n + 4); }
@@ -169,27 +179,30 @@ __global__ __launch_bounds__(256, MINB) void gemm_f16_kernel(const GemmHP p) {
     for (int i = 0; i < 2; ++i) {
         __syncthreads();
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) Ls[((r & 3) + 8 * (r >> 2) + 4 * fh) * G_LROW + j * 32 + fr] = acc[i][j][r];
         __syncthreads();
-        u32x4 rv[4];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int m = m0 + wm0 + 32 * i + er + 8 * t;
-            rv[t] = (u32x4){0u, 0u, 0u, 0u};
-            if (p.res && m < p.M && n < p.N) rv[t] = *(const u32x4*)(p.res + (long long)m * p.ldr + n);
-        }
+        for (int t0 = 0; t0 < NIT; t0 += 4) {              // residual loads of four row groups in flight together
+            u32x4 rv[4];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int row = er + 8 * t, m = m0 + wm0 + 32 * i + row;
-            const f32x4 v0 = *(const f32x4*)(Ls + row * G_LROW + ec) + b0, v1 = *(const f32x4*)(Ls + row * G_LROW + ec + 4) + b1;
-            const f16x8 rh = __builtin_bit_cast(f16x8, rv[t]);
-            float o[8];
+            for (int t = 0; t < 4; ++t) {
+                const int m = m0 + wm0 + 32 * i + er + RPI * (t0 + t);
+                rv[t] = (u32x4){0u, 0u, 0u, 0u};
+                if (p.res && m < p.M && n < p.N) rv[t] = *(const u32x4*)(p.res + (long long)m * p.ldr + n);
+            }
 #pragma unroll
-            for (int q = 0; q < 4; ++q) { o[q] = act_f(v0[q], p.act) + (float)rh[q]; o[4 + q] = act_f(v1[q], p.act) + (float)rh[4 + q]; }
-            if (m < p.M && n < p.N)
-                *(u32x4*)(p.c + (long long)m * p.ldc + n) = (u32x4){pack2(o[0], o[1]), pack2(o[2], o[3]), pack2(o[4], o[5]), pack2(o[6], o[7])};
+            for (int t = 0; t < 4; ++t) {
+                const int row = er + RPI * (t0 + t), m = m0 + wm0 + 32 * i + row;
+                const f32x4 v0 = *(const f32x4*)(Ls + row * G_LROW + ec) + b0, v1 = *(const f32x4*)(Ls + row * G_LROW + ec + 4) + b1;
+                const f16x8 rh = __builtin_bit_cast(f16x8, rv[t]);
+                float o[8];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { o[q] = act_f(v0[q], p.act) + (float)rh[q]; o[4 + q] = act_f(v1[q], p.act) + (float)rh[4 + q]; }
+                if (m < p.M && n < p.N)
+                    *(u32x4*)(p.c + (long long)m * p.ldc + n) = (u32x4){pack2(o[0], o[1]), pack2(o[2], o[3]), pack2(o[4], o[5]), pack2(o[6], o[7])};
+            }
         }
     }
 }
@@ -503,11 +516,16 @@ extern "C" int dbmm_gemm_f16(const void* a, int64_t lda, const void* w, int64_t 
     p.lda = lda; p.ldw = ldw; p.ldr = ldr; p.ldc = ldc;
     p.a_total = ((M - 1) * lda + K) * 2; p.w_total = ((N - 1) * ldw + K) * 2;
     p.M = (int)M; p.N = (int)N; p.K = (int)K; p.act = act;
-    p.tiles_n = (int)((N + GBN - 1) / GBN);
+    // developer A/B knobs: DBMM_F16_BK = 32 | 64 (K depth of a chunk), DBMM_F16_BN256 = 0 | 1 (128 x 256 tile for wide GEMMs)
+    static const int bk = [] { const char* e = getenv("DBMM_F16_BK"); return e ? atoi(e) : 64; }();
+    static const int bn256 = [] { const char* e = getenv("DBMM_F16_BN256"); return e ? atoi(e) : 1; }();
+    const bool wide = bn256 && N >= 768 && (N % 256) == 0 && M >= 32768;     // (ViT-B/32 at 25,600 rows measured 3 % slower on it)
+    const int bn = wide ? 256 : 128;
+    p.tiles_n = (int)((N + bn - 1) / bn);
     p.n_tiles = (int)((M + GBM - 1) / GBM) * p.tiles_n;
-    static const int bk = [] { const char* e = getenv("DBMM_F16_BK"); return e ? atoi(e) : 64; }();   // developer A/B knob
-    if (bk == 32) hipLaunchKernelGGL((gemm_f16_kernel<32, 4>), dim3(p.n_tiles), dim3(256), 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL((gemm_f16_kernel<64, 2>), dim3(p.n_tiles), dim3(256), 0, (hipStream_t)stream, p);
+    if (wide) hipLaunchKernelGGL((gemm_f16_kernel<32, 256, 2>), dim3(p.n_tiles), dim3(256), 0, (hipStream_t)stream, p);
+    else if (bk == 32) hipLaunchKernelGGL((gemm_f16_kernel<32, 128, 4>), dim3(p.n_tiles), dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((gemm_f16_kernel<64, 128, 2>), dim3(p.n_tiles), dim3(256), 0, (hipStream_t)stream, p);
     DBMM_CHECK_LAUNCH();
     return DBMM_OK;
 }
