@@ -1618,7 +1618,22 @@ int conv_impl(const float* x, const float* w, const float* bias, const float* re
         return DBMM_E_ARG;
     }
     hipStream_t s = (hipStream_t)stream;
-    if (KH == 1 && KW == 1 && stride == 1 && pad == 0) return launch_modes<0, 0>(p, s, 1, ws, wsb);  // plain GEMM
+    if (KH == 1 && KW == 1 && stride == 1 && pad == 0) {                                           // plain GEMM
+        // developer A/B knob: the 128 x 256 tile (see gemm_impl) for wide 1x1 convs.  Off by default: measured on RN50
+        // layers 3-4 at B = 1024 it is neutral (32.7 k vs 32.7-32.8 k images/s): residual epilogue of a 128-register tile, fewer tiles per round.
+        static const int bn256 = [] { const char* e = getenv("DBMM_IGEMM_BN256_CONV"); return e ? atoi(e) : 0; }();
+        if (bn256 && !p.pool2 && p.wh && p.nw == 1 && p.a_absmax && p.a_bytes && (K % 32) == 0 && Cout >= 1024 && (Cout % 256) == 0 &&
+            M >= 8192) {
+            p.tiles_n = (int)(Cout / 256);
+            p.n_tiles = (int)((M + 127) / 128) * p.tiles_n;
+            hipLaunchKernelGGL((igemm_x3_kernel<128, 256, 2, 2, 0, 2, 0, 2, 1, 32>), dim3(p.n_tiles), dim3(256), 0, s, p);
+            const int c[11] = {128, 256, 2, 2, 0, 0, 32, 2, 2, 0, 1};
+            for (int i = 0; i < 11; ++i) g_last_cfg[i] = c[i];
+            DBMM_CHECK_LAUNCH();
+            return DBMM_OK;
+        }
+        return launch_modes<0, 0>(p, s, 1, ws, wsb);
+    }
     return launch_modes<1, 0>(p, s, 1, ws, wsb);
 }
 
