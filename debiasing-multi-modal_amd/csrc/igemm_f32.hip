@@ -1634,6 +1634,25 @@ int conv_impl(const float* x, const float* w, const float* bias, const float* re
         }
         return launch_modes<0, 0>(p, s, 1, ws, wsb);
     }
+    {
+        // KxK convs that the halo kernel does not take (the pooled 3x3 convs of the stride-2 blocks) with >= 256 output
+        // channels: the 128 x 256 tile halves the per-FLOP cost of the gather + split of the activations, which is what
+        // bounds the per-tap kernel.  DBMM_IGEMM_BN256_KXK=0 disables.
+        static const int bn256 = [] { const char* e = getenv("DBMM_IGEMM_BN256_KXK"); return e ? atoi(e) : 1; }();
+        const char* he = getenv("DBMM_IGEMM_HALO");
+        const bool halo_takes_it = (he ? atoi(he) : 1) && KH == 3 && KW == 3 && stride == 1 && pad == 1 && !p.pool2;
+        const bool pool_ok = !p.pool2 || ((Cout & 3) == 0 && (!residual || true));
+        if (bn256 && !halo_takes_it && p.wh && p.nw == 1 && p.a_absmax && p.a_bytes && p.slab == 32 && (Cin % 32) == 0 && KH * KW <= 32 &&
+            (Cout % 256) == 0 && M >= 8192 && pool_ok) {
+            p.tiles_n = (int)(Cout / 256);
+            p.n_tiles = (int)((M + 127) / 128) * p.tiles_n;
+            hipLaunchKernelGGL((igemm_x3_kernel<128, 256, 2, 2, 1, 2, 0, 2, 1, 32>), dim3(p.n_tiles), dim3(256), 0, s, p);
+            const int c[11] = {128, 256, 2, 2, 1, 0, 32, 2, 2, 0, 1};
+            for (int i = 0; i < 11; ++i) g_last_cfg[i] = c[i];
+            DBMM_CHECK_LAUNCH();
+            return DBMM_OK;
+        }
+    }
     return launch_modes<1, 0>(p, s, 1, ws, wsb);
 }
 
