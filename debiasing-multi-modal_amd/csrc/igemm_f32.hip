@@ -1430,7 +1430,7 @@ inline int forced_bk() {
 // 3x3 / stride 1 / pad 1 convs on the halo kernel (see igemm_tile_halo).  Returns 1 when it launched.
 template <int BN>
 int launch_halo(IgemmP& p, hipStream_t s, void* ws, size_t ws_bytes, int* rc) {
-    constexpr int BM = 128, MB = BN == 32 ? 4 : 3;       // 37 KB / 42 KB / 50 KB of LDS per workgroup
+    constexpr int BM = 128, MB = BN == 32 ? 4 : (BN == 256 ? 2 : 3);   // 37 / 42 / 50 / 67 KB of LDS per workgroup
     const int tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = (p.N + BN - 1) / BN;
     p.n_tiles = tiles_m * p.tiles_n;
@@ -1466,6 +1466,12 @@ int launch_halo(IgemmP& p, hipStream_t s, void* ws, size_t ws_bytes, int* rc) {
     return 1;
 }
 
+// DBMM_IGEMM_HALO256=1: 256-column tiles in the halo kernel for layers with N % 256 == 0 (developer A/B knob)
+inline int halo256() {
+    static const int v = [] { const char* e = getenv("DBMM_IGEMM_HALO256"); return e ? atoi(e) : 0; }();
+    return v;
+}
+
 template <int AMODE, int WMODE>
 int launch_modes(IgemmP& p, hipStream_t s, int nbatch = 1, void* ws = nullptr, size_t wsb = 0) {
     // tile choice: widest N tile that N fills; drop to 64x64 when the 128-wide grid would
@@ -1479,7 +1485,9 @@ int launch_modes(IgemmP& p, hipStream_t s, int nbatch = 1, void* ws = nullptr, s
             (p.N & 3) == 0) {
             int rc = 0;
             if (p.N <= 32 ? launch_halo<32>(p, s, ws, wsb, &rc)
-                          : (p.N <= 64 ? launch_halo<64>(p, s, ws, wsb, &rc) : launch_halo<128>(p, s, ws, wsb, &rc)))
+                          : (p.N <= 64 ? launch_halo<64>(p, s, ws, wsb, &rc)
+                                       : (halo256() && (p.N % 256) == 0 ? launch_halo<256>(p, s, ws, wsb, &rc)
+                                                                        : launch_halo<128>(p, s, ws, wsb, &rc))))
                 return rc;
         }
     }
