@@ -1630,8 +1630,9 @@ int conv_impl(const float* x, const float* w, const float* bias, const float* re
         // developer A/B knob: the 128 x 256 tile (see gemm_impl) for wide 1x1 convs.  Off by default: measured on RN50
         // layers 3-4 at B = 1024 it is neutral (32.7 k vs 32.7-32.8 k images/s): residual epilogue of a 128-register tile, fewer tiles per round.
         static const int bn256 = [] { const char* e = getenv("DBMM_IGEMM_BN256_CONV"); return e ? atoi(e) : 0; }();
-        if (bn256 && !p.pool2 && p.wh && p.nw == 1 && p.a_absmax && p.a_bytes && (K % 32) == 0 && Cout >= 1024 && (Cout % 256) == 0 &&
-            M >= 8192) {
+        // bn256: 1 = every 1x1 conv with Cout % 256 == 0, 2 = only the deep-K ones (K >= 512: conv1 of layers 3-4)
+        if (bn256 && !p.pool2 && p.wh && p.nw == 1 && p.a_absmax && p.a_bytes && (K % 32) == 0 && (Cout % 256) == 0 &&
+            (bn256 == 1 || K >= 512) && M >= 8192) {
             p.tiles_n = (int)(Cout / 256);
             p.n_tiles = (int)((M + 127) / 128) * p.tiles_n;
             hipLaunchKernelGGL((igemm_x3_kernel<128, 256, 2, 2, 0, 2, 0, 2, 1, 32>), dim3(p.n_tiles), dim3(256), 0, s, p);
