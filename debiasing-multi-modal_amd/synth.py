@@ -167,6 +167,7 @@ def clip_state_dict(seed, arch="RN50", **over):
     cfgs = {
         "RN50": dict(kind="rn", layers=(3, 4, 6, 3), width=64, embed=1024, res=224, twidth=512, tlayers=12),
         "RN101": dict(kind="rn", layers=(3, 4, 23, 3), width=64, embed=512, res=224, twidth=512, tlayers=12),
+        "RN50x4": dict(kind="rn", layers=(4, 6, 10, 6), width=80, embed=640, res=288, twidth=640, tlayers=12),
         "ViT-B/32": dict(kind="vit", patch=32, width=768, layers=12, embed=512, res=224, twidth=512, tlayers=12),
         "ViT-L/14@336px": dict(kind="vit", patch=14, width=1024, layers=24, embed=768, res=336, twidth=768, tlayers=12),
         # tiny configs used by the full-tensor parity fixtures

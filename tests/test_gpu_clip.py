@@ -81,6 +81,21 @@ def test_encode_image_vs_oracle_other_inputs(arch, B, models):
     assert ((f.cpu() @ Wn) / 0.01 - (fr @ Wn) / 0.01).abs().max() < 1e-3
 
 
+@pytest.mark.parametrize("arch,B", [("RN101", 2), ("RN50x4", 1)])
+def test_other_rn_architectures_of_the_reference_cli(arch, B, models):
+    """clip_inference.py:280 also offers RN101 and RN50x4: a 23-block stage, and widths (80, 320, ...) that are not multiples
+    of 32, which take the general kernels instead of the fp16-pair / halo / chain ones -- against the oracle on the CPU."""
+    seed = 5
+    sd = synth.clip_state_dict(seed, arch)
+    model = models(arch, seed)
+    res = model.visual.input_resolution
+    img = synth.images(31, B, res)
+    with torch.no_grad():
+        ref = CO.encode_image(sd, img)
+    out = model.encode_image(img.cuda())
+    assert tuple(out.shape) == tuple(ref.shape) and relerr(out.cpu(), ref) < 5e-5
+
+
 def test_clip_forward_and_surface(models):
     model = models("tiny-RN", 3)
     assert model.dtype == torch.float32 and model.visual.input_resolution == 64
