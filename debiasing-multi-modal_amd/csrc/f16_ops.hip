@@ -216,35 +216,42 @@ __global__ __launch_bounds__(256, MINB) void gemm_f16_kernel(const GemmHP p) {
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int A_OROW = 72;                                       // O staging pitch in halves (144 B rows: conflict-free b64 writes)
 
+// QT = 32-query tiles per wave: 1 (a workgroup covers 128 queries; the default) or 2 (256: every K / V fragment read from LDS
+// and every staged K / V tile serves twice as many MFMAs -- kept behind DBMM_MHA_F16_QT2, it measured slower)
+template <int QT>
 __global__ __launch_bounds__(256, 2) void mha_f16_kernel(const u16* __restrict__ qkv, u16* __restrict__ out, int L, int E,
                                                          int heads, int causal, float scale_log2e) {
     __shared__ __attribute__((aligned(16))) u16 Ks[64 * 64];
     __shared__ __attribute__((aligned(16))) u16 Vt[64 * 64];
     __shared__ __attribute__((aligned(16))) u16 Os[4 * 32 * A_OROW];
+    constexpr int QB = 128 * QT;                                 // queries per workgroup
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 31, fh = lane >> 5;
     const int qb = blockIdx.x, head = blockIdx.y, b = blockIdx.z;
     const long long row0 = (long long)b * L;
     const long long ld = 3LL * E;
-    const int q_idx = qb * 128 + wave * 32 + fr;                 // this lane's query
-    const int q_ld = q_idx < L ? q_idx : L - 1;
-
+    int q_idx[QT];                                               // this lane's queries
     // Q fragments (B operand of S^T): lane (query, k half fh) holds d = 16 s + 8 fh .. + 7
-    u32x4 qf[4];
+    u32x4 qf[QT][4];
+    f32x16 o_acc[QT][2];
+    float m_run[QT], l_run[QT];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) qf[s] = *(const u32x4*)(qkv + (row0 + q_ld) * ld + head * 64 + 16 * s + 8 * fh);
-
-    f32x16 o_acc[2];
+    for (int qt = 0; qt < QT; ++qt) {
+        q_idx[qt] = qb * QB + (wave * QT + qt) * 32 + fr;
+        const int q_ld = q_idx[qt] < L ? q_idx[qt] : L - 1;
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+        for (int s = 0; s < 4; ++s) qf[qt][s] = *(const u32x4*)(qkv + (row0 + q_ld) * ld + head * 64 + 16 * s + 8 * fh);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) o_acc[j][r] = 0.f;
-    float m_run = -INFINITY, l_run = 0.f;
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o_acc[qt][j][r] = 0.f;
+        m_run[qt] = -INFINITY; l_run[qt] = 0.f;
+    }
 
     // staging: thread loads 16 B (8 d) of key rows tid >> 3 and (tid >> 3) + 32 for K and V
     const int lc = tid & 7, lk = tid >> 3;
     u32x4 k_r[2], v_r[2];
-    const int q_hi = qb * 128 + 127 < L - 1 ? qb * 128 + 127 : L - 1;
+    const int q_hi = qb * QB + QB - 1 < L - 1 ? qb * QB + QB - 1 : L - 1;
     const int n_keys = causal ? q_hi + 1 : L;                   // causal: keys past the block's last query never count
     const int T = (n_keys + 63) / 64;
     auto load_tile = [&](int t) {
@@ -277,55 +284,63 @@ __global__ __launch_bounds__(256, 2) void mha_f16_kernel(const u16* __restrict__
     __syncthreads();
     for (int t = 0; t < T; ++t) {
         if (t + 1 < T) load_tile(t + 1);
-        // ---- S^T[key][query] for the tile's two 32-key halves ------------------------------------------------------
-        f32x16 s_acc[2];
+        // ---- S^T[key][query] for the tile's two 32-key halves: one K fragment read serves every query tile ---------------
+        f32x16 s_acc[QT][2];
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt) {
+        for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s_acc[kt][r] = 0.f;
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s_acc[qt][kt][r] = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 const int row = kt * 32 + fr;
                 const u32x4 kf = *(const u32x4*)(Ks + row * 64 + (((2 * s + fh) ^ swz64(row)) << 3));
-                s_acc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, kf), __builtin_bit_cast(f16x8, qf[s]),
-                                                                   s_acc[kt], 0, 0, 0);
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt)
+                    s_acc[qt][kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, kf), __builtin_bit_cast(f16x8, qf[qt][s]),
+                                                                           s_acc[qt][kt], 0, 0, 0);
             }
-        }
-        // ---- online softmax: this lane holds keys (r&3) + 8 (r>>2) + 4 fh of each half for ITS query ----------------
-        float mx = -INFINITY;
+        // ---- online softmax: a lane holds keys (r&3) + 8 (r>>2) + 4 fh of each half for ITS query of every tile ----------
+        u32x4 pf[QT][2][2];
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
+        for (int qt = 0; qt < QT; ++qt) {
+            float mx = -INFINITY;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = t * 64 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-                float v = s_acc[kt][r] * scale_log2e;
-                if (key >= L || (causal && key > q_idx)) v = -INFINITY;
-                s_acc[kt][r] = v;
-                mx = fmaxf(mx, v);
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = t * 64 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                    float v = s_acc[qt][kt][r] * scale_log2e;
+                    if (key >= L || (causal && key > q_idx[qt])) v = -INFINITY;
+                    s_acc[qt][kt][r] = v;
+                    mx = fmaxf(mx, v);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run[qt], mx);
+            const float m_use = m_new == -INFINITY ? 0.f : m_new;   // a fully masked row so far: exp2(-inf - 0) = 0
+            const float alpha = exp2f(m_run[qt] - m_use);
+            float psum = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) {
+                float pv[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { pv[r] = exp2f(s_acc[qt][kt][r] - m_use); psum += pv[r]; }
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+                    pf[qt][kt][u] = (u32x4){pack2(pv[8 * u], pv[8 * u + 1]), pack2(pv[8 * u + 2], pv[8 * u + 3]),
+                                            pack2(pv[8 * u + 4], pv[8 * u + 5]), pack2(pv[8 * u + 6], pv[8 * u + 7])};
             }
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx);
-        const float m_use = m_new == -INFINITY ? 0.f : m_new;   // a fully masked row so far: exp2(-inf - 0) = 0
-        const float alpha = exp2f(m_run - m_use);
-        float psum = 0.f;
-        u32x4 pf[2][2];
+            l_run[qt] = l_run[qt] * alpha + psum;
+            m_run[qt] = m_new;
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt) {
-            float pv[16];
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { pv[r] = exp2f(s_acc[kt][r] - m_use); psum += pv[r]; }
-#pragma unroll
-            for (int u = 0; u < 2; ++u)
-                pf[kt][u] = (u32x4){pack2(pv[8 * u], pv[8 * u + 1]), pack2(pv[8 * u + 2], pv[8 * u + 3]),
-                                    pack2(pv[8 * u + 4], pv[8 * u + 5]), pack2(pv[8 * u + 6], pv[8 * u + 7])};
+                for (int r = 0; r < 16; ++r) o_acc[qt][j][r] *= alpha;
         }
-        l_run = l_run * alpha + psum;
-        m_run = m_new;
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o_acc[j][r] *= alpha;
-        // ---- O^T[d][query] += V^T[d][keys] P^T[keys][query] -----------------------------------------------------------
+        // ---- O^T[d][query] += V^T[d][keys] P^T[keys][query]: one V^T fragment read serves every query tile ----------------
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -334,30 +349,35 @@ __global__ __launch_bounds__(256, 2) void mha_f16_kernel(const u16* __restrict__
                 for (int j = 0; j < 2; ++j) {
                     const int d = j * 32 + fr, chunk = 2 * (2 * kt + u) + fh;
                     const u32x4 vf = *(const u32x4*)(Vt + d * 64 + ((chunk ^ swz64(d)) << 3));
-                    o_acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, vf), __builtin_bit_cast(f16x8, pf[kt][u]),
-                                                                      o_acc[j], 0, 0, 0);
+#pragma unroll
+                    for (int qt = 0; qt < QT; ++qt)
+                        o_acc[qt][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, vf), __builtin_bit_cast(f16x8, pf[qt][kt][u]),
+                                                                              o_acc[qt][j], 0, 0, 0);
                 }
         __syncthreads();
         if (t + 1 < T) store_tile();
         __syncthreads();
     }
-    // ---- normalise; O^T -> rows through LDS; 16-B stores ----------------------------------------------------------
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-    const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
+    // ---- normalise; O^T -> rows through LDS (wave-private staging, one query tile at a time); 16-B stores ----------------
     u16* Ow = Os + wave * (32 * A_OROW);
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int qt = 0; qt < QT; ++qt) {
+        const float l_tot = l_run[qt] + __shfl_xor(l_run[qt], 32, 64);
+        const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int d = j * 32 + 8 * g + 4 * fh;
-            *(u32x2*)(Ow + fr * A_OROW + d) = (u32x2){pack2(o_acc[j][4 * g] * inv, o_acc[j][4 * g + 1] * inv),
-                                                       pack2(o_acc[j][4 * g + 2] * inv, o_acc[j][4 * g + 3] * inv)};
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int d = j * 32 + 8 * g + 4 * fh;
+                *(u32x2*)(Ow + fr * A_OROW + d) = (u32x2){pack2(o_acc[qt][j][4 * g] * inv, o_acc[qt][j][4 * g + 1] * inv),
+                                                           pack2(o_acc[qt][j][4 * g + 2] * inv, o_acc[qt][j][4 * g + 3] * inv)};
+            }
+        // (the wave's own LDS writes are ordered before its reads, and these reads before the next tile's writes)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = (lane >> 3) + 8 * i, q = qb * QB + (wave * QT + qt) * 32 + row;
+            if (q < L) *(u32x4*)(out + (row0 + q) * (long long)E + head * 64 + (lane & 7) * 8) = *(const u32x4*)(Ow + row * A_OROW + (lane & 7) * 8);
         }
-    // (wave-private staging: the wave's own LDS writes are ordered before its reads)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = (lane >> 3) + 8 * i, q = qb * 128 + wave * 32 + row;
-        if (q < L) *(u32x4*)(out + (row0 + q) * (long long)E + head * 64 + (lane & 7) * 8) = *(const u32x4*)(Ow + row * A_OROW + (lane & 7) * 8);
     }
 }
 
@@ -536,9 +556,18 @@ extern "C" int dbmm_mha_core_f16(const void* qkv, void* out, int64_t B, int64_t 
     if (B <= 0 || L <= 0 || E <= 0 || heads <= 0 || B > 65535 || heads > 65535) return DBMM_E_SHAPE;
     if (E != heads * 64) return DBMM_E_UNSUPPORTED;              // head_dim 64 (every CLIP tower)
     if (!dbmm_aligned16(qkv) || !dbmm_aligned16(out)) return DBMM_E_ALIGN;
-    const dim3 grid((unsigned)((L + 127) / 128), (unsigned)heads, (unsigned)B);
-    hipLaunchKernelGGL(mha_f16_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const u16*)qkv, (u16*)out, (int)L, (int)E,
-                       (int)heads, causal ? 1 : 0, 0.125f * 1.4426950408889634f);
+    // developer A/B knob, off: 64 queries per wave measured 8 % SLOWER on ViT-L/14@336 (106 -> 115 ms per step of attention):
+    // 256 registers hold occupancy at 2 workgroups per CU where the 32-query form (161 registers) runs 3
+    static const int qt2 = [] { const char* e = getenv("DBMM_MHA_F16_QT2"); return e ? atoi(e) : 0; }();
+    if (qt2 && L > 128) {
+        const dim3 grid((unsigned)((L + 255) / 256), (unsigned)heads, (unsigned)B);
+        hipLaunchKernelGGL(mha_f16_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, (const u16*)qkv, (u16*)out, (int)L, (int)E,
+                           (int)heads, causal ? 1 : 0, 0.125f * 1.4426950408889634f);
+    } else {
+        const dim3 grid((unsigned)((L + 127) / 128), (unsigned)heads, (unsigned)B);
+        hipLaunchKernelGGL(mha_f16_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, (const u16*)qkv, (u16*)out, (int)L, (int)E,
+                           (int)heads, causal ? 1 : 0, 0.125f * 1.4426950408889634f);
+    }
     DBMM_CHECK_LAUNCH();
     return DBMM_OK;
 }
