@@ -2,12 +2,14 @@
 """Developer tool: device preprocessing throughput vs the host (Pillow) path."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
 import numpy as np
 import torch
 import dbmm_amd
+from PIL import Image
 from dbmm_amd import preprocess as PP
-import preprocess_oracle as PO
+from dbmm_amd.clip.clip import _transform          # the host (Pillow) preprocess of clip.load, clip/clip.py:79-86
+
+host_pp = _transform(224)
 
 for name, (H, W), B in [("CelebA 218x178", (218, 178), 512), ("Waterbirds-like 375x500", (375, 500), 512),
                         ("12 MP 3000x4000", (3000, 4000), 16)]:
@@ -22,7 +24,7 @@ for name, (H, W), B in [("CelebA 218x178", (218, 178), 512), ("Waterbirds-like 3
     t_dev = (time.perf_counter() - t0) / 3
     t0 = time.perf_counter()
     for im in host:
-        PO.transform(im, 224)
+        host_pp(Image.fromarray(im, "RGB"))
     t_host = (time.perf_counter() - t0) / len(host)
     print(f"{name}: device {B / t_dev:9.0f} img/s ({t_dev / B * 1e6:7.1f} us/img incl. launch)   "
           f"host Pillow 1 core {1 / t_host:7.0f} img/s ({t_host * 1e3:6.2f} ms/img)")
