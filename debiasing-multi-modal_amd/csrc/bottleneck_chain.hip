@@ -223,15 +223,17 @@ __global__ __launch_bounds__(256, 2) void bottleneck_chain_kernel(const ChainP p
     u32x4 af[KS][2], af2[DUAL ? 4 : 1][2];
     bool first_pass = true;
     // one 64-wide k pass of an A operand (row pitch `ldk` floats, k offset `k0`) -> 4 fragment steps
-    auto stage_pass = [&](const __amdgpu_buffer_rsrc_t& rs, int ldk, int k0, float sc, u32x4 (*dst)[2]) {
+    auto stage_issue = [&](const __amdgpu_buffer_rsrc_t& rs, int ldk, int k0, f32x4 (&q)[8]) {
         const int lc = tid & 15, lr = tid >> 4;
-        f32x4 q[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int row = lr + 16 * i, m = m0 + row;
             const unsigned off = m < p.M ? (unsigned)(row_pixel<POOL>(p, m) - g0) * (unsigned)(ldk * 4) + lc * 16u : OOR;
             q[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, (unsigned)(k0 * 4), 0));
         }
+    };
+    auto stage_finish = [&](const f32x4 (&q)[8], float sc, u32x4 (*dst)[2]) {
+        const int lc = tid & 15, lr = tid >> 4;
         if (!first_pass) __syncthreads();                 // the previous pass's fragments have been read
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -254,6 +256,15 @@ __global__ __launch_bounds__(256, 2) void bottleneck_chain_kernel(const ChainP p
             dst[ks][1] = *(const u32x4*)(Ay + BM * 64 + off);
         }
     };
+    auto stage_pass = [&](const __amdgpu_buffer_rsrc_t& rs, int ldk, int k0, float sc, u32x4 (*dst)[2]) {
+        f32x4 q[8];
+        stage_issue(rs, ldk, k0, q);
+        stage_finish(q, sc, dst);
+    };
+    // DUAL + CONV2: the branch input's loads are issued BEFORE the conv2 phase and consumed after it (their round trip
+    // would otherwise sit exposed between the two phases of every tile)
+    f32x4 q2[(DUAL && CONV2) ? 8 : 1];
+    if constexpr (DUAL && CONV2) stage_issue(rsR, 64, 0, q2);
     int s_a;                                            // exponent of the scale the A fragments carry
     if constexpr (!CONV2) {
         s_a = scale_exp(*p.a_absmax);
@@ -401,7 +412,8 @@ __global__ __launch_bounds__(256, 2) void bottleneck_chain_kernel(const ChainP p
     float dual_dyn = 1.f;
     if constexpr (DUAL) {
         const int s_a2 = scale_exp(*p.a2_absmax);
-        stage_pass(rsR, 64, 0, pow2f(s_a2), af2);
+        if constexpr (CONV2) stage_finish(q2, pow2f(s_a2), af2);
+        else stage_pass(rsR, 64, 0, pow2f(s_a2), af2);
         dual_dyn = pow2f(s_a - s_a2);
     }
     __syncthreads();                                    // the y2 planes are dead: the region becomes the slab
