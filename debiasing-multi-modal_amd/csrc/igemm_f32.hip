@@ -570,6 +570,31 @@ __device__ __forceinline__ void split2h_pair(float x0, float x1, float sc, unsig
 #endif
 }
 
+// instruction-order fences of the split kernels' K loop (see kloop): X3_SCHED 0 = none (compiler's order),
+// 1 = loads first, all MFMAs, then the split; 2 = loads first, the split interleaves with the second half of the MFMAs
+#ifndef X3_SCHED
+#define X3_SCHED 2
+#endif
+#if X3_SCHED == 0
+#define X3_FENCE_TOP()
+#define X3_FENCE_MID()
+#define X3_SPLIT_KS (BK / 16)
+#elif X3_SCHED == 1
+#define X3_FENCE_TOP() __builtin_amdgcn_sched_barrier(0)
+#define X3_FENCE_MID() __builtin_amdgcn_sched_barrier(0)
+#define X3_SPLIT_KS (BK / 16)
+#else
+#define X3_FENCE_TOP() __builtin_amdgcn_sched_barrier(0)
+#define X3_FENCE_MID() __builtin_amdgcn_sched_barrier(0)
+#define X3_SPLIT_KS (BK / 32)
+#endif
+
+// timing ablations for developer builds (-DX3_ABL=bits; results are wrong by construction): 1 no MFMAs,
+// 2 activation loads return zeros without touching memory, 4 same for the weight loads, 8 no split / LDS store of A
+#ifndef X3_ABL
+#define X3_ABL 0
+#endif
+
 template <int BM, int BN, int NP, int NW, int BK>
 struct GeoX3 {   // LDS floats for the split path (NP / NW 16-bit planes of A / W, two stages) vs the epilogue staging
     static constexpr int STAGE_U16 = (NP * BM + NW * BN) * BK;
@@ -708,7 +733,7 @@ __device__ __forceinline__ void igemm_tile_x3(const IgemmP& p, float* lds, int t
     f32x4 a_r0[ALD], a_r1[ALD];
     u32x4 w_r0[NW * WLD], w_r1[NW * WLD];
     auto load_chunk = [&](int k0, f32x4 (&a_reg)[ALD], u32x4 (&w_reg)[NW * WLD], bool valid) {
-        const __amdgpu_buffer_rsrc_t ra = valid ? rsA : rsA0, rw = valid ? rsW : rsW0;   // scalar selects
+        const __amdgpu_buffer_rsrc_t ra = (valid && !(X3_ABL & 2)) ? rsA : rsA0, rw = (valid && !(X3_ABL & 4)) ? rsW : rsW0;   // scalar selects
         if constexpr (AMODE == 0) {
 #pragma unroll
             for (int i = 0; i < ALD; ++i) a_reg[i] = buf_load16(ra, fa_off[i], (unsigned)k0 * 4u);
@@ -750,6 +775,8 @@ __device__ __forceinline__ void igemm_tile_x3(const IgemmP& p, float* lds, int t
                 *(u32x2*)(Ab + 0 * BM * BK + off) = (u32x2){(unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16)};
                 *(u32x2*)(Ab + 1 * BM * BK + off) = (u32x2){(unsigned)m[0] | ((unsigned)m[1] << 16), (unsigned)m[2] | ((unsigned)m[3] << 16)};
                 *(u32x2*)(Ab + 2 * BM * BK + off) = (u32x2){(unsigned)l[0] | ((unsigned)l[1] << 16), (unsigned)l[2] | ((unsigned)l[3] << 16)};
+            } else if constexpr (X3_ABL & 8) {
+                asm volatile("" ::"v"(a_reg[i]));
             } else {
                 // two packed fp16 results per pair of elements, one mixed-precision FMA each:
                 // hi = f16(x * sc), lo = f16(x * sc - hi) (the fp32 difference is exact), written
@@ -783,11 +810,11 @@ __device__ __forceinline__ void igemm_tile_x3(const IgemmP& p, float* lds, int t
 
     const int fr = lane & 31, fh = lane >> 5;
 
-    auto compute = [&](int stage) {
+    auto compute = [&](int stage, int ks_lo = 0, int ks_hi = BK / 16) {
         const u16* Ab = Ap + stage * STAGE;
         const u16* Wb = Ab + NP * BM * BK;
 #pragma unroll
-        for (int ks = 0; ks < BK / 16; ++ks) {
+        for (int ks = ks_lo; ks < ks_hi; ++ks) {
             // this lane's 8 k values of sub-step ks: chunk 2*ks + fh, swizzled (tile row offsets are
             // multiples of 32, so the swizzle depends on fr only)
             const int fch = ((2 * ks + fh) ^ x3_swz<BK>(fr)) << 3;
@@ -814,7 +841,9 @@ __device__ __forceinline__ void igemm_tile_x3(const IgemmP& p, float* lds, int t
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j) {
-                        if constexpr (NP == 3)
+                        if constexpr (X3_ABL & 1) {
+                            asm volatile("" ::"v"(af[i][pa]), "v"(wf[j][pb]));
+                        } else if constexpr (NP == 3)
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[i][pa]),
                                                                                 __builtin_bit_cast(bf16x8, wf[j][pb]), acc[i][j], 0, 0, 0);
                         else
@@ -836,12 +865,23 @@ __device__ __forceinline__ void igemm_tile_x3(const IgemmP& p, float* lds, int t
         for (int kc = kb; kc < ke; kc += 2) {
             // (no branches inside: a chunk past the end arrives as zeros through the zero-extent
             //  descriptors and adds nothing; an odd chunk count costs one phantom chunk)
+            // The scheduling fences keep the order written here.  Left alone the compiler sinks the
+            // loads below half of the MFMAs (their destination registers double as fragment
+            // registers) and hoists the split of the OTHER set to the top of the next half step:
+            // issue -> use shrinks from two half steps to a quarter of one and every wave sits in
+            // s_waitcnt vmcnt for an HBM round trip per chunk.
             load_chunk((kc + 2) * BK, a_r0, w_r0, kc + 2 < ke);
-            compute(0);
+            X3_FENCE_TOP();
+            compute(0, 0, X3_SPLIT_KS);
+            X3_FENCE_MID();
+            compute(0, X3_SPLIT_KS, BK / 16);
             store_chunk(1, a_r1, w_r1);
             __syncthreads();
             load_chunk((kc + 3) * BK, a_r1, w_r1, kc + 3 < ke);
-            compute(1);
+            X3_FENCE_TOP();
+            compute(1, 0, X3_SPLIT_KS);
+            X3_FENCE_MID();
+            compute(1, X3_SPLIT_KS, BK / 16);
             store_chunk(0, a_r0, w_r0);
             __syncthreads();
         }
@@ -924,26 +964,36 @@ __global__ __launch_bounds__(256, MINB) void igemm_x3_kernel(const IgemmP p) {
 // A work unit is 6 K steps (two (slab, kh) groups): two A stages alternate per group, two W stages
 // per step, all indices static, no branches in the loop.  Needs Cin % 64 == 0.
 // ---------------------------------------------------------------------------------------------
-template <int BN>
+template <int BN, int POOL = 0>
 struct GeoHalo {
-    static constexpr int AR = 136;                        // LDS rows per A plane (8704 B = 34 x 256): 130 used + a 256-B zero line in rows 132..135
+    // LDS rows per A plane.  Standard row order: 136 (8704 B = 34 x 256): 130 used + a 256-B zero line in rows 132..135.
+    // POOL (2x2-window-major rows, see igemm_tile_halo): two strips of 66 pixels at rows 0 and 72, zero line in rows 140..143.
+    static constexpr int AR = POOL ? 144 : 136;
+    static constexpr int ZROW = POOL ? 140 : 132;         // first row of the zero line
+    static constexpr int STRIP = 72;                      // POOL: LDS row of the dy = 1 strip (72 keeps the fragment reads conflict-free)
     static constexpr int A_STAGE = 2 * AR * 32;           // u16: [2 planes][AR][32]
     static constexpr int W_STAGE = BN * 32;               // u16: [BN][32]
     static constexpr int TILE_FLOATS = (2 * A_STAGE + 2 * W_STAGE) / 2;
 };
 
-template <int BN, int WAVES_M, int WAVES_N>
+// POOL = 1: the conv feeds a fused 2x2 average pool, tile rows run window-major (row m = 4 * pooled pixel + dy * 2 + dx,
+// like the pool2 mode of igemm_tile_x3).  The 128 rows are 32 windows = two image rows x 64 columns per (slab, kh)
+// group, held as two strips of 66 pixels (left halo, 32 x (dx 0, dx 1), right halo): fragment row (w, dy, dx) of tap kw
+// reads LDS row dy * 72 + 2 w + dx + kw.  Windows that wrap to the next pooled row / image load from wherever they
+// live; a strip neighbour that is not the image neighbour is exactly a border tap and masked like every border tap.
+template <int BN, int WAVES_M, int WAVES_N, int POOL = 0>
 __device__ __forceinline__ void igemm_tile_halo(const IgemmP& p, float* lds, int tile, int ub, int ue, float* partial) {
     constexpr int BM = 128, BK = 32;
     using G = Geo<BM, BN, WAVES_M, WAVES_N, BK>;
-    using H = GeoHalo<BN>;
+    using H = GeoHalo<BN, POOL>;
     constexpr int TM = G::TM, TN = G::TN, WTN = G::WTN, LROW = G::LROW;
     // Masked taps read zeros from the 256-B line at rows 132..135, at the SAME offset modulo 256 B as the address they
     // replace: a redirected lane then sits on the bank quad it would have used anyway, so the redirect adds no bank
     // conflict (one shared zero row did: PMC showed 18 % conflict cycles on the 14x14 / 7x7 maps, where most 16-lane
     // groups hold a border pixel)
-    constexpr int AR = H::AR, ZB = 132 * 32;
-    constexpr int ALD = 5;                                // 130 rows x 8 k-quads / 256 threads, passes of 32 rows
+    constexpr int AR = H::AR, ZB = H::ZROW * 32;
+    constexpr int ALD = 5;                                // 130 (POOL: 132) rows x 8 k-quads / 256 threads, passes of 32 rows
+    constexpr int NLD = POOL ? 132 : 130;                 // rows the loader fills
     constexpr int RPW = 64, WLD = (BN + RPW - 1) / RPW;   // W: 4 chunks per row, 64 rows per pass
     u16* As = (u16*)lds;                                  // [2 stages][2 planes][AR][32]
     u16* Ws = As + 2 * H::A_STAGE;                        // [2 stages][BN][32]
@@ -956,7 +1006,8 @@ __device__ __forceinline__ void igemm_tile_halo(const IgemmP& p, float* lds, int
 
     // A descriptor rebased to the first pixel the tile can touch, m0 - 1 - W (see a_desc); for the tiles at the very
     // start of the tensor the base stays 0 and "negative" pixels wrap past the extent = zeros, as before
-    const int px0 = m0 - 1 - p.W > 0 ? m0 - 1 - p.W : 0;
+    const int pxf = POOL ? pool2_base_pixel(p, m0 >> 2) : m0;     // first output pixel of the tile
+    const int px0 = pxf - 1 - p.W > 0 ? pxf - 1 - p.W : 0;
     const long long a_shift = (long long)px0 * p.Cin * 4;
     __amdgpu_buffer_rsrc_t rsA = a_desc(p.a, p.a_total, a_shift);
     __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.wh, 0, (int)p.wh_bytes, 0x00020000);
@@ -970,7 +1021,17 @@ __device__ __forceinline__ void igemm_tile_halo(const IgemmP& p, float* lds, int
 #pragma unroll
     for (int i = 0; i < ALD; ++i) {
         const int j = lr + 32 * i;
-        fa_off[i] = j < 130 ? (unsigned)((m0 - 1 + j - px0) * p.Cin) * 4u + lc * 16u : OOR;
+        if constexpr (POOL) {
+            // loader row j = strip dy = j / 66, strip column c = j % 66: c = 0 / 65 are the halo pixels left of the first
+            // and right of the last window, c = 1 + 2 w + dx the window pixels
+            const int dy = j >= 66, c = j - 66 * dy;
+            const int wl = c == 0 ? 0 : (c == 65 ? 31 : (c - 1) >> 1), dxo = c == 0 ? -1 : (c == 65 ? 2 : (c - 1) & 1);
+            const int mp = (m0 >> 2) + wl;
+            fa_off[i] = (j < NLD && 4 * mp < p.M)
+                            ? (unsigned)((pool2_base_pixel(p, mp) + dy * p.W + dxo - px0) * p.Cin) * 4u + lc * 16u : OOR;
+        } else {
+            fa_off[i] = j < NLD ? (unsigned)((m0 - 1 + j - px0) * p.Cin) * 4u + lc * 16u : OOR;
+        }
     }
     unsigned fw_off[WLD];
 #pragma unroll
@@ -986,7 +1047,15 @@ __device__ __forceinline__ void igemm_tile_halo(const IgemmP& p, float* lds, int
         const int r = wm0 + i * 32 + fr, m = m0 + r;
         unsigned msk = 0;
         if (m < p.M) {
-            const int hw = p.Ho * p.Wo, n = m / hw, rem = m - n * hw, ho = rem / p.Wo, wo = rem - ho * p.Wo;
+            int ho, wo;
+            if constexpr (POOL) {
+                const int q = m & 3, mp = m >> 2, wp2 = p.Wo >> 1, hwp = (p.Ho >> 1) * wp2;
+                const int rem = mp % hwp, hp = rem / wp2;
+                ho = 2 * hp + (q >> 1); wo = 2 * (rem - hp * wp2) + (q & 1);
+            } else {
+                const int hw = p.Ho * p.Wo, n = m / hw, rem = m - n * hw;
+                ho = rem / p.Wo; wo = rem - ho * p.Wo;
+            }
 #pragma unroll
             for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
@@ -995,11 +1064,12 @@ __device__ __forceinline__ void igemm_tile_halo(const IgemmP& p, float* lds, int
                         msk |= 1u << (kh * 3 + kw);
         }
         fmask[i] = msk;
+        const int lrow = POOL ? ((r >> 1) & 1) * H::STRIP + (r >> 2) * 2 + (r & 1) : r;   // LDS row of the kw = 0 tap
 #pragma unroll
         for (int kw = 0; kw < 3; ++kw)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
-                faddr[i][kw][ks] = (r + kw) * 32 + (((2 * ks + fh) ^ x3_swz<32>(r + kw)) << 3);
+                faddr[i][kw][ks] = (lrow + kw) * 32 + (((2 * ks + fh) ^ x3_swz<32>(lrow + kw)) << 3);
     }
     int wfaddr[TN][2];
 #pragma unroll
@@ -1024,8 +1094,9 @@ __device__ __forceinline__ void igemm_tile_halo(const IgemmP& p, float* lds, int
         u16* Ab = As + stage * H::A_STAGE;
 #pragma unroll
         for (int i = 0; i < ALD; ++i) {
-            const int row = lr + 32 * i;
-            if (row < 130) {
+            const int j = lr + 32 * i;
+            const int row = (POOL && j >= 66) ? j + (H::STRIP - 66) : j;
+            if (j < NLD) {
                 unsigned hp[2], lp[2];
 #pragma unroll
                 for (int j = 0; j < 2; ++j) split2h_pair(a_r[i][2 * j], a_r[i][2 * j + 1], a_sc, hp[j], lp[j]);
@@ -1093,9 +1164,9 @@ __device__ __forceinline__ void igemm_tile_halo(const IgemmP& p, float* lds, int
     const int nk_all = p.K / 32;
     const int t_end = ue * 6 < nk_all ? ue * 6 : nk_all, g_end = ue * 2 < nk_all / 3 ? ue * 2 : nk_all / 3;
     __syncthreads();                                      // a previous tile of this workgroup may still use the LDS
-    // the 256-B zero line (rows 132..135) of both planes of both A stages (never written by the loader)
+    // the 256-B zero line (rows ZROW .. ZROW + 3) of both planes of both A stages (never written by the loader)
     if (tid < 2 * 2 * 4 * 4) {                            // 2 stages x 2 planes x 4 rows x 4 chunks of 16 B
-        const int ch = tid & 3, row = 132 + ((tid >> 2) & 3), pl = (tid >> 4) & 1, st = tid >> 5;
+        const int ch = tid & 3, row = H::ZROW + ((tid >> 2) & 3), pl = (tid >> 4) & 1, st = tid >> 5;
         *(u32x4*)(As + st * H::A_STAGE + pl * AR * 32 + row * 32 + ch * 8) = (u32x4){0u, 0u, 0u, 0u};
     }
     load_a(2 * ub, true);
@@ -1160,14 +1231,14 @@ __device__ __forceinline__ void igemm_tile_halo(const IgemmP& p, float* lds, int
     }
 }
 
-template <int BN, int WAVES_M, int WAVES_N, int MINB, int SK>
+template <int BN, int WAVES_M, int WAVES_N, int MINB, int SK, int POOL = 0>
 __global__ __launch_bounds__(256, MINB) void igemm_halo_kernel(const IgemmP p) {
     using G = Geo<128, BN, WAVES_M, WAVES_N, 32>;
-    constexpr int LDSF = GeoHalo<BN>::TILE_FLOATS > G::EPI_FLOATS ? GeoHalo<BN>::TILE_FLOATS : G::EPI_FLOATS;
+    constexpr int LDSF = GeoHalo<BN, POOL>::TILE_FLOATS > G::EPI_FLOATS ? GeoHalo<BN, POOL>::TILE_FLOATS : G::EPI_FLOATS;
     __shared__ __attribute__((aligned(16))) float lds[LDSF];
     const int nu = (p.K / 32 + 5) / 6;                    // units of 6 K steps per tile (stream-K: K % 192 == 0)
     if constexpr (!SK) {
-        igemm_tile_halo<BN, WAVES_M, WAVES_N>(p, lds, xcd_remap(blockIdx.x, p.n_tiles), 0, nu, nullptr);
+        igemm_tile_halo<BN, WAVES_M, WAVES_N, POOL>(p, lds, xcd_remap(blockIdx.x, p.n_tiles), 0, nu, nullptr);
     } else {
         const long long U = (long long)p.n_tiles * nu;
         long long u = U * blockIdx.x / p.sk_blocks;
@@ -1178,7 +1249,7 @@ __global__ __launch_bounds__(256, MINB) void igemm_halo_kernel(const IgemmP p) {
             float* partial = (ub == 0 && ue == nu)
                                  ? nullptr
                                  : p.sk_ws + ((size_t)blockIdx.x * 2 + (seg ? 1 : 0)) * (size_t)(128 * BN);
-            igemm_tile_halo<BN, WAVES_M, WAVES_N>(p, lds, tile, ub, ue, partial);
+            igemm_tile_halo<BN, WAVES_M, WAVES_N, POOL>(p, lds, tile, ub, ue, partial);
             u += ue - ub;
         }
     }
@@ -1428,9 +1499,9 @@ inline int forced_bk() {
 }
 
 // 3x3 / stride 1 / pad 1 convs on the halo kernel (see igemm_tile_halo).  Returns 1 when it launched.
-template <int BN>
+template <int BN, int POOL = 0>
 int launch_halo(IgemmP& p, hipStream_t s, void* ws, size_t ws_bytes, int* rc) {
-    constexpr int BM = 128, MB = BN == 32 ? 4 : (BN == 256 ? 2 : 3);   // 37 / 42 / 50 / 67 KB of LDS per workgroup
+    constexpr int BM = 128, MB = BN == 32 ? 4 : (BN == 256 ? 2 : 3);   // 37 / 42 / 50 / 67 KB of LDS per workgroup (POOL: + 2 KB)
     const int tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = (p.N + BN - 1) / BN;
     p.n_tiles = tiles_m * p.tiles_n;
@@ -1441,7 +1512,7 @@ int launch_halo(IgemmP& p, hipStream_t s, void* ws, size_t ws_bytes, int* rc) {
     static const int sk_mode = [] { const char* e = getenv("DBMM_IGEMM_STREAMK"); return e ? atoi(e) : 1; }();
     const int grid_sk = NUM_CUS * MB;
     const size_t need = (size_t)grid_sk * 2 * BM * BN * sizeof(float);
-    if (sk_mode && whole_units && ws && ws_bytes >= need && dbmm_aligned16(ws) && nu >= 4) {
+    if (!POOL && sk_mode && whole_units && ws && ws_bytes >= need && dbmm_aligned16(ws) && nu >= 4) {
         const double per_slot = (double)p.n_tiles / NUM_CUS;
         const double eff = per_slot / (double)((p.n_tiles + NUM_CUS - 1) / NUM_CUS);
         if (sk_mode == 2 || (eff < 0.93 && (long long)p.n_tiles * nu >= 4LL * grid_sk && !sk_skip(p.n_tiles, MB))) {
@@ -1450,12 +1521,16 @@ int launch_halo(IgemmP& p, hipStream_t s, void* ws, size_t ws_bytes, int* rc) {
     }
     const dim3 g(p.sk_blocks ? p.sk_blocks : p.n_tiles, 1);
     constexpr int WM = BN == 32 ? 4 : 2, WN = BN == 32 ? 1 : 2;
-    if (p.sk_blocks)
-        hipLaunchKernelGGL((igemm_halo_kernel<BN, WM, WN, MB, 1>), g, dim3(256), 0, s, p);
-    else
-        hipLaunchKernelGGL((igemm_halo_kernel<BN, WM, WN, MB, 0>), g, dim3(256), 0, s, p);
+    if constexpr (POOL) {
+        hipLaunchKernelGGL((igemm_halo_kernel<BN, WM, WN, MB, 0, 1>), g, dim3(256), 0, s, p);
+    } else {
+        if (p.sk_blocks)
+            hipLaunchKernelGGL((igemm_halo_kernel<BN, WM, WN, MB, 1>), g, dim3(256), 0, s, p);
+        else
+            hipLaunchKernelGGL((igemm_halo_kernel<BN, WM, WN, MB, 0>), g, dim3(256), 0, s, p);
+    }
     {
-        const int c[11] = {BM, BN, WM, WN, 1, 0, 32, MB, 4, p.sk_blocks ? 1 : 0, 1};   // [8] = 4: halo kernel
+        const int c[11] = {BM, BN, WM, WN, 1, POOL, 32, MB, 4, p.sk_blocks ? 1 : 0, 1};   // [8] = 4: halo kernel, [5] = POOL
         for (int i = 0; i < 11; ++i) g_last_cfg[i] = c[i];
     }
     *rc = (int)hipGetLastError();
@@ -1464,6 +1539,14 @@ int launch_halo(IgemmP& p, hipStream_t s, void* ws, size_t ws_bytes, int* rc) {
         *rc = (int)hipGetLastError();
     }
     return 1;
+}
+
+// DBMM_IGEMM_HALO_POOL: pooled (2x2-window-major) 3x3 convs on the halo kernel: 0 never, 1 where the 128 x 256
+// per-tap tile does not apply (Cout % 256 != 0: layer 2's first block), 2 (default) every pooled 3x3 conv.
+// RN50, B = 1024, same box: 32.44 k / 32.78 k / 33.34 k images/s for 0 / 1 / 2.
+inline int halo_pool() {   // read on every call: tests compare the variants in one process
+    const char* e = getenv("DBMM_IGEMM_HALO_POOL");
+    return e ? atoi(e) : 2;
 }
 
 // DBMM_IGEMM_HALO256=1: 256-column tiles in the halo kernel for layers with N % 256 == 0 (developer A/B knob)
@@ -1480,6 +1563,13 @@ int launch_modes(IgemmP& p, hipStream_t s, int nbatch = 1, void* ws = nullptr, s
     if constexpr (AMODE == 1 && WMODE == 0) {
         // DBMM_IGEMM_HALO=0 selects the per-tap kernel (read on every call: tests compare both in one process)
         const char* e = getenv("DBMM_IGEMM_HALO");
+        if ((e ? atoi(e) : 1) && nbatch == 1 && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && p.slab == 32 &&
+            p.wh && p.nw == 1 && p.a_absmax && (p.Cin % 32) == 0 && p.a_bytes && p.wh_bytes && (p.N & 3) == 0 &&
+            p.pool2 && p.N > 32 && (p.M & 3) == 0 && (p.ldc & 3) == 0 && (!p.res || (p.ldr & 3) == 0) &&
+            (halo_pool() == 2 || (halo_pool() == 1 && (p.N % 256) != 0))) {
+            int rc = 0;
+            if (p.N <= 64 ? launch_halo<64, 1>(p, s, ws, wsb, &rc) : launch_halo<128, 1>(p, s, ws, wsb, &rc)) return rc;
+        }
         if ((e ? atoi(e) : 1) && nbatch == 1 && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && p.slab == 32 &&
             p.wh && p.nw == 1 && p.a_absmax && !p.pool2 && (p.Cin % 32) == 0 && p.a_bytes && p.wh_bytes &&
             (p.N & 3) == 0) {
@@ -1644,12 +1734,13 @@ int conv_impl(const float* x, const float* w, const float* bias, const float* re
         return launch_modes<0, 0>(p, s, 1, ws, wsb);
     }
     {
-        // KxK convs that the halo kernel does not take (the pooled 3x3 convs of the stride-2 blocks) with >= 256 output
-        // channels: the 128 x 256 tile halves the per-FLOP cost of the gather + split of the activations, which is what
-        // bounds the per-tap kernel.  DBMM_IGEMM_BN256_KXK=0 disables.
+        // KxK convs that the halo kernel does not take (pooled 3x3 convs under DBMM_IGEMM_HALO_POOL < 2, strided or
+        // larger windows) with >= 256 output channels: the 128 x 256 tile halves the per-FLOP cost of the gather + split
+        // of the activations, which is what bounds the per-tap kernel.  DBMM_IGEMM_BN256_KXK=0 disables.
         static const int bn256 = [] { const char* e = getenv("DBMM_IGEMM_BN256_KXK"); return e ? atoi(e) : 1; }();
         const char* he = getenv("DBMM_IGEMM_HALO");
-        const bool halo_takes_it = (he ? atoi(he) : 1) && KH == 3 && KW == 3 && stride == 1 && pad == 1 && !p.pool2;
+        const bool halo_takes_it = (he ? atoi(he) : 1) && KH == 3 && KW == 3 && stride == 1 && pad == 1 &&
+                                   (!p.pool2 || halo_pool() == 2);
         const bool pool_ok = !p.pool2 || ((Cout & 3) == 0 && (!residual || true));
         if (bn256 && !halo_takes_it && p.wh && p.nw == 1 && p.a_absmax && p.a_bytes && p.slab == 32 && (Cin % 32) == 0 && KH * KW <= 32 &&
             (Cout % 256) == 0 && M >= 8192 && pool_ok) {

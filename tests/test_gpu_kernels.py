@@ -541,11 +541,17 @@ def test_split_planes_f16_single_only_when_exact():
     assert ops.split_planes_f16(w.half().float())[2] == 2                   # not asked for
 
 
-@pytest.mark.parametrize("B,H,Cin,Cout,single", [(8, 28, 128, 64, True), (4, 20, 32, 32, True), (64, 28, 128, 128, True),
-                                                 (64, 28, 128, 128, False), (256, 14, 64, 256, True), (3, 12, 48, 64, False)])
-def test_conv_pool2_fused_equals_conv_then_avgpool(B, H, Cin, Cout, single):
+@pytest.mark.parametrize("B,H,Cin,Cout,single,halo_pool", [
+    (8, 28, 128, 64, True, 1), (4, 20, 32, 32, True, 1), (64, 28, 128, 128, True, 1), (64, 28, 128, 128, True, 0),
+    (64, 28, 128, 128, False, 1), (256, 14, 64, 256, True, 1), (256, 14, 64, 256, True, 2), (3, 12, 48, 64, False, 1),
+    (9, 56, 128, 128, True, 1), (131, 14, 64, 128, True, 1), (37, 26, 64, 64, True, 1), (690, 6, 64, 128, True, 1),
+    (131, 14, 96, 128, True, 1), (64, 28, 128, 512, True, 2), (7, 64, 32, 96, True, 1)])
+def test_conv_pool2_fused_equals_conv_then_avgpool(B, H, Cin, Cout, single, halo_pool, monkeypatch):
     """conv + ReLU + AvgPool2d(2) in one epilogue (rows walked 2x2-window-major) is bit-identical
-    to the same conv followed by dbmm_avgpool2d, and agrees with an fp64 reference."""
+    to the same conv followed by dbmm_avgpool2d, and agrees with an fp64 reference.  halo_pool = DBMM_IGEMM_HALO_POOL:
+    1 puts the pooled conv on the window-major halo kernel where Cout % 256 != 0, 2 (default) everywhere, 0 nowhere
+    (per-tap kernel).  Widths 26 / 14 / 6: the 32 windows of a tile wrap over 3 / 5 / 11+ pooled rows and over images."""
+    monkeypatch.setenv("DBMM_IGEMM_HALO_POOL", str(halo_pool))
     x = rnd(1, "x", (B, Cin, H, H)); w = rnd(2, "w", (Cout, Cin, 3, 3), (Cin * 9) ** -0.5)
     if single:
         w = w.half().float()
@@ -553,7 +559,8 @@ def test_conv_pool2_fused_equals_conv_then_avgpool(B, H, Cin, Cout, single):
     ref = F.conv2d(x.double(), w.double(), None, padding=1) * sc.double().view(1, -1, 1, 1) + b.double().view(1, -1, 1, 1)
     ref = F.avg_pool2d(torch.relu(ref), 2).permute(0, 2, 3, 1)
     xd = x.permute(0, 2, 3, 1).contiguous().to(DEV)
-    wp, wl = ops.pack_conv_weight(w.to(DEV))
+    # K order of the model (clip/model.py: 32-channel slabs, taps adjacent) for the halo_pool cases, tap-major otherwise
+    wp, wl = ops.pack_conv_weight(w.to(DEV), chunk_major=32 if (halo_pool != 1 or B * H * H >= 128 * 192) else False)
     ph, we, n = ops.split_planes_f16(wp, allow_single=single)
     kw = dict(w_planes_f16=ph, w_exp=we, x_absmax=xd.abs().max().reshape(1), out_scale=sc.to(DEV))
     am1, am2 = torch.zeros(1, device=DEV), torch.zeros(1, device=DEV)
@@ -567,7 +574,12 @@ def test_conv_pool2_fused_equals_conv_then_avgpool(B, H, Cin, Cout, single):
     else:
         assert torch.equal(fused, unf)
     assert relerr(fused.cpu().double(), ref) < 5e-6
-    if tag.startswith("igemm_x3_kernel<"):          # fused kernel ran: its scalar is the pooled maximum
+    big = single and Cin % 32 == 0 and B * H * H >= 192 * 128
+    if big and (halo_pool == 2 or (halo_pool == 1 and Cout % 256)) and Cout > 32:
+        assert tag.startswith("igemm_halo_kernel<") and tag.endswith(", 1>"), tag
+    if big and halo_pool == 0:
+        assert tag.startswith("igemm_x3_kernel<"), tag
+    if tag.startswith("igemm_x3_kernel<") or tag.startswith("igemm_halo_kernel<"):   # fused kernel ran: its scalar is the pooled maximum
         assert am1.item() == fused.abs().max().item()
     assert am1.item() <= am2.item()
 
@@ -760,7 +772,7 @@ def _last_cfg():
     return list(cfg)
 
 
-def test_operands_over_2gib_stay_on_the_split_kernels():
+def test_operands_over_2gib_stay_on_the_split_kernels(monkeypatch):
     """RN50 layer 1 at the headline batch 1024 holds 3.3 GB activation tensors.  Buffer descriptors
     address 32 bits, so every tile rebases its descriptor on a 64-bit base (a_desc in igemm_f32.hip):
     operands past 2 GiB must still run the fp16-pair / halo / dual-source kernels (cfg[8] in 2, 4, 5 --
@@ -827,12 +839,16 @@ def test_operands_over_2gib_stay_on_the_split_kernels():
         ref = F.conv2d(x[i].permute(2, 0, 1)[None].double(), w.double(), None, padding=1)[0].permute(1, 2, 0)
         ref = torch.relu(ref * sc.double() + b.double())
         assert relerr(y[i].double().cpu(), ref.cpu()) < 5e-6, i
-    # --- the per-tap conv kernel on the same tensor, pooled (window-major rows)
-    yp = ops.conv_bn_act(x, wp, b, None, 3, 3, 1, 1, ops.ACT_RELU, wl, w_planes_f16=ph, w_exp=we,
-                         x_absmax=x.abs().max().reshape(1), out_scale=sc, pool=2)
-    assert _last_cfg()[8] == 2 and _last_cfg()[4] == 1, _last_cfg()
-    for i in (0, 1440, B - 1):
-        assert relerr(yp[i].cpu(), F.avg_pool2d(y[i].permute(2, 0, 1)[None], 2)[0].permute(1, 2, 0).cpu()) < 2e-6, i
+    # --- the same tensor pooled (window-major rows): the halo kernel's pooled variant, then the per-tap conv kernel
+    for knob, kind in (("2", 4), ("0", 2)):
+        monkeypatch.setenv("DBMM_IGEMM_HALO_POOL", knob)
+        yp = ops.conv_bn_act(x, wp, b, None, 3, 3, 1, 1, ops.ACT_RELU, wl, w_planes_f16=ph, w_exp=we,
+                             x_absmax=x.abs().max().reshape(1), out_scale=sc, pool=2)
+        cfg = _last_cfg()
+        assert cfg[8] == kind and (cfg[5] == 1 if kind == 4 else cfg[4] == 1), cfg
+        for i in (0, 1440, B - 1):
+            assert relerr(yp[i].cpu(), F.avg_pool2d(y[i].permute(2, 0, 1)[None], 2)[0].permute(1, 2, 0).cpu()) < 2e-6, i
+        del yp
 
 
 @pytest.mark.parametrize("B,H,W,K,N,P,pooled", [(8, 56, 56, 64, 256, 64, False), (8, 56, 56, 64, 256, 128, True), (3, 10, 14, 64, 128, 64, False),
