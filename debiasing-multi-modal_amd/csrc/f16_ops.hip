@@ -54,6 +54,19 @@ struct GemmHP {
 };
 
 constexpr int GBM = 128;
+#ifndef GF16_SCHED
+#define GF16_SCHED 1
+#endif
+#if GF16_SCHED >= 1
+#define GF16_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define GF16_FENCE()
+#endif
+#if GF16_SCHED >= 2
+#define GF16_FENCE2() __builtin_amdgcn_sched_barrier(0)
+#else
+#define GF16_FENCE2()
+#endif
 
 // GBK = K depth of a chunk: 64 (128-B LDS rows, 64 KB for two stages, 2 workgroups per CU) or 32 (64-B rows, 32 KB, 3 per CU)
 template <int GBK>
@@ -156,13 +169,19 @@ __global__ __launch_bounds__(256, MINB) void gemm_f16_kernel(const GemmHP p) {
     store_chunk(0, a_r0, w_r0);
     __syncthreads();
     // chunk kc lives in stage kc & 1; set r1 holds chunk kc+1 on even steps, r0 on odd ones
+    // (the scheduling fences keep the loads in front of the MFMAs: left alone the compiler sinks them behind the LDS
+    //  stores of the other set, whose s_waitcnt vmcnt(0) then drains the whole queue in the middle of the step)
     for (int kc = 0; kc < nk; kc += 2) {
         load_chunk(kc + 2, a_r0, w_r0);
+        GF16_FENCE();
         compute(0);
+        GF16_FENCE2();
         store_chunk(1, a_r1, w_r1);
         __syncthreads();
         load_chunk(kc + 3, a_r1, w_r1);
+        GF16_FENCE();
         compute(1);                                       // (kc + 1 == nk: a chunk of zeros)
+        GF16_FENCE2();
         store_chunk(0, a_r0, w_r0);
         __syncthreads();
     }
