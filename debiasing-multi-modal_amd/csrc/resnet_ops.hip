@@ -9,9 +9,89 @@ namespace {
 // ---------------------------------------------------------------------------------------
 // stem conv1: 3x3, stride 2, pad 1, Cin = 3, NCHW image -> NHWC, + bias (folded BN) + ReLU.
 // One thread per output pixel: its 27 input taps live in registers, weights [27][Cout] are
-// broadcast from LDS in groups of 8 output channels.  0.2 % of the network's FLOPs.
+// broadcast from LDS in groups of 8 output channels.  0.2 % of the network's FLOPs, but 1.6 GB of
+// output at B = 1024: the results go through an LDS staging tile so that the workgroup's 256
+// pixels x Cout channels leave as ONE contiguous run of 16-B lane stores (a thread storing its own
+// pixel's channels writes 16 B into 64 different 128-B lines per instruction: 2.6 TB/s).
 // ---------------------------------------------------------------------------------------
+template <int COUT>
 __global__ __launch_bounds__(256) void stem_s2_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                      const float* __restrict__ bias, float* __restrict__ y,
+                                                      float* __restrict__ y_absmax, int B, int H, int W, int Ho,
+                                                      int Wo) {
+    constexpr int Cout = COUT, PITCH = COUT + 4;                // staging row pitch (floats): 16-B aligned, rows shifted by 4 banks
+    __shared__ __attribute__((aligned(16))) float sw[28 * COUT];        // [27][Cout] then bias[Cout]
+    __shared__ __attribute__((aligned(16))) float stage[256 * PITCH];
+    for (int i = threadIdx.x; i < 27 * Cout; i += blockDim.x) sw[i] = w[i];
+    for (int i = threadIdx.x; i < Cout; i += blockDim.x) sw[27 * Cout + i] = bias ? bias[i] : 0.f;
+    __syncthreads();
+    const long long m0 = (long long)blockIdx.x * blockDim.x, m = m0 + threadIdx.x;
+    const long long M = (long long)B * Ho * Wo;
+    float omax = 0.f;                       // outputs are post-ReLU: max == max|y|
+    if (m < M) {
+    const int wo = (int)(m % Wo), ho = (int)((m / Wo) % Ho), n = (int)(m / ((long long)Wo * Ho));
+    float xin[27];
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+            const int hi = ho * 2 - 1 + kh, wi = wo * 2 - 1 + kw;
+            const bool ok = hi >= 0 && hi < H && wi >= 0 && wi < W;
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                xin[(kh * 3 + kw) * 3 + c] = ok ? x[(((long long)n * 3 + c) * H + hi) * W + wi] : 0.f;
+        }
+    float* so = stage + threadIdx.x * PITCH;
+    for (int c0 = 0; c0 < Cout; c0 += 8) {
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+#pragma unroll
+        for (int t = 0; t < 27; ++t) {
+            // (weights as scalar loads straight from memory, SGPR operands of the FMAs, measured 0.93 ms against
+            //  0.67 ms through LDS at B = 1024: the SGPR file spills into VGPR lanes)
+            const f32x4 w0 = *(const f32x4*)(sw + t * Cout + c0);
+            const f32x4 w1 = *(const f32x4*)(sw + t * Cout + c0 + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc[j] = fmaf(xin[t], w0[j], acc[j]);
+                acc[4 + j] = fmaf(xin[t], w1[j], acc[4 + j]);
+            }
+        }
+        f32x4 o0, o1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            o0[j] = fmaxf(acc[j] + sw[27 * Cout + c0 + j], 0.f);
+            o1[j] = fmaxf(acc[4 + j] + sw[27 * Cout + c0 + 4 + j], 0.f);
+        }
+        *(f32x4*)(so + c0) = o0;
+        *(f32x4*)(so + c0 + 4) = o1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) omax = fmaxf(omax, fmaxf(o0[j], o1[j]));
+    }
+    }
+    __syncthreads();
+    // the workgroup's pixels m0 .. m0 + 255 are contiguous in y ([M][Cout]): 16-B chunk q of the run = pixel q / (Cout/4)
+    constexpr int QPP = COUT / 4;
+    const long long run = (M - m0 < 256 ? M - m0 : 256) * QPP;
+    f32x4* yo = (f32x4*)(y + m0 * Cout);
+#pragma unroll 4
+    for (int q = threadIdx.x; q < 256 * QPP; q += 256)
+        if (q < run) yo[q] = *(const f32x4*)(stage + (q / QPP) * PITCH + (q % QPP) * 4);
+    if (y_absmax) {       // one (filtered) atomic per workgroup: every workgroup targets the same address
+        __shared__ float wmax[4];
+        omax = wave_max(omax);
+        if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = omax;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            omax = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+            if (omax > *(volatile const float*)y_absmax) atomicMax((unsigned*)y_absmax, __float_as_uint(omax));
+        }
+    }
+}
+
+// any Cout % 8 == 0 (tiny test geometries): every thread stores its own pixel's channels
+__global__ __launch_bounds__(256) void stem_s2_generic_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                       const float* __restrict__ bias, float* __restrict__ y,
                                                       float* __restrict__ y_absmax, int B, int H, int W, int Ho,
                                                       int Wo, int Cout) {
@@ -146,9 +226,17 @@ extern "C" int dbmm_conv_stem_s2(const float* x_nchw, const float* w, const floa
     const int64_t Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
     const int64_t M = B * Ho * Wo;
     if (M > INT32_MAX) return DBMM_E_SHAPE;
-    const size_t smem = (size_t)(28 * Cout) * sizeof(float);
-    hipLaunchKernelGGL(stem_s2_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), smem, (hipStream_t)stream,
-                       x_nchw, w, bias, y_nhwc, y_absmax, (int)B, (int)H, (int)W, (int)Ho, (int)Wo, (int)Cout);
+    const dim3 g((unsigned)((M + 255) / 256));
+    hipStream_t s = (hipStream_t)stream;
+#define DBMM_STEM(C) hipLaunchKernelGGL(stem_s2_kernel<C>, g, dim3(256), 0, s, x_nchw, w, bias, y_nhwc, y_absmax, (int)B, (int)H, (int)W, (int)Ho, (int)Wo)
+    if (Cout == 32) DBMM_STEM(32);            // RN50 / RN101
+    else if (Cout == 40) DBMM_STEM(40);       // RN50x4
+    else if (Cout == 48) DBMM_STEM(48);       // RN50x16
+    else if (Cout == 64) DBMM_STEM(64);       // RN50x64
+    else
+        hipLaunchKernelGGL(stem_s2_generic_kernel, g, dim3(256), (size_t)(28 * Cout) * sizeof(float), s, x_nchw, w, bias, y_nhwc,
+                           y_absmax, (int)B, (int)H, (int)W, (int)Ho, (int)Wo, (int)Cout);
+#undef DBMM_STEM
     DBMM_CHECK_LAUNCH();
     return DBMM_OK;
 }

@@ -102,7 +102,7 @@ def test_conv_chunk_major_weights(B, H, Cin, Cout):
     assert wl0 == ops.WL_TAP_MAJOR and wp0.shape == (Cout, 72)
 
 
-@pytest.mark.parametrize("B,R,Cout", [(2, 64, 32), (3, 33, 16), (1, 224, 32)])
+@pytest.mark.parametrize("B,R,Cout", [(2, 64, 32), (3, 33, 16), (1, 224, 32), (3, 33, 32), (2, 50, 40), (1, 36, 48), (5, 30, 64)])
 def test_conv_stem_s2(B, R, Cout):
     x = rnd(1, "x", (B, 3, R, R)); w = rnd(2, "w", (Cout, 3, 3, 3), 27 ** -0.5); b = rnd(3, "b", (Cout,), 0.1)
     ref = F.relu(F.conv2d(x, w, b, stride=2, padding=1)).permute(0, 2, 3, 1)
