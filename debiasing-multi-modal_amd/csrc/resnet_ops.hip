@@ -2,6 +2,7 @@
 // attention-pool token assembly and its one-query attention core.  All HBM-bound
 // (coalesced, float4 where the layout allows); the heavy projections go through
 // dbmm_gemm_bias_act.
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -85,6 +86,187 @@ __global__ __launch_bounds__(256) void stem_s2_kernel(const float* __restrict__ 
         __syncthreads();
         if (threadIdx.x == 0) {
             omax = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+            if (omax > *(volatile const float*)y_absmax) atomicMax((unsigned*)y_absmax, __float_as_uint(omax));
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// stem conv1 on the matrix cores (Cout = 32 or 64).  The 27-tap gather is the A operand of a
+// 32 pixels x 32 (27 + 5 zero) K x Cout product: each lane fetches the 16 taps its fragment rows
+// need straight from the NCHW image (masked taps through the descriptor's out-of-range zero),
+// splits them into fp16 hi + lo under the WAVE's own exact power-of-two scale (a wave's outputs
+// depend on its own 32 pixels only, so no tensor-wide maximum is needed), the weights -- folded
+// BatchNorm, not fp16-exact -- are split the same way once per wave, and an fp32 product is the
+// three MFMA products (lo,hi) (hi,lo) (hi,hi): 12 MFMAs per 32 pixels replace 864 FMAs per pixel,
+// no LDS at all.  The accumulator layout (column = channel) stores two whole 128-B pixel rows per
+// wave instruction.  Bound: HBM (0.15 MB in + 1.6 MB out per image at 224 px).
+// ---------------------------------------------------------------------------------------
+typedef _Float16 stem_f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int stem_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ stem_f16x8 stem_frag(const unsigned (&v)[4]) { return __builtin_bit_cast(stem_f16x8, (stem_u32x4){v[0], v[1], v[2], v[3]}); }
+
+__device__ __forceinline__ int stem_scale_exp(float amax) {          // 2^s * amax in [2^13, 2^14): fp16 hi + lo keep 22 bits
+    const unsigned b = __float_as_uint(amax) & 0x7fffffffu;
+    int s = b ? 13 - ((int)(b >> 23) - 127) : 0;
+    return s < -60 ? -60 : (s > 60 ? 60 : s);
+}
+__device__ __forceinline__ float stem_pow2(int e) { return __uint_as_float((unsigned)(e + 127) << 23); }
+__device__ __forceinline__ void stem_split_pair(float x0, float x1, float sc, unsigned& hi, unsigned& lo) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(hi) : "v"(x0), "v"(sc));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(hi) : "v"(x1), "v"(sc));
+    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(lo) : "v"(x0), "v"(sc), "v"(hi));
+    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(lo) : "v"(x1), "v"(sc), "v"(hi));
+#else
+    (void)x0; (void)x1; (void)sc; hi = lo = 0;
+#endif
+}
+
+#ifndef STEM_PREFETCH
+#define STEM_PREFETCH 1
+#define STEM_MINB(NB) (NB == 1 ? 3 : 2)
+#endif
+template <int NB>                                                    // NB = Cout / 32
+__global__ __launch_bounds__(256, STEM_MINB(NB)) void stem_s2_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                           const float* __restrict__ bias, float* __restrict__ y,
+                                                           float* __restrict__ y_absmax, int B, int H, int W, int Ho, int Wo,
+                                                           int n_blocks) {
+    constexpr int Cout = NB * 32;
+    constexpr unsigned OOR = 0x80000000u;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int fr = lane & 31, fh = lane >> 5;
+    const long long M = (long long)B * Ho * Wo, img = 3LL * H * W;
+    // K slot (fh, t = ks * 8 + i) -> tap.  Any bijection works as long as both operands use it; this one keeps a slot's
+    // two taps (fh = 0 / 1) compile-time constants, so offsets and validity bits are scalar selects instead of 32 VGPRs:
+    //   t < 9: (kw, c) = (t / 3, t % 3), kh = fh;   t >= 9: kh = 2, (kw, c) pair t - 9 (fh = 0) or t - 2 (fh = 1, t = 9, 10)
+    auto slot_tap = [](int f, int t, int& kh, int& kw, int& c) -> bool {
+        int pr;
+        if (t < 9) { kh = f; pr = t; }
+        else { kh = 2; pr = f ? t - 2 : t - 9; if (pr > 8) { kh = kw = c = 0; return false; } }
+        kw = pr / 3; c = pr - kw * 3;
+        return true;
+    };
+    // weights: B operand, column n = channel j * 32 + fr, the same K indices; split under the wave's scale
+    unsigned wh[NB][2][4], wlo[NB][2][4];
+    float bv[NB];
+    int e_w;
+    {
+        float wv[NB][16], wmax = 0.f;
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                int kh0, kw0, c0, kh1, kw1, c1;
+                const bool v0 = slot_tap(0, t, kh0, kw0, c0), v1 = slot_tap(1, t, kh1, kw1, c1);
+                const int k = fh ? (kh1 * 3 + kw1) * 3 + c1 : (kh0 * 3 + kw0) * 3 + c0;
+                wv[j][t] = (fh ? v1 : v0) ? w[k * Cout + j * 32 + fr] : 0.f;
+                wmax = fmaxf(wmax, fabsf(wv[j][t]));
+            }
+        e_w = stem_scale_exp(wave_max(wmax));
+        const float sc = stem_pow2(e_w);
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) stem_split_pair(wv[j][ks * 8 + 2 * q], wv[j][ks * 8 + 2 * q + 1], sc, wh[j][ks][q], wlo[j][ks][q]);
+            bv[j] = bias ? bias[j * 32 + fr] : 0.f;
+        }
+    }
+    const int n_waves = gridDim.x * 4;
+    float xv[16];
+    long long img0 = 0;                                              // image of the block's first pixel (descriptor base)
+    auto gather = [&](int blk) {
+        const long long m = (long long)blk * 32 + fr;
+        const long long mb = (long long)blk * 32;
+        img0 = mb / ((long long)Ho * Wo);
+        const long long left = (long long)B - img0;
+        const long long ext = (left < 2 ? left : 2) * img * 4;        // 32 pixels touch at most two images
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(x + img0 * img), 0, (int)ext, 0x00020000);
+        unsigned base = OOR;
+        int mask = 0;
+        if (m < M) {
+            const int wo = (int)(m % Wo), ho = (int)((m / Wo) % Ho);
+            const int n = (int)(m / ((long long)Wo * Ho) - img0);
+            const int hi0 = 2 * ho - 1, wi0 = 2 * wo - 1;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                if (hi0 + d >= 0 && hi0 + d < H) mask |= 1 << d;
+                if (wi0 + d >= 0 && wi0 + d < W) mask |= 8 << d;
+            }
+            base = (unsigned)((long long)n * img + (long long)hi0 * W + wi0);      // may wrap below zero: only used with valid taps
+        }
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            int kh0, kw0, c0, kh1, kw1, c1;
+            const bool v0 = slot_tap(0, t, kh0, kw0, c0), v1 = slot_tap(1, t, kh1, kw1, c1);
+            const int off0 = (c0 * H + kh0) * W + kw0, off1 = (c1 * H + kh1) * W + kw1;          // uniform
+            const int bit0 = v0 ? (1 << kh0) | (8 << kw0) : 64, bit1 = v1 ? (1 << kh1) | (8 << kw1) : 64;   // bit 6 is never in a mask
+            const int bit = fh ? bit1 : bit0;
+            const bool ok = (mask & bit) == bit;
+            xv[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, ok ? (base + (unsigned)(fh ? off1 : off0)) * 4u : OOR, 0, 0));
+        }
+    };
+    float omax = 0.f;
+    int blk = blockIdx.x * 4 + wave;
+    if (STEM_PREFETCH && blk < n_blocks) gather(blk);
+    for (; blk < n_blocks; blk += n_waves) {
+        if (!STEM_PREFETCH) gather(blk);
+        float amax = 0.f;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) amax = fmaxf(amax, fabsf(xv[t]));
+        const int e_a = stem_scale_exp(wave_max(amax));
+        const float sc = stem_pow2(e_a);
+        unsigned ah[2][4], al[2][4];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) stem_split_pair(xv[ks * 8 + 2 * q], xv[ks * 8 + 2 * q + 1], sc, ah[ks][q], al[ks][q]);
+        const long long mb = (long long)blk * 32;
+        if (STEM_PREFETCH && blk + n_waves < n_blocks) gather(blk + n_waves);   // next block's taps in flight during the MFMAs and stores
+        const float osc = stem_pow2(-e_a - e_w);
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(stem_frag(al[ks]), stem_frag(wh[j][ks]), acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(stem_frag(ah[ks]), stem_frag(wlo[j][ks]), acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(stem_frag(ah[ks]), stem_frag(wh[j][ks]), acc, 0, 0, 0);
+            // accumulator register r = pixel row (r & 3) + 8 (r >> 2) + 4 fh, column = channel j * 32 + fr
+            const long long rows_left = M - mb;
+            const long long bytes = (rows_left < 32 ? rows_left : 32) * Cout * 4;
+            const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)(y + mb * Cout), 0, (int)bytes, 0x00020000);
+            const unsigned voff = (unsigned)((4 * fh * Cout + j * 32 + fr) * 4);
+            float bmax = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row0 = (r & 3) + 8 * (r >> 2);                          // + 4 fh
+                const float v = fmaxf(fmaf(acc[r], osc, bv[j]), 0.f);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ry, voff, (unsigned)(row0 * Cout * 4), 0);
+                bmax = fmaxf(bmax, v);
+            }
+            // rows past M exist only in the very last block: their lanes gathered zeros, so v = relu(bias) there
+            if (rows_left >= 32) omax = fmaxf(omax, bmax);
+            else
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if ((r & 3) + 8 * (r >> 2) + 4 * fh < rows_left) omax = fmaxf(omax, fmaxf(fmaf(acc[r], osc, bv[j]), 0.f));
+        }
+    }
+    if (y_absmax) {
+        __shared__ float wmax_s[4];
+        omax = wave_max(omax);
+        if (lane == 0) wmax_s[wave] = omax;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            omax = fmaxf(fmaxf(wmax_s[0], wmax_s[1]), fmaxf(wmax_s[2], wmax_s[3]));
             if (omax > *(volatile const float*)y_absmax) atomicMax((unsigned*)y_absmax, __float_as_uint(omax));
         }
     }
@@ -229,6 +411,20 @@ extern "C" int dbmm_conv_stem_s2(const float* x_nchw, const float* w, const floa
     const dim3 g((unsigned)((M + 255) / 256));
     hipStream_t s = (hipStream_t)stream;
 #define DBMM_STEM(C) hipLaunchKernelGGL(stem_s2_kernel<C>, g, dim3(256), 0, s, x_nchw, w, bias, y_nhwc, y_absmax, (int)B, (int)H, (int)W, (int)Ho, (int)Wo)
+    // DBMM_STEM_MFMA=0: the FMA kernels (read on every call: the tests compare both)
+    const char* e = getenv("DBMM_STEM_MFMA");
+    if ((e ? atoi(e) : 1) && (Cout == 32 || Cout == 64) && 3 * H * W * 8 < 0x7FFFFFF0LL && (M + 31) / 32 <= INT32_MAX) {
+        const int n_blocks = (int)((M + 31) / 32);
+        const int wgs = (n_blocks + 3) / 4 < 256 * 8 ? (n_blocks + 3) / 4 : 256 * 8;
+        if (Cout == 32)
+            hipLaunchKernelGGL(stem_s2_mfma_kernel<1>, dim3(wgs), dim3(256), 0, s, x_nchw, w, bias, y_nhwc, y_absmax, (int)B, (int)H,
+                               (int)W, (int)Ho, (int)Wo, n_blocks);
+        else
+            hipLaunchKernelGGL(stem_s2_mfma_kernel<2>, dim3(wgs), dim3(256), 0, s, x_nchw, w, bias, y_nhwc, y_absmax, (int)B, (int)H,
+                               (int)W, (int)Ho, (int)Wo, n_blocks);
+        DBMM_CHECK_LAUNCH();
+        return DBMM_OK;
+    }
     if (Cout == 32) DBMM_STEM(32);            // RN50 / RN101
     else if (Cout == 40) DBMM_STEM(40);       // RN50x4
     else if (Cout == 48) DBMM_STEM(48);       // RN50x16
