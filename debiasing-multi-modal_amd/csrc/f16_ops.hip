@@ -40,7 +40,13 @@ __device__ __forceinline__ unsigned pack2(float a, float b) {
 }
 __device__ __forceinline__ float act_f(float v, int act) {
     if (act == DBMM_ACT_RELU) return fmaxf(v, 0.f);
+    // QuickGELU v * sigmoid(1.702 v) on the hardware exp2 / rcp (1 ulp each; the result is rounded to fp16 anyway).
+    // v -> -inf: exp2 -> inf, rcp -> 0, v * 0 = -0; v -> +inf: exp2 -> 0, v * 1.
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (act == DBMM_ACT_QUICKGELU) return v * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-2.4554669595930157f * v));
+#else
     if (act == DBMM_ACT_QUICKGELU) return v / (1.f + expf(-1.702f * v));
+#endif
     return v;
 }
 
@@ -223,6 +229,208 @@ __global__ __launch_bounds__(256, MINB) void gemm_f16_kernel(const GemmHP p) {
                     *(u32x4*)(p.c + (long long)m * p.ldc + n) = (u32x4){pack2(o[0], o[1]), pack2(o[2], o[3]), pack2(o[4], o[5]), pack2(o[6], o[7])};
             }
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// GEMM, deep-pipelined: 256 x 256 x 64 tiles, 8 waves (2 x 4, 128 x 64 of output each), one workgroup per CU.
+// The structure of cdna_hip_programming.md section 5 ("256^2 8-phase"), re-derived for this kernel's 32x32x16 fp16 MFMA:
+//   * operands reach LDS by LDS-DMA (buffer_load ... lds, 1 KB per wave instruction): no staging registers, no ds_write;
+//     the XOR swizzle that keeps ds_read_b128 conflict-free is applied to the SOURCE chunk index;
+//   * a K tile is four HALF-TILES of 128 rows x 64 k (16 KB): Ah0 / Ah1 = the first / second 64 rows of both wave rows'
+//     A blocks, Bh0 / Bh1 = the first / second 32 columns of all four wave columns' W blocks.  A wave walks its 128 x 64
+//     block as four 64 x 32 quadrants, one per PHASE: (A0,B0) (A0,B1) (A1,B1) (A1,B0), so a phase needs at most one new
+//     half of each operand (12 / 4 / 8 / 0 ds_read_b128) and every half-tile has ONE phase in which it is first needed;
+//   * each phase also stages one half-tile (2 DMA instructions per thread) for five phases later; s_waitcnt vmcnt(6)
+//     (three half-tiles stay in flight -- the queue is never drained in the loop) retires the one staged three phases ago,
+//     which is read one phase after that wait; a slot is restaged >= 3 phases after its last read.  Two LDS buffers
+//     x four half-tiles = 128 KB;
+//   * the wave rows run ONE BARRIER APART: while waves 0-3 issue their 8 MFMAs (256 cycles, s_setprio 1) waves 4-7 do
+//     their LDS reads, DMA issue and waits, and vice versa -- each SIMD's two waves alternate on the matrix pipe.
+//   * with one workgroup per CU nothing else hides a tile's first round trip or its epilogue, so the workgroups are
+//     PERSISTENT (one per CU, each walking a contiguous tile range of its XCD) and the next tile's first five half-tiles
+//     are issued BEFORE the current tile's epilogue, whose LDS staging lives beside the ring (160 KB in all).
+// Needs N % 256 == 0 and K % 128 == 0 (two K tiles per loop trip).  Epilogue as in gemm_f16_kernel.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int PH_HALF = 128 * 64 * 2;                              // bytes of a half-tile
+
+__device__ __forceinline__ void glds16(__amdgpu_buffer_rsrc_t r, unsigned char* lds_dst, unsigned voff, unsigned soff) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_dst, 16, voff, soff, 0, 0);
+#else
+    (void)r; (void)lds_dst; (void)voff; (void)soff;
+#endif
+}
+
+__global__ __launch_bounds__(512, 1) void gemm_f16_8ph_kernel(const GemmHP p) {
+    // [buffer 2][Ah0, Bh0, Bh1, Ah1] = 128 KB, then the epilogue staging.  The staging (8 waves x 32 x 68 floats = 68 KB) starts
+    // at 80 KB: the next tile's first five half-tiles (buffer 0 and Ah0 of buffer 1 = the first 80 KB) land beside it.
+    constexpr int EPI_OFF = 5 * PH_HALF;
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[160 * 1024];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6), wr = wid >> 2, wc = wid & 3;
+    const int fr = lane & 31, fh = lane >> 5;
+    // this workgroup's tiles: the XCD's contiguous range (xcd_remap's split), walked with the stride of the XCD's workgroups
+    const int nwg = gridDim.x, xcd = blockIdx.x & 7, slot_in_xcd = blockIdx.x >> 3, wg_per_xcd = (nwg - xcd + 7) >> 3;
+    const int tq = p.n_tiles >> 3, trm = p.n_tiles & 7;
+    const int t_lo = xcd < trm ? xcd * (tq + 1) : trm * (tq + 1) + (xcd - trm) * tq, t_hi = t_lo + tq + (xcd < trm ? 1 : 0);
+    const __amdgpu_buffer_rsrc_t rsA0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.a, 0, 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsW0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, 0, 0x00020000);
+    __amdgpu_buffer_rsrc_t rsA = rsA0, rsW = rsW0;
+    int m0 = 0, n0 = 0;
+    // stager: thread -> LDS chunk (tid + 512 i) of a half-tile = local row (tid >> 3) + 64 i, slot tid & 7; it fetches
+    // source chunk slot ^ swz(row).  Half-tile kind k = 0..3 (Ah0, Bh0, Bh1, Ah1) -> operand rows:
+    //   A half h: tile row (lr >> 6) * 128 + h * 64 + (lr & 63);   W half h: tile column (lr >> 5) * 64 + h * 32 + (lr & 31)
+    unsigned voff[4][2];
+    auto set_tile = [&](int tile) {
+        m0 = (tile / p.tiles_n) * 256; n0 = (tile % p.tiles_n) * 256;
+        rsA = desc(p.a, p.a_total, (long long)m0 * p.lda * 2);
+        rsW = desc(p.w, p.w_total, (long long)n0 * p.ldw * 2);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int lr = (tid >> 3) + 64 * i, c = (tid & 7) ^ ((lr >> 1) & 7);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int ra = (lr >> 6) * 128 + h * 64 + (lr & 63), rw = (lr >> 5) * 64 + h * 32 + (lr & 31);
+                voff[h ? 3 : 0][i] = m0 + ra < p.M ? (unsigned)ra * (unsigned)(p.lda * 2) + c * 16u : OOR;
+                voff[h ? 2 : 1][i] = (unsigned)rw * (unsigned)(p.ldw * 2) + c * 16u;
+            }
+        }
+    };
+    const int nT = p.K / 64;
+    // stage number q: kind q & 3 of K tile q >> 2 into buffer (q >> 2) & 1; tiles past the end go through the zero-extent
+    // descriptors so that every phase issues exactly two DMA instructions per wave (the vmcnt arithmetic relies on it)
+    auto stage = [&](int kind, int buf, int t) {
+        const bool isA = kind == 0 || kind == 3, valid = t < nT;
+        const __amdgpu_buffer_rsrc_t rs = isA ? (valid ? rsA : rsA0) : (valid ? rsW : rsW0);
+        unsigned char* slot = lds + (buf * 4 + kind) * PH_HALF + wid * 1024;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) glds16(rs, slot + i * 8192, voff[kind][i], (unsigned)t * 128u);
+    };
+    // fragment addresses inside a half-tile (bytes): A rows wr * 64 + blk * 32 + fr, W rows wc * 32 + fr, chunk (2 ks + fh) ^ swz
+    int aoff[2][4], boff[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int r = wr * 64 + b * 32 + fr;
+            aoff[b][ks] = r * 128 + (((2 * ks + fh) ^ ((r >> 1) & 7)) << 4);
+        }
+        const int r = wc * 32 + fr;
+        boff[ks] = r * 128 + (((2 * ks + fh) ^ ((r >> 1) & 7)) << 4);
+    }
+    f32x16 acc[4][2];
+    u32x4 fa[2][4], fb0[4], fb1[4];
+
+    // one phase: j = phase within the loop trip (static), t2 = first K tile of the trip
+    auto phase = [&](int j, int t2) {
+        const int ph = j & 3, buf = (j >> 2) & 1;
+        const unsigned char* base = lds + buf * 4 * PH_HALF;
+        if (ph == 0) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) fb0[ks] = *(const u32x4*)(base + 1 * PH_HALF + boff[ks]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) fa[b][ks] = *(const u32x4*)(base + 0 * PH_HALF + aoff[b][ks]);
+        } else if (ph == 1) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) fb1[ks] = *(const u32x4*)(base + 2 * PH_HALF + boff[ks]);
+        } else if (ph == 2) {
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) fa[b][ks] = *(const u32x4*)(base + 3 * PH_HALF + aoff[b][ks]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            const int q = j + 5;                                      // stage number relative to the trip's first tile
+            stage(q & 3, (q >> 2) & 1, t2 + (q >> 2));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+        const int ai = (ph >= 2) ? 2 : 0, bj = (ph == 1 || ph == 2) ? 1 : 0;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+                acc[ai + b][bj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[b][ks]),
+                                                                         __builtin_bit_cast(f16x8, bj ? fb1[ks] : fb0[ks]), acc[ai + b][bj], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+    };
+
+    // prologue of a tile: stages 0 .. 4 (K tile 0 complete + Ah0 of K tile 1)
+    auto prologue = [&]() {
+#pragma unroll
+        for (int q = 0; q < 5; ++q) stage(q & 3, (q >> 2) & 1, q >> 2);
+    };
+    constexpr int WTN = 64, G_LROW = WTN + 4, LPR = WTN / 8, RPI = 64 / LPR, NIT = 32 / RPI;
+    float* Ls = (float*)(lds + EPI_OFF) + wid * (32 * G_LROW);
+    const int ec = (lane % LPR) * 8, er = lane / LPR;
+    const int wm0 = wr * 128, wn0 = wc * 64;
+
+    int tile = t_lo + slot_in_xcd;
+    if (tile < t_hi) { set_tile(tile); prologue(); }
+    for (; tile < t_hi; tile += wg_per_xcd) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    // everything this wave has in flight (the prologue issued before the previous tile's epilogue, that epilogue's own
+    // loads and stores) is retired here; the prologue's five half-tiles had the whole epilogue to land
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    // the vmcnt(6) arithmetic of the phases wants three half-tiles in flight: re-issue nothing, the first three waits are
+    // simply satisfied at once
+    if (wr == 1) __builtin_amdgcn_s_barrier();                        // the second wave row runs one barrier behind
+    for (int t2 = 0; t2 < nT; t2 += 2) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) phase(j, t2);
+    }
+    if (wr == 0) __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // the (zero-extent) tail DMA of this tile
+    __builtin_amdgcn_s_barrier();                                     // every wave is done with the ring
+    const int em0 = m0, en0 = n0;
+    if (tile + wg_per_xcd < t_hi) { set_tile(tile + wg_per_xcd); prologue(); }   // in flight during the epilogue below
+
+    // epilogue: each wave transposes its 128 x 64 block 32 rows at a time through its own LDS slice (see gemm_f16_kernel)
+    const int n = en0 + wn0 + ec;
+    f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;
+    if (p.bias) { b0 = *(const f32x4*)(p.bias + n); b1 = *(const f32x4*)(p.bias + n + 4); }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) Ls[((r & 3) + 8 * (r >> 2) + 4 * fh) * G_LROW + j * 32 + fr] = acc[i][j][r];
+        u32x4 rv[NIT];
+#pragma unroll
+        for (int t = 0; t < NIT; ++t) {
+            const int m = em0 + wm0 + 32 * i + er + RPI * t;
+            rv[t] = (u32x4){0u, 0u, 0u, 0u};
+            if (p.res && m < p.M) rv[t] = *(const u32x4*)(p.res + (long long)m * p.ldr + n);
+        }
+#pragma unroll
+        for (int t = 0; t < NIT; ++t) {
+            const int row = er + RPI * t, m = em0 + wm0 + 32 * i + row;
+            const f32x4 v0 = *(const f32x4*)(Ls + row * G_LROW + ec) + b0, v1 = *(const f32x4*)(Ls + row * G_LROW + ec + 4) + b1;
+            const f16x8 rh = __builtin_bit_cast(f16x8, rv[t]);
+            float o[8];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { o[q] = act_f(v0[q], p.act) + (float)rh[q]; o[4 + q] = act_f(v1[q], p.act) + (float)rh[4 + q]; }
+            if (m < p.M)
+                *(u32x4*)(p.c + (long long)m * p.ldc + n) = (u32x4){pack2(o[0], o[1]), pack2(o[2], o[3]), pack2(o[4], o[5]), pack2(o[6], o[7])};
+        }
+    }
     }
 }
 
@@ -558,6 +766,18 @@ extern "C" int dbmm_gemm_f16(const void* a, int64_t lda, const void* w, int64_t 
     // developer A/B knobs: DBMM_F16_BK = 32 | 64 (K depth of a chunk), DBMM_F16_BN256 = 0 | 1 (128 x 256 tile for wide GEMMs)
     static const int bk = [] { const char* e = getenv("DBMM_F16_BK"); return e ? atoi(e) : 64; }();
     static const int bn256 = [] { const char* e = getenv("DBMM_F16_BN256"); return e ? atoi(e) : 1; }();
+    // DBMM_F16_8PH=0: without the deep-pipelined 256 x 256 kernel (read on every call: the tests compare both)
+    {
+        const char* e8 = getenv("DBMM_F16_8PH");
+        if ((e8 ? atoi(e8) : 1) && (N % 256) == 0 && (K % 128) == 0 && M >= 16384) {
+            p.tiles_n = (int)(N / 256);
+            p.n_tiles = (int)((M + 255) / 256) * p.tiles_n;
+            const int grid = p.n_tiles < 256 ? p.n_tiles : 256;   // persistent: one workgroup per CU
+            hipLaunchKernelGGL(gemm_f16_8ph_kernel, dim3(grid), dim3(512), 0, (hipStream_t)stream, p);
+            DBMM_CHECK_LAUNCH();
+            return DBMM_OK;
+        }
+    }
     const bool wide = bn256 && N >= 768 && (N % 256) == 0 && M >= 32768;     // (ViT-B/32 at 25,600 rows measured 3 % slower on it)
     const int bn = wide ? 256 : 128;
     p.tiles_n = (int)((N + bn - 1) / bn);

@@ -40,6 +40,31 @@ def test_gemm_f16(M, N, K, res, act):
     assert relerr(out.double().cpu(), v.cpu()) < 1.5e-3           # 2^-11 output rounding + fp32 accumulation
 
 
+@pytest.mark.parametrize("M,N,K,res,act", [(16384 + 77, 512, 256, True, 2), (32768, 256, 128, False, 0), (20000, 1024, 4096, True, 0),
+                                           (577 * 64, 3072, 1024, False, 2), (16384, 768, 3072, True, 0)])
+def test_gemm_f16_deep_pipelined_kernel(M, N, K, res, act, monkeypatch):
+    """the 256 x 256 x 64 eight-phase kernel (N % 256 == 0, K % 128 == 0, M >= 16384) against fp64 ELEMENT-wise -- a staging
+    race would show as a few wrong tiles, which a norm-wise error hides -- over repeated launches, and against the
+    two-barrier kernel (DBMM_F16_8PH=0) on the same operands"""
+    g = torch.Generator(device=DEV); g.manual_seed(M + N + K)
+    a = torch.randn((M, K), device=DEV, generator=g).half(); w = (torch.randn((N, K), device=DEV, generator=g) * K ** -0.5).half()
+    b = torch.randn((N,), device=DEV, generator=g); r = torch.randn((M, N), device=DEV, generator=g).half() if res else None
+    rows = torch.cat([torch.arange(0, 600, device=DEV), torch.randint(0, M, (3000,), device=DEV, generator=g), torch.arange(M - 300, M, device=DEV)])
+    v = a[rows].double() @ w.double().t() + b.double()
+    v = {0: v, 1: torch.relu(v), 2: v * torch.sigmoid(1.702 * v)}[act]
+    if res:
+        v = v + r[rows].double()
+    monkeypatch.setenv("DBMM_F16_8PH", "0")
+    base = ops.gemm_f16(a, w, b, residual=r, act=act)
+    monkeypatch.setenv("DBMM_F16_8PH", "1")
+    for _ in range(4):
+        out = ops.gemm_f16(a, w, b, residual=r, act=act)
+        assert torch.allclose(out[rows].double(), v, rtol=2e-3, atol=2e-3)
+        # same products, fp32 accumulation in another order, one fp16 rounding: at most an ulp or two apart, everywhere
+        assert (out.float() - base.float()).abs().max().item() <= 4e-3 * max(1.0, base.float().abs().max().item())
+        assert (out != base).float().mean().item() < 0.05
+
+
 def test_gemm_f16_strided_rows_and_rejects():
     g = torch.Generator(device=DEV); g.manual_seed(5)
     t = torch.randn((9, 7, 64), device=DEV, generator=g).half(); w = torch.randn((32, 64), device=DEV, generator=g).half()
