@@ -249,10 +249,17 @@ __global__ __launch_bounds__(256, MINB) void gemm_f16_kernel(const GemmHP p) {
 //     their LDS reads, DMA issue and waits, and vice versa -- each SIMD's two waves alternate on the matrix pipe.
 //   * with one workgroup per CU nothing else hides a tile's first round trip or its epilogue, so the workgroups are
 //     PERSISTENT (one per CU, each walking a contiguous tile range of its XCD) and the next tile's first five half-tiles
-//     are issued BEFORE the current tile's epilogue, whose LDS staging lives beside the ring (160 KB in all).
+//     are issued BEFORE the current tile's epilogue, which needs no LDS: the W half-tiles are the even / odd columns,
+//     so a lane's two accumulator blocks are adjacent columns and every register is one packed dword of a full row segment.
 // Needs N % 256 == 0 and K % 128 == 0 (two K tiles per loop trip).  Epilogue as in gemm_f16_kernel.
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int PH_HALF = 128 * 64 * 2;                              // bytes of a half-tile
+#ifndef GF16_DEPHASE
+#define GF16_DEPHASE 0
+#endif
+#ifndef GF16_ABL            // timing ablations (results wrong): 1 no C stores, 2 no epilogue arithmetic either, 8 no main loop
+#define GF16_ABL 0
+#endif
 
 __device__ __forceinline__ void glds16(__amdgpu_buffer_rsrc_t r, unsigned char* lds_dst, unsigned voff, unsigned soff) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -262,11 +269,9 @@ __device__ __forceinline__ void glds16(__amdgpu_buffer_rsrc_t r, unsigned char* 
 #endif
 }
 
+template <int ACT, int RES>                                          // epilogue specialised: a run-time `act` costs 22 VALU per output pair
 __global__ __launch_bounds__(512, 1) void gemm_f16_8ph_kernel(const GemmHP p) {
-    // [buffer 2][Ah0, Bh0, Bh1, Ah1] = 128 KB, then the epilogue staging.  The staging (8 waves x 32 x 68 floats = 68 KB) starts
-    // at 80 KB: the next tile's first five half-tiles (buffer 0 and Ah0 of buffer 1 = the first 80 KB) land beside it.
-    constexpr int EPI_OFF = 5 * PH_HALF;
-    __shared__ __attribute__((aligned(1024))) unsigned char lds[160 * 1024];
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[8 * PH_HALF];      // [buffer 2][Ah0, Bh0, Bh1, Ah1] = 128 KB
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6), wr = wid >> 2, wc = wid & 3;
     const int fr = lane & 31, fh = lane >> 5;
@@ -280,7 +285,9 @@ __global__ __launch_bounds__(512, 1) void gemm_f16_8ph_kernel(const GemmHP p) {
     int m0 = 0, n0 = 0;
     // stager: thread -> LDS chunk (tid + 512 i) of a half-tile = local row (tid >> 3) + 64 i, slot tid & 7; it fetches
     // source chunk slot ^ swz(row).  Half-tile kind k = 0..3 (Ah0, Bh0, Bh1, Ah1) -> operand rows:
-    //   A half h: tile row (lr >> 6) * 128 + h * 64 + (lr & 63);   W half h: tile column (lr >> 5) * 64 + h * 32 + (lr & 31)
+    //   A half h: tile row (lr >> 6) * 128 + h * 64 + (lr & 63);   W half h: tile column (lr >> 5) * 64 + 2 * (lr & 31) + h
+    //   (W half 0 = the EVEN columns of every wave column's 64, half 1 = the odd ones: accumulator blocks j = 0 / 1 of a lane
+    //    are then two ADJACENT output columns -- one packed dword in the epilogue)
     unsigned voff[4][2];
     auto set_tile = [&](int tile) {
         m0 = (tile / p.tiles_n) * 256; n0 = (tile % p.tiles_n) * 256;
@@ -291,7 +298,7 @@ __global__ __launch_bounds__(512, 1) void gemm_f16_8ph_kernel(const GemmHP p) {
             const int lr = (tid >> 3) + 64 * i, c = (tid & 7) ^ ((lr >> 1) & 7);
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                const int ra = (lr >> 6) * 128 + h * 64 + (lr & 63), rw = (lr >> 5) * 64 + h * 32 + (lr & 31);
+                const int ra = (lr >> 6) * 128 + h * 64 + (lr & 63), rw = (lr >> 5) * 64 + 2 * (lr & 31) + h;
                 voff[h ? 3 : 0][i] = m0 + ra < p.M ? (unsigned)ra * (unsigned)(p.lda * 2) + c * 16u : OOR;
                 voff[h ? 2 : 1][i] = (unsigned)rw * (unsigned)(p.ldw * 2) + c * 16u;
             }
@@ -371,12 +378,19 @@ __global__ __launch_bounds__(512, 1) void gemm_f16_8ph_kernel(const GemmHP p) {
 #pragma unroll
         for (int q = 0; q < 5; ++q) stage(q & 3, (q >> 2) & 1, q >> 2);
     };
-    constexpr int WTN = 64, G_LROW = WTN + 4, LPR = WTN / 8, RPI = 64 / LPR, NIT = 32 / RPI;
-    float* Ls = (float*)(lds + EPI_OFF) + wid * (32 * G_LROW);
-    const int ec = (lane % LPR) * 8, er = lane / LPR;
     const int wm0 = wr * 128, wn0 = wc * 64;
 
     int tile = t_lo + slot_in_xcd;
+    // De-phase the workgroups.  Every tile takes the same time, so persistent workgroups that start together reach their
+    // epilogues together: 256 x (128 KB of C + residual + the next A tile) hit HBM in one burst while it idles during
+    // the main loops -- measured as a FIXED 14-16 us per tile whatever K (K sweep, tools/bench_gemm_f16.py).  The groups
+    // of workgroups that share an A tile (tiles_n consecutive slots of an XCD; kept in step for the L2) start spread
+    // over one tile time instead.
+    if (GF16_DEPHASE && (t_hi - t_lo) >= 3 * wg_per_xcd) {
+        const int per = (wg_per_xcd + p.tiles_n - 1) / p.tiles_n, grp = (slot_in_xcd / p.tiles_n) + per * xcd, ngrp = per * 8;
+        const int units = (int)((long long)grp * nT * 1400 / ngrp) >> 10;       // ~1400 cycles per K tile, s_sleep 16 = 1024 cycles
+        for (int u = 0; u < units; ++u) __builtin_amdgcn_s_sleep(16);
+    }
     if (tile < t_hi) { set_tile(tile); prologue(); }
     for (; tile < t_hi; tile += wg_per_xcd) {
 #pragma unroll
@@ -392,7 +406,7 @@ __global__ __launch_bounds__(512, 1) void gemm_f16_8ph_kernel(const GemmHP p) {
     // the vmcnt(6) arithmetic of the phases wants three half-tiles in flight: re-issue nothing, the first three waits are
     // simply satisfied at once
     if (wr == 1) __builtin_amdgcn_s_barrier();                        // the second wave row runs one barrier behind
-    for (int t2 = 0; t2 < nT; t2 += 2) {
+    for (int t2 = 0; t2 < ((GF16_ABL & 8) ? 2 : nT); t2 += 2) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) phase(j, t2);
     }
@@ -402,33 +416,45 @@ __global__ __launch_bounds__(512, 1) void gemm_f16_8ph_kernel(const GemmHP p) {
     const int em0 = m0, en0 = n0;
     if (tile + wg_per_xcd < t_hi) { set_tile(tile + wg_per_xcd); prologue(); }   // in flight during the epilogue below
 
-    // epilogue: each wave transposes its 128 x 64 block 32 rows at a time through its own LDS slice (see gemm_f16_kernel)
-    const int n = en0 + wn0 + ec;
-    f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;
-    if (p.bias) { b0 = *(const f32x4*)(p.bias + n); b1 = *(const f32x4*)(p.bias + n + 4); }
+    // epilogue straight from the accumulators, no LDS: lane (fr, fh) holds output columns 2 fr and 2 fr + 1 (blocks j = 0 / 1,
+    // see the stager's column map) of rows 32 i + (r & 3) + 8 (r >> 2) + 4 fh: one packed dword per register, 32 lanes = one
+    // whole 128-B row segment, two rows per wave instruction -- the full-rate access shape, residual loads likewise.
+    // (Through the LDS transpose of gemm_f16_kernel the 68 KB of fp32 staging writes cost as much as the MFMAs of two K
+    //  tiles; with swapped MFMA operands -- a lane owning 4 columns of ITS row, 8-B accesses to 32 different lines per
+    //  instruction -- the vector-memory path made it slower still: 848 -> 663 TF on the out-projection shape.)
+    {
+        const int n = en0 + wn0 + 2 * fr;
+        float bn0 = 0.f, bn1 = 0.f;
+        if (p.bias) { bn0 = p.bias[n]; bn1 = p.bias[n + 1]; }
+        // descriptors rebased to the wave's first row: the extent ends with the last valid row, so rows past M are dropped
+        // by the hardware (no branches); lane offset = its column pair + its half's 4-row step, the row of a register is a
+        // wave-uniform scalar offset
+        const int mw = em0 + wm0;
+        const long long rows_left = (long long)p.M - mw;
+        const __amdgpu_buffer_rsrc_t rsC = desc(p.c, rows_left > 0 ? ((rows_left - 1) * p.ldc + p.N) * 2 + (long long)mw * p.ldc * 2 : 0, (long long)mw * p.ldc * 2);
+        const __amdgpu_buffer_rsrc_t rsR = p.res ? desc(p.res, rows_left > 0 ? ((rows_left - 1) * p.ldr + p.N) * 2 + (long long)mw * p.ldr * 2 : 0, (long long)mw * p.ldr * 2)
+                                                 : __builtin_amdgcn_make_buffer_rsrc((void*)p.c, 0, 0, 0x00020000);
+        const unsigned vc = (unsigned)((4 * fh * p.ldc + n) * 2), vr = (unsigned)((4 * fh * p.ldr + n) * 2);
+        // all 64 residual loads in flight together (the fragment registers are dead here): one round trip, not four
+        unsigned rvv[RES ? 4 : 1][16];
+        if constexpr (RES) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) Ls[((r & 3) + 8 * (r >> 2) + 4 * fh) * G_LROW + j * 32 + fr] = acc[i][j][r];
-        u32x4 rv[NIT];
-#pragma unroll
-        for (int t = 0; t < NIT; ++t) {
-            const int m = em0 + wm0 + 32 * i + er + RPI * t;
-            rv[t] = (u32x4){0u, 0u, 0u, 0u};
-            if (p.res && m < p.M) rv[t] = *(const u32x4*)(p.res + (long long)m * p.ldr + n);
+                for (int r = 0; r < 16; ++r)
+                    rvv[i][r] = __builtin_amdgcn_raw_buffer_load_b32(rsR, vr, (unsigned)((32 * i + (r & 3) + 8 * (r >> 2)) * p.ldr * 2), 0);
         }
 #pragma unroll
-        for (int t = 0; t < NIT; ++t) {
-            const int row = er + RPI * t, m = em0 + wm0 + 32 * i + row;
-            const f32x4 v0 = *(const f32x4*)(Ls + row * G_LROW + ec) + b0, v1 = *(const f32x4*)(Ls + row * G_LROW + ec + 4) + b1;
-            const f16x8 rh = __builtin_bit_cast(f16x8, rv[t]);
-            float o[8];
+        for (int i = 0; i < 4; ++i) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) { o[q] = act_f(v0[q], p.act) + (float)rh[q]; o[4 + q] = act_f(v1[q], p.act) + (float)rh[4 + q]; }
-            if (m < p.M)
-                *(u32x4*)(p.c + (long long)m * p.ldc + n) = (u32x4){pack2(o[0], o[1]), pack2(o[2], o[3]), pack2(o[4], o[5]), pack2(o[6], o[7])};
+            for (int r = 0; r < 16; ++r) {
+                const f16x2 rh = __builtin_bit_cast(f16x2, RES ? rvv[i][r] : 0u);
+                float o0 = act_f(acc[i][0][r] + bn0, ACT), o1 = act_f(acc[i][1][r] + bn1, ACT);
+                if (RES) { o0 += (float)rh[0]; o1 += (float)rh[1]; }
+                if (GF16_ABL & 2) { asm volatile("" ::"v"(acc[i][0][r]), "v"(acc[i][1][r]), "v"(rh)); continue; }
+                if (GF16_ABL & 1) { asm volatile("" ::"v"(pack2(o0, o1))); continue; }
+                __builtin_amdgcn_raw_buffer_store_b32(pack2(o0, o1), rsC, vc, (unsigned)((32 * i + (r & 3) + 8 * (r >> 2)) * p.ldc * 2), 0);
+            }
         }
     }
     }
@@ -773,7 +799,11 @@ extern "C" int dbmm_gemm_f16(const void* a, int64_t lda, const void* w, int64_t 
             p.tiles_n = (int)(N / 256);
             p.n_tiles = (int)((M + 255) / 256) * p.tiles_n;
             const int grid = p.n_tiles < 256 ? p.n_tiles : 256;   // persistent: one workgroup per CU
-            hipLaunchKernelGGL(gemm_f16_8ph_kernel, dim3(grid), dim3(512), 0, (hipStream_t)stream, p);
+            hipStream_t s8 = (hipStream_t)stream;
+#define DBMM_8PH(A, R) hipLaunchKernelGGL((gemm_f16_8ph_kernel<A, R>), dim3(grid), dim3(512), 0, s8, p)
+            if (residual) { if (act == 0) DBMM_8PH(0, 1); else if (act == 1) DBMM_8PH(1, 1); else DBMM_8PH(2, 1); }
+            else { if (act == 0) DBMM_8PH(0, 0); else if (act == 1) DBMM_8PH(1, 0); else DBMM_8PH(2, 0); }
+#undef DBMM_8PH
             DBMM_CHECK_LAUNCH();
             return DBMM_OK;
         }
