@@ -86,7 +86,14 @@ struct IgemmP {
     const float* oscale;                // optional per-output-channel scale applied to the accumulator (unfolded BN)
     const float* a_absmax;              // fp16-pair path: device scalar >= max|A| (null: path not in use)
     float* absmax_out;                  // optional device scalar: atomic max of |C| over the written outputs
+    int epi_direct;                     // epilogue straight from the accumulator layout (igemm_epilogue.inc); DBMM_IGEMM_EPI_DIRECT=0: staged
 };
+
+// read on every call: tests compare the two epilogues in one process
+inline int epi_direct_env() {
+    const char* e = getenv("DBMM_IGEMM_EPI_DIRECT");
+    return e ? atoi(e) : 1;
+}
 
 // fp16-pair path: A is scaled by 2^s so that max|A| * 2^s lies in [2^13, 2^14) (fp16 tops out at
 // 65504; the fp32 accumulator is rescaled by 2^-(s + w_exp) in the epilogue -- powers of two,
@@ -518,6 +525,7 @@ __device__ __forceinline__ void igemm_tile(const IgemmP& p, float* lds, int tile
     }
     const float acc_scale = igemm_acc_scale(p);   // 1 unless this is the fix-up of an fp16-pair launch
     {
+constexpr bool EPI_DIRECT = false;        // fp32-input kernels: small register budgets, small share of the time
 #include "igemm_epilogue.inc"
     }
 }
@@ -606,7 +614,7 @@ struct GeoX3 {   // LDS floats for the split path (NP / NW 16-bit planes of A / 
 template <int BK>
 __device__ __forceinline__ int x3_swz(int row) { return BK == 16 ? ((row >> 3) & 1) : ((row >> 2) & 3); }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int AMODE, int NP, int NW, int BK, int TWO = 0>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int AMODE, int NP, int NW, int BK, int TWO = 0, int EPID = 1>
 __device__ __forceinline__ void igemm_tile_x3(const IgemmP& p, float* lds, int tile, int kb, int ke, float* partial) {
     static_assert(BK == 16 || BK == 32, "BK");
     static_assert((NP == 3 && NW == 3) || (NP == 2 && (NW == 2 || NW == 1)), "planes");
@@ -923,6 +931,7 @@ __device__ __forceinline__ void igemm_tile_x3(const IgemmP& p, float* lds, int t
     }
     const float acc_scale = NP == 2 ? igemm_acc_scale(p) : 1.f;
     {
+constexpr bool EPI_DIRECT = NP == 2 && EPID && TM * TN <= 4;   // fp16-pair kernels with <= 64 accumulator registers, not the stream-K builds (register budget)
 #include "igemm_epilogue.inc"
     }
 }
@@ -934,7 +943,7 @@ __global__ __launch_bounds__(256, MINB) void igemm_x3_kernel(const IgemmP p) {
     __shared__ __attribute__((aligned(16))) float lds[LDSF];
     const int nk = p.K / BK + (TWO ? p.K2 / BK : 0);
     if constexpr (!SK) {
-        igemm_tile_x3<BM, BN, WAVES_M, WAVES_N, AMODE, NP, NW, BK, TWO>(p, lds, xcd_remap(blockIdx.x, p.n_tiles), 0, nk, nullptr);
+        igemm_tile_x3<BM, BN, WAVES_M, WAVES_N, AMODE, NP, NW, BK, TWO, 1>(p, lds, xcd_remap(blockIdx.x, p.n_tiles), 0, nk, nullptr);
     } else {
         const long long U = (long long)p.n_tiles * nk;
         long long u = U * blockIdx.x / p.sk_blocks;
@@ -945,7 +954,7 @@ __global__ __launch_bounds__(256, MINB) void igemm_x3_kernel(const IgemmP p) {
             float* partial = (kb == 0 && ke == nk)
                                  ? nullptr
                                  : p.sk_ws + ((size_t)blockIdx.x * 2 + (seg ? 1 : 0)) * (size_t)(BM * BN);
-            igemm_tile_x3<BM, BN, WAVES_M, WAVES_N, AMODE, NP, NW, BK, TWO>(p, lds, tile, kb, ke, partial);
+            igemm_tile_x3<BM, BN, WAVES_M, WAVES_N, AMODE, NP, NW, BK, TWO, 0>(p, lds, tile, kb, ke, partial);
             u += ke - kb;
         }
     }
@@ -981,7 +990,7 @@ struct GeoHalo {
 // group, held as two strips of 66 pixels (left halo, 32 x (dx 0, dx 1), right halo): fragment row (w, dy, dx) of tap kw
 // reads LDS row dy * 72 + 2 w + dx + kw.  Windows that wrap to the next pooled row / image load from wherever they
 // live; a strip neighbour that is not the image neighbour is exactly a border tap and masked like every border tap.
-template <int BN, int WAVES_M, int WAVES_N, int POOL = 0>
+template <int BN, int WAVES_M, int WAVES_N, int POOL = 0, int EPID = 1>
 __device__ __forceinline__ void igemm_tile_halo(const IgemmP& p, float* lds, int tile, int ub, int ue, float* partial) {
     constexpr int BM = 128, BK = 32;
     using G = Geo<BM, BN, WAVES_M, WAVES_N, BK>;
@@ -1227,6 +1236,7 @@ __device__ __forceinline__ void igemm_tile_halo(const IgemmP& p, float* lds, int
     }
     const float acc_scale = igemm_acc_scale(p);
     {
+constexpr bool EPI_DIRECT = EPID && TM * TN <= 4;
 #include "igemm_epilogue.inc"
     }
 }
@@ -1238,7 +1248,7 @@ __global__ __launch_bounds__(256, MINB) void igemm_halo_kernel(const IgemmP p) {
     __shared__ __attribute__((aligned(16))) float lds[LDSF];
     const int nu = (p.K / 32 + 5) / 6;                    // units of 6 K steps per tile (stream-K: K % 192 == 0)
     if constexpr (!SK) {
-        igemm_tile_halo<BN, WAVES_M, WAVES_N, POOL>(p, lds, xcd_remap(blockIdx.x, p.n_tiles), 0, nu, nullptr);
+        igemm_tile_halo<BN, WAVES_M, WAVES_N, POOL, 1>(p, lds, xcd_remap(blockIdx.x, p.n_tiles), 0, nu, nullptr);
     } else {
         const long long U = (long long)p.n_tiles * nu;
         long long u = U * blockIdx.x / p.sk_blocks;
@@ -1249,7 +1259,7 @@ __global__ __launch_bounds__(256, MINB) void igemm_halo_kernel(const IgemmP p) {
             float* partial = (ub == 0 && ue == nu)
                                  ? nullptr
                                  : p.sk_ws + ((size_t)blockIdx.x * 2 + (seg ? 1 : 0)) * (size_t)(128 * BN);
-            igemm_tile_halo<BN, WAVES_M, WAVES_N, POOL>(p, lds, tile, ub, ue, partial);
+            igemm_tile_halo<BN, WAVES_M, WAVES_N, POOL, 0>(p, lds, tile, ub, ue, partial);
             u += ue - ub;
         }
     }
@@ -1651,6 +1661,7 @@ int gemm_impl(const float* a, int64_t lda, int trans_a, const float* w, int64_t 
     if (!trans_w && (K & 3)) return DBMM_E_SHAPE;
     if (trans_w && (N & 3)) return DBMM_E_SHAPE;
     IgemmP p{};
+    p.epi_direct = epi_direct_env();
     p.a = a; p.w = w; p.bias = bias; p.res = residual; p.c = c;
     p.lda = lda; p.ldw = ldw; p.ldr = ldr; p.ldc = ldc;
     p.M = (int)M; p.N = (int)N; p.K = (int)K; p.act = act; p.alpha = alpha;
@@ -1698,6 +1709,7 @@ int conv_impl(const float* x, const float* w, const float* bias, const float* re
     const int64_t M = B * Ho * Wo, K = KH * KW * Cin;
     if (M > INT32_MAX || K > INT32_MAX) return DBMM_E_SHAPE;
     IgemmP p{};
+    p.epi_direct = epi_direct_env();
     p.a = x; p.w = w; p.bias = bias; p.res = residual; p.c = y;
     p.lda = Cin; p.ldw = K; p.ldr = Cout; p.ldc = Cout;
     p.M = (int)M; p.N = (int)Cout; p.K = (int)K; p.act = act; p.alpha = 1.f;
@@ -1796,6 +1808,7 @@ extern "C" int dbmm_gemm_batched(const float* a, int64_t lda, int64_t stride_a, 
     if ((!trans_a && (K & 3)) || (trans_a && (M & 3)) || (!trans_w && (K & 3)) || (trans_w && (N & 3)))
         return DBMM_E_SHAPE;
     IgemmP p{};
+    p.epi_direct = epi_direct_env();
     p.a = a; p.w = w; p.bias = bias; p.res = nullptr; p.c = c;
     p.lda = lda; p.ldw = ldw; p.ldr = 0; p.ldc = ldc;
     p.sa = stride_a; p.sw = stride_w; p.sbias = stride_bias; p.sc = stride_c;
@@ -1912,6 +1925,7 @@ extern "C" int dbmm_gemm_dual_bn_act_x2(const float* a, int64_t lda, const float
     if (wb >= lim || wb2 >= lim) return DBMM_E_UNSUPPORTED;      // (activations may exceed 2 GiB: tiles rebase, a_desc)
     constexpr int BM = 128, BN = 128, MB = 3;
     IgemmP p{};
+    p.epi_direct = epi_direct_env();
     p.a = a; p.lda = lda; p.a_bytes = (unsigned)(ab < lim ? ab : lim); p.a_total = ab; p.a_absmax = a_absmax;
     p.wh = (const unsigned short*)w_plane_f16; p.wh_bytes = (unsigned)wb; p.ldw = ldw; p.w_exp = w_exp; p.nw = 1;
     p.a2 = a2; p.lda2 = lda2; p.a2_bytes = (unsigned)(ab2 < lim ? ab2 : lim); p.a2_total = ab2; p.a2_absmax = a2_absmax; p.K2 = (int)K2;

@@ -596,6 +596,45 @@ def test_conv_pool2_unsupported_shapes_compose():
     assert relerr(out.cpu(), ref) < 2e-5
 
 
+@pytest.mark.parametrize("M,N,K,res,act", [(25637, 256, 256, True, 1), (25605, 200, 64, True, 0), (25600, 768, 768, False, 2), (128 * 300 + 5, 1024, 256, True, 1)])
+def test_direct_epilogue_equals_staged_epilogue(M, N, K, res, act, monkeypatch):
+    """the fp16-pair GEMM's two epilogues -- straight from the accumulator layout (default) and staged through LDS
+    (DBMM_IGEMM_EPI_DIRECT=0) -- perform the same arithmetic per element: outputs and the output maximum are bit-identical;
+    ragged M (rows past M fall off the descriptor), N not a multiple of 32 (columns past N are masked lanes)"""
+    a = rnd(1, "a", (M, K), 2.0).to(DEV); w = rnd(2, "w", (N, K), K ** -0.5).half().float().to(DEV); b = rnd(3, "b", (N,), 0.1).to(DEV)
+    r = rnd(4, "r", (M, N)).to(DEV) if res else None
+    ph, we, n = ops.split_planes_f16(w, allow_single=True)
+    outs = []
+    for knob in ("1", "0"):
+        monkeypatch.setenv("DBMM_IGEMM_EPI_DIRECT", knob)
+        am = torch.zeros(1, device=DEV)
+        y = ops.gemm(a, w, b, r, act=act, w_planes_f16=ph, w_exp=we, a_absmax=a.abs().max().reshape(1), c_absmax=am)
+        assert ops._last_igemm_tag().startswith("igemm_x3_kernel<"), ops._last_igemm_tag()
+        assert am.item() == y.abs().max().item()
+        outs.append(y)
+    assert torch.equal(outs[0], outs[1])
+    if not res:
+        ref = a.double() @ w.double().t() + b.double()
+        ref = {0: ref, 1: torch.relu(ref), 2: ref * torch.sigmoid(1.702 * ref)}[act]
+        assert relerr(outs[0].double().cpu(), ref.cpu()) < 5e-6
+    # the same for a conv with BatchNorm scale and residual: 1x1 (GEMM kernel) and 3x3 (halo kernel), ragged pixel count
+    B, H, C = 5, 14, 64
+    x = rnd(6, "x", (B, H, H, C)).to(DEV); sc = (0.5 + synth.uniform(7, "sc", (N,))).to(DEV)
+    for k in (1, 3):
+        wk = rnd(8, "wk", (N, C, k, k), (C * k * k) ** -0.5).half().float().to(DEV)
+        wp, wl = ops.pack_conv_weight(wk, chunk_major=32)
+        pk, wek, _ = ops.split_planes_f16(wp, allow_single=True)
+        rr = rnd(9, "rr", (B, H, H, N)).to(DEV)
+        ys = []
+        for knob in ("1", "0"):
+            monkeypatch.setenv("DBMM_IGEMM_EPI_DIRECT", knob)
+            am = torch.zeros(1, device=DEV)
+            ys.append(ops.conv_bn_act(x, wp, b, rr, k, k, 1, k // 2, ops.ACT_RELU, wl, w_planes_f16=pk, w_exp=wek,
+                                      x_absmax=x.abs().max().reshape(1), y_absmax=am, out_scale=sc))
+            assert am.item() == ys[-1].abs().max().item()
+        assert torch.equal(ys[0], ys[1])
+
+
 @pytest.mark.parametrize("M,N,K,single,res,act", [(25600, 768, 768, True, True, 0), (25600, 2304, 768, True, False, 0),
                                                   (25600, 3072, 768, True, False, 2), (1000, 256, 64, True, True, 0),
                                                   (4096, 512, 2048, False, True, 0), (616, 192, 96, False, False, 2)])
