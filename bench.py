@@ -57,6 +57,8 @@ def kernel_products(tag):
     product per product, priced against the full 2500 TFLOP/s)."""
     if tag.startswith(("gemm_f16_kernel", "mha_f16_kernel")):
         return 0
+    if tag.startswith("gemm_pair_8ph_kernel"):
+        return 2                                                  # fp16 pair x one exact weight plane
     if tag.startswith("mha_pair_kernel"):
         return 3                                                  # activation pair x activation pair
     if tag.startswith("mha_mfma_kernel"):

@@ -92,6 +92,7 @@ _SIGS = {
                                        _L, _L, _L, _L, _L, _L, _P],
     "dbmm_gemm_bias_act_x3": [_P, _L, _P, _P, _L, _P, _P, _L, _P, _L, _L, _L, _L, _F, _I, _P, _Z, _P],
     "dbmm_gemm_batched": [_P, _L, _L, _I, _P, _L, _L, _I, _P, _L, _P, _L, _L, _L, _L, _L, _L, _F, _I, _P],
+    "dbmm_gemm_pair_8ph": [_P, _L, _P, _P, _I, _L, _P, _P, _P, _L, _P, _L, _P, _L, _L, _L, _F, _I, _P],
     "dbmm_conv_stem_s2": [_P, _P, _P, _P, _P, _L, _L, _L, _L, _P],
     "dbmm_avgpool2d": [_P, _P, _L, _L, _L, _L, _L, _P],
     "dbmm_workspace_bytes_attnpool": [_L, _L, _L],

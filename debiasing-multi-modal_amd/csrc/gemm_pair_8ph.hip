@@ -1,0 +1,328 @@
+// Parity-mode GEMM of the transformer towers on the deep-pipelined structure of gemm_f16_8ph_kernel (f16_ops.hip):
+//   c = act(alpha * ((a @ w^T) * out_scale + bias) + residual),  a fp32 [M][K],  w exact in ONE fp16 plane (w * 2^w_exp),
+// at fp32 accuracy: a = (hi + lo) * 2^-s, two fp16 MFMA products per fp32 product, fp32 accumulation (the fp16-pair
+// arithmetic of igemm_f32.hip; clip/model.py:171-240 are the GEMMs it serves in the parity mode).
+//
+// What differs from the fp16 kernel: the activations are fp32 in HBM, so LDS-DMA brings them in as fp32 and the split into
+// (hi, lo) happens when a wave READS its fragments -- 16 VALU per 32 x 16 fragment, placed in the "load" half of a phase,
+// i.e. while the other wave group of the SIMD owns the matrix pipe (VALU and MFMA of different waves overlap).  Every
+// wave that shares an A row block repeats that split, so the waves are laid out 4 x 2 (64 x 128 of output each; with
+// 2 x 4 the four waves of a row quadrupled the split and the kernel ran BELOW the two-barrier one: 337 vs 506 TF-eq at
+// K = 4096): two waves per row block = as many split instructions as splitting once on the way into LDS.  To keep two
+// buffers of four half-tiles inside LDS a K tile is 32 deep: A half-tile 128 rows x 32 k fp32 = 16 KB (2 DMA instructions
+// per thread), W half-tile 128 rows x 32 k fp16 = 8 KB (1), 96 KB in all.  A phase is one 32 x 64 quadrant x 32 k =
+// 2 column blocks x 2 k-steps x 2 products = 8 MFMAs, as in the fp16 kernel, and the stage / wait / read distances are the same
+// (stage five phases ahead, retire three stages back, read one phase after the wait); only the vmcnt constants differ
+// because the stages issue 2 / 1 / 1 / 2 instructions: outstanding after the wait = the last three stages = 5 / 4 / 4 / 5.
+// Persistent workgroups, next tile's first five half-tiles issued before the epilogue, epilogue straight from the
+// accumulator layout (one register = two 128-B fp32 row segments), branch-free buffer accesses, activation / residual
+// compile-time.  Needs N % 256 == 0, K % 64 == 0.
+#include <stdlib.h>
+#include "common.h"
+
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr unsigned OOR = 0x80000000u;
+constexpr long long EXT_LIM = 0x7FFFFFF0LL;
+constexpr int A_HALF = 128 * 32 * 4, W_HALF = 128 * 32 * 2;        // bytes of the half-tiles
+constexpr int BUF = 2 * A_HALF + 2 * W_HALF;                       // one buffer: Ah0, Bh0, Bh1, Ah1
+constexpr int OFF_AH0 = 0, OFF_BH0 = A_HALF, OFF_BH1 = A_HALF + W_HALF, OFF_AH1 = A_HALF + 2 * W_HALF;
+
+struct PairP {
+    const float* a; const float* a_absmax; const unsigned short* w; const float* oscale; const float* bias; const float* res;
+    float* c; float* c_absmax;
+    long long lda, ldw, ldr, ldc, a_total, w_total;
+    int M, N, K, w_exp, tiles_n, n_tiles;
+    float alpha;
+};
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t desc(const void* base, long long total, long long shift) {
+    long long ext = total - shift;
+    ext = ext < 0 ? 0 : (ext > EXT_LIM ? EXT_LIM : ext);
+    return __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)base + shift), 0, (int)ext, 0x00020000);
+}
+__device__ __forceinline__ void glds16(__amdgpu_buffer_rsrc_t r, unsigned char* lds_dst, unsigned voff, unsigned soff) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_dst, 16, voff, soff, 0, 0);
+#else
+    (void)r; (void)lds_dst; (void)voff; (void)soff;
+#endif
+}
+__device__ __forceinline__ int scale_exp(float amax) {      // s with amax * 2^s in [2^13, 2^14)
+    const unsigned b = __float_as_uint(amax) & 0x7fffffffu;
+    int s = b ? 13 - ((int)(b >> 23) - 127) : 0;
+    return s < -60 ? -60 : (s > 60 ? 60 : s);
+}
+__device__ __forceinline__ float pow2f(int e) { return __uint_as_float((unsigned)(e + 127) << 23); }
+__device__ __forceinline__ void split2h_pair(float x0, float x1, float sc, unsigned& hi, unsigned& lo) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(hi) : "v"(x0), "v"(sc));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(hi) : "v"(x1), "v"(sc));
+    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(lo) : "v"(x0), "v"(sc), "v"(hi));
+    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(lo) : "v"(x1), "v"(sc), "v"(hi));
+#else
+    (void)x0; (void)x1; (void)sc; hi = lo = 0;
+#endif
+}
+__device__ __forceinline__ f16x8 frag(const unsigned (&v)[4]) { return __builtin_bit_cast(f16x8, (u32x4){v[0], v[1], v[2], v[3]}); }
+
+template <int ACT, int RES>
+__global__ __launch_bounds__(512, 1) void gemm_pair_8ph_kernel(const PairP p) {
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * BUF];          // 96 KB
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6), wr = wid >> 1, wc = wid & 1, grp = wid >> 2;   // 4 x 2 waves, two groups of four
+    const int fr = lane & 31, fh = lane >> 5;
+    // this workgroup's tiles: its XCD's contiguous range (xcd_remap's split), walked with the stride of the XCD's workgroups
+    const int nwg = gridDim.x, xcd = blockIdx.x & 7, slot_in_xcd = blockIdx.x >> 3, wg_per_xcd = (nwg - xcd + 7) >> 3;
+    const int tq = p.n_tiles >> 3, trm = p.n_tiles & 7;
+    const int t_lo = xcd < trm ? xcd * (tq + 1) : trm * (tq + 1) + (xcd - trm) * tq, t_hi = t_lo + tq + (xcd < trm ? 1 : 0);
+    const __amdgpu_buffer_rsrc_t rsA0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.a, 0, 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsW0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, 0, 0x00020000);
+    __amdgpu_buffer_rsrc_t rsA = rsA0, rsW = rsW0;
+    int m0 = 0, n0 = 0;
+    // stager.  A half-tile: thread -> 16-B chunk (tid + 512 i) = local row (tid >> 3) + 64 i, slot tid & 7 of a 128-B row; it
+    // fetches source chunk slot ^ ((row >> 1) & 7).  W half-tile: chunk tid = local row tid >> 2, slot tid & 3 of a 64-B row,
+    // source chunk slot ^ ((row >> 2) & 3).  Operand rows of a local row lr:
+    //   A half h: tile row (lr >> 5) * 64 + h * 32 + (lr & 31);   W half h: tile column (lr >> 6) * 128 + h * 64 + (lr & 63)
+    unsigned voffA[2][2], voffW[2];
+    auto set_tile = [&](int tile) {
+        m0 = (tile / p.tiles_n) * 256; n0 = (tile % p.tiles_n) * 256;
+        rsA = desc(p.a, p.a_total, (long long)m0 * p.lda * 4);
+        rsW = desc(p.w, p.w_total, (long long)n0 * p.ldw * 2);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int lr = (tid >> 3) + 64 * i, c = (tid & 7) ^ ((lr >> 1) & 7);
+                const int ra = (lr >> 5) * 64 + h * 32 + (lr & 31);
+                voffA[h][i] = m0 + ra < p.M ? (unsigned)ra * (unsigned)(p.lda * 4) + c * 16u : OOR;
+            }
+            const int lr = tid >> 2, c = (tid & 3) ^ ((lr >> 2) & 3);
+            voffW[h] = (unsigned)((lr >> 6) * 128 + h * 64 + (lr & 63)) * (unsigned)(p.ldw * 2) + c * 16u;
+        }
+    };
+    const int nT = p.K / 32;
+    // stage kind k = 0..3 (Ah0, Bh0, Bh1, Ah1) of K tile t into buffer `buf`; tiles past the end go through the zero-extent
+    // descriptors so that every phase issues its fixed number of DMA instructions (the vmcnt constants rely on it)
+    auto stage = [&](int kind, int buf, int t) {
+        const bool valid = t < nT;
+        unsigned char* base = lds + buf * BUF;
+        if (kind == 0 || kind == 3) {
+            const __amdgpu_buffer_rsrc_t rs = valid ? rsA : rsA0;
+            unsigned char* slot = base + (kind == 0 ? OFF_AH0 : OFF_AH1) + wid * 1024;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) glds16(rs, slot + i * 8192, voffA[kind == 3][i], (unsigned)t * 128u);
+        } else {
+            const __amdgpu_buffer_rsrc_t rs = valid ? rsW : rsW0;
+            glds16(rs, base + (kind == 1 ? OFF_BH0 : OFF_BH1) + wid * 1024, voffW[kind == 2], (unsigned)t * 64u);
+        }
+    };
+    // fragment addresses inside a half-tile (bytes).  A: local row wr * 32 + fr, this lane's 8 k values of k-step ks are fp32
+    // chunks 4 ks + 2 fh and + 1 (32 B); W: local rows wc * 64 + cb * 32 + fr (two column blocks), fp16 chunk 2 ks + fh
+    int aoff[2][2], boff[2][2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        const int r = wr * 32 + fr, s = (r >> 1) & 7;
+        aoff[ks][0] = r * 128 + (((4 * ks + 2 * fh) ^ s) << 4);
+        aoff[ks][1] = r * 128 + (((4 * ks + 2 * fh + 1) ^ s) << 4);
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+            const int rw = wc * 64 + cb * 32 + fr;
+            boff[cb][ks] = rw * 64 + (((2 * ks + fh) ^ ((rw >> 2) & 3)) << 4);
+        }
+    }
+    const int s_a = scale_exp(*p.a_absmax);
+    const float a_sc = pow2f(s_a), acc_scale = pow2f(-s_a - p.w_exp);
+    f32x16 acc[2][4];                                                 // [A half (32 rows)][W half * 2 + column block]
+    unsigned fah[2][4], fal[2][4];                                    // [ks]: hi / lo planes of the A fragment
+    u32x4 fb0[2][2], fb1[2][2];                                       // [column block][ks]
+
+    auto read_a = [&](const unsigned char* half) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const f32x4 x0 = *(const f32x4*)(half + aoff[ks][0]), x1 = *(const f32x4*)(half + aoff[ks][1]);
+            split2h_pair(x0[0], x0[1], a_sc, fah[ks][0], fal[ks][0]);
+            split2h_pair(x0[2], x0[3], a_sc, fah[ks][1], fal[ks][1]);
+            split2h_pair(x1[0], x1[1], a_sc, fah[ks][2], fal[ks][2]);
+            split2h_pair(x1[2], x1[3], a_sc, fah[ks][3], fal[ks][3]);
+        }
+    };
+    // one phase: j = phase within the loop trip (static), t2 = first K tile of the trip
+    auto phase = [&](int j, int t2) {
+        const int ph = j & 3, buf = (j >> 2) & 1;
+        const unsigned char* base = lds + buf * BUF;
+        if (ph == 0) {
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) fb0[cb][ks] = *(const u32x4*)(base + OFF_BH0 + boff[cb][ks]);
+            read_a(base + OFF_AH0);
+        } else if (ph == 1) {
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) fb1[cb][ks] = *(const u32x4*)(base + OFF_BH1 + boff[cb][ks]);
+        } else if (ph == 2) {
+            read_a(base + OFF_AH1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            const int q = j + 5;                                      // stage number relative to the trip's first tile
+            stage(q & 3, (q >> 2) & 1, t2 + (q >> 2));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // outstanding after this wait = the last three stages: kinds (j+5, j+4, j+3) & 3 with 2 / 1 / 1 / 2 instructions each
+        if ((j & 3) == 0 || (j & 3) == 3) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+        const int ai = (ph >= 2) ? 1 : 0, bj = (ph == 1 || ph == 2) ? 1 : 0;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb)                            // (lo, w) first, then (hi, w)
+                acc[ai][2 * bj + cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(frag(fal[ks]), __builtin_bit_cast(f16x8, bj ? fb1[cb][ks] : fb0[cb][ks]),
+                                                                              acc[ai][2 * bj + cb], 0, 0, 0);
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb)
+                acc[ai][2 * bj + cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(frag(fah[ks]), __builtin_bit_cast(f16x8, bj ? fb1[cb][ks] : fb0[cb][ks]),
+                                                                              acc[ai][2 * bj + cb], 0, 0, 0);
+        }
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+    };
+    // prologue of a tile: stages 0 .. 4 (K tile 0 complete + Ah0 of K tile 1)
+    auto prologue = [&]() {
+#pragma unroll
+        for (int q = 0; q < 5; ++q) stage(q & 3, (q >> 2) & 1, q >> 2);
+    };
+    const int wm0 = wr * 64, wn0 = wc * 128;
+    float out_amax = 0.f;
+
+    int tile = t_lo + slot_in_xcd;
+    if (tile < t_hi) { set_tile(tile); prologue(); }
+    for (; tile < t_hi; tile += wg_per_xcd) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        // everything this wave has in flight (the prologue issued before the previous tile's epilogue, that epilogue's own
+        // loads and stores) is retired here; the first waits of the phases are then satisfied at once
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (grp == 1) __builtin_amdgcn_s_barrier();                   // the second wave group runs one barrier behind
+        for (int t2 = 0; t2 < nT; t2 += 2) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) phase(j, t2);
+        }
+        if (grp == 0) __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the (zero-extent) tail DMA of this tile
+        __builtin_amdgcn_s_barrier();                                 // every wave is done with the ring
+        const int em0 = m0, en0 = n0;
+        if (tile + wg_per_xcd < t_hi) { set_tile(tile + wg_per_xcd); prologue(); }   // in flight during the epilogue below
+
+        // epilogue straight from the accumulators: lane (fr, fh) holds column 32 j + fr of the wave's 128 (blocks j = 0..3), rows
+        // 32 i + (r & 3) + 8 (r >> 2) + 4 fh: one register = two 128-B row segments per wave instruction.  Rows >= M fall off
+        // the descriptors' extents; residual in units of (row block, column-block pair), the next unit's in flight behind
+        // the current one.
+        const int mw = em0 + wm0;
+        const long long rows_left = (long long)p.M - mw;
+        const __amdgpu_buffer_rsrc_t rsC = desc(p.c, rows_left > 0 ? ((rows_left - 1) * p.ldc + p.N) * 4 + (long long)mw * p.ldc * 4 : 0,
+                                                (long long)mw * p.ldc * 4);
+        const __amdgpu_buffer_rsrc_t rsR = RES ? desc(p.res, rows_left > 0 ? ((rows_left - 1) * p.ldr + p.N) * 4 + (long long)mw * p.ldr * 4 : 0,
+                                                      (long long)mw * p.ldr * 4)
+                                               : rsW0;
+        unsigned vc[4], vr[4];
+        float sv[4], bv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = en0 + wn0 + 32 * j + fr;
+            vc[j] = (unsigned)((4 * fh * p.ldc + n) * 4); vr[j] = (unsigned)((4 * fh * p.ldr + n) * 4);
+            sv[j] = (p.oscale ? p.oscale[n] : 1.f) * acc_scale;
+            bv[j] = p.bias ? p.bias[n] : 0.f;
+        }
+        float rv[RES ? 2 : 1][2][16];
+        auto load_res = [&](int u, int slot) {                        // unit u = (i = u >> 1, column blocks 2 (u & 1), + 1)
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    rv[slot][jj][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                        rsR, vr[2 * (u & 1) + jj], (unsigned)((32 * (u >> 1) + (r & 3) + 8 * (r >> 2)) * p.ldr * 4), 0));
+        };
+        if constexpr (RES) load_res(0, 0);
+        const bool full = rows_left >= 64;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if constexpr (RES) { if (u + 1 < 4) load_res(u + 1, (u + 1) & 1); }
+            const int i = u >> 1;
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const int j = 2 * (u & 1) + jj;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v = (acc[i][j][r] * sv[j] + bv[j]) * p.alpha;
+                    if constexpr (RES) v += rv[u & 1][jj][r];
+                    if (ACT == DBMM_ACT_RELU) v = fmaxf(v, 0.f);
+                    else if (ACT == DBMM_ACT_QUICKGELU) v = v / (1.f + expf(-1.702f * v));
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsC, vc[j],
+                                                          (unsigned)((32 * i + (r & 3) + 8 * (r >> 2)) * p.ldc * 4), 0);
+                    if (full || 32 * i + (r & 3) + 8 * (r >> 2) + 4 * fh < rows_left) out_amax = fmaxf(out_amax, fabsf(v));
+                }
+            }
+        }
+    }
+    if (p.c_absmax) {                                                 // one (filtered) atomic per workgroup
+        out_amax = wave_max(out_amax);
+        __syncthreads();                                              // all DMA drained (loop exit), the ring is free
+        float* red = (float*)lds;
+        if (lane == 0) red[wid] = out_amax;
+        __syncthreads();
+        if (tid == 0) {
+            float m = red[0];
+#pragma unroll
+            for (int i = 1; i < 8; ++i) m = fmaxf(m, red[i]);
+            if (m > *(volatile const float*)p.c_absmax) atomicMax((unsigned*)p.c_absmax, __float_as_uint(m));
+        }
+    }
+}
+
+}  // namespace
+
+// see include/dbmm.h
+extern "C" int dbmm_gemm_pair_8ph(const float* a, int64_t lda, const float* a_absmax, const void* w_plane_f16, int w_exp, int64_t ldw,
+                                  const float* out_scale, const float* bias, const float* residual, int64_t ldr, float* c, int64_t ldc,
+                                  float* c_absmax, int64_t M, int64_t N, int64_t K, float alpha, int act, void* stream) {
+    if (!a || !a_absmax || !w_plane_f16 || !c) return DBMM_E_ARG;
+    if (M <= 0 || N <= 0 || K <= 0 || M > INT32_MAX || N > INT32_MAX || K > INT32_MAX) return DBMM_E_SHAPE;
+    if (act < 0 || act > 2) return DBMM_E_ARG;
+    if ((N % 256) || (K % 64) || w_exp < -40 || w_exp > 40) return DBMM_E_UNSUPPORTED;
+    if ((lda & 3) || (ldw & 7) || !dbmm_aligned16(a) || !dbmm_aligned16(w_plane_f16) || !dbmm_aligned16(c) ||
+        (residual && !dbmm_aligned16(residual)))
+        return DBMM_E_ALIGN;
+    const long long wb = ((N - 1) * ldw + K) * 2;
+    if (wb >= EXT_LIM || 256 * lda * 4 >= EXT_LIM || 256 * ldc * 4 >= EXT_LIM || (residual && 256 * ldr * 4 >= EXT_LIM)) return DBMM_E_UNSUPPORTED;
+    PairP p{};
+    p.a = a; p.a_absmax = a_absmax; p.w = (const unsigned short*)w_plane_f16; p.oscale = out_scale; p.bias = bias; p.res = residual;
+    p.c = c; p.c_absmax = c_absmax;
+    p.lda = lda; p.ldw = ldw; p.ldr = ldr; p.ldc = ldc; p.a_total = ((M - 1) * lda + K) * 4; p.w_total = wb;
+    p.M = (int)M; p.N = (int)N; p.K = (int)K; p.w_exp = w_exp; p.alpha = alpha;
+    p.tiles_n = (int)(N / 256);
+    p.n_tiles = (int)((M + 255) / 256) * p.tiles_n;
+    const int grid = p.n_tiles < 256 ? p.n_tiles : 256;               // persistent: one workgroup per CU
+    hipStream_t s = (hipStream_t)stream;
+#define DBMM_P8(A, R) hipLaunchKernelGGL((gemm_pair_8ph_kernel<A, R>), dim3(grid), dim3(512), 0, s, p)
+    if (residual) { if (act == 0) DBMM_P8(0, 1); else if (act == 1) DBMM_P8(1, 1); else DBMM_P8(2, 1); }
+    else { if (act == 0) DBMM_P8(0, 0); else if (act == 1) DBMM_P8(1, 0); else DBMM_P8(2, 0); }
+#undef DBMM_P8
+    DBMM_CHECK_LAUNCH();
+    return DBMM_OK;
+}

@@ -1673,6 +1673,25 @@ int gemm_impl(const float* a, int64_t lda, int trans_a, const float* w, int64_t 
         // wide GEMMs (transformer projections): a 128 x 256 tile halves the per-FLOP cost of fetching and splitting the fp32
         // activations (the A tile is shared by twice as many output columns); 128 accumulator registers, 2 workgroups per CU.
         // DBMM_IGEMM_BN256=0 disables.
+        // DBMM_GEMM_8PH=1: the deep-pipelined 256 x 256 kernel (gemm_pair_8ph.hip) instead.  Off by default: with the fp32 ->
+        // (hi, lo) split done when the fragments are read it only ties the two-barrier kernel (ViT-L/14@336 shapes, same box:
+        // 427 vs 388 TF-eq at N 3072 K 1024, 460 vs 501 at N 1024 K 4096, 357 vs 414 with a residual at K 1024); it needs
+        // the split done ONCE per tile (convert in place in LDS a phase before the first read) to pull ahead.  Read on every
+        // call: the tests run both.
+        {
+            const char* e8 = getenv("DBMM_GEMM_8PH");
+            if ((e8 ? atoi(e8) : 0) && p.wh && p.nw == 1 && p.a_absmax && (N % 256) == 0 && (K % 64) == 0 && M >= 16384 && (lda & 3) == 0 &&
+                (ldw & 7) == 0 && dbmm_aligned16(c) && (!residual || dbmm_aligned16(residual)) && 256 * (lda > ldc ? lda : ldc) * 4 < 0x7FFFFFF0LL &&
+                p.wh_bytes) {
+                const int rc = dbmm_gemm_pair_8ph(a, lda, sx.a_absmax, p.wh, p.w_exp, ldw, sx.oscale, bias, residual, ldr, c, ldc, sx.absmax_out,
+                                                  M, N, K, alpha, act, stream);
+                if (rc == DBMM_OK) {
+                    const int cfg[11] = {256, 256, 2, 4, 0, 0, 32, 1, 6, 0, 1};      // [8] = 6: gemm_pair_8ph_kernel
+                    for (int i = 0; i < 11; ++i) g_last_cfg[i] = cfg[i];
+                }
+                if (rc != DBMM_E_UNSUPPORTED) return rc;
+            }
+        }
         static const int bn256 = [] { const char* e = getenv("DBMM_IGEMM_BN256"); return e ? atoi(e) : 1; }();
         if (bn256 && p.wh && p.nw == 1 && p.a_absmax && p.a_bytes && (K % 32) == 0 && N >= 768 && (N % 256) == 0 && M >= 8192 &&
             (ldc & 3) == 0 && (!residual || (ldr & 3) == 0)) {

@@ -232,6 +232,14 @@ int dbmm_bottleneck_block_chain_x2(const float* y1, const float* y1_absmax, cons
                                    const float* bias1, float* y1_out, float* y1_out_absmax, int64_t B, int64_t H,
                                    int64_t W, int64_t K, int64_t N, int64_t P, void* stream);
 
+/* The same GEMM (w_planes = 1 only) on the deep-pipelined 256 x 256 kernel (csrc/gemm_pair_8ph.hip): fp32 activations by
+ * LDS-DMA, split into fp16 (hi, lo) when the fragments are read, two wave groups one barrier apart.  N % 256 == 0,
+ * K % 64 == 0.  Measured on a par with the default kernel, not ahead of it: dbmm_gemm_bias_act_x2 routes the wide
+ * transformer projections here only under DBMM_GEMM_8PH=1. */
+int dbmm_gemm_pair_8ph(const float* a, int64_t lda, const float* a_absmax, const void* w_plane_f16, int w_exp, int64_t ldw,
+                       const float* out_scale, const float* bias, const float* residual, int64_t ldr, float* c, int64_t ldc,
+                       float* c_absmax, int64_t M, int64_t N, int64_t K, float alpha, int act, void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * fp16 mode of the transformer towers -- the reference's GPU path (convert_weights, clip/model.py:375-396; fp16
  * activations, fp32 LayerNorm statistics, clip/model.py:157-163).  Tensors marked f16 are IEEE half in HBM; every

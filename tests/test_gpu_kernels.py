@@ -635,6 +635,38 @@ def test_direct_epilogue_equals_staged_epilogue(M, N, K, res, act, monkeypatch):
         assert torch.equal(ys[0], ys[1])
 
 
+@pytest.mark.parametrize("M,N,K,res,act", [(16384 + 77, 512, 128, True, 2), (25600, 2304, 768, False, 0), (20000, 1024, 4096, True, 0),
+                                           (577 * 32, 3072, 1024, False, 2), (16384, 768, 3072, True, 1)])
+def test_gemm_pair_deep_pipelined_kernel(M, N, K, res, act, monkeypatch):
+    """parity-mode GEMM on the 256 x 256 eight-phase kernel (gemm_pair_8ph.hip; N % 256 == 0, K % 64 == 0, M >= 16384):
+    element-wise against fp64 -- a staging race would show as a few wrong tiles -- over repeated launches, against the
+    two-barrier fp16-pair kernel (DBMM_GEMM_8PH=0) on the same operands, and the output-maximum scalar"""
+    g = torch.Generator(device=DEV); g.manual_seed(M + N + K)
+    a = torch.randn((M, K), device=DEV, generator=g) * 2.0; w = (torch.randn((N, K), device=DEV, generator=g) * K ** -0.5).half().float()
+    b = torch.randn((N,), device=DEV, generator=g) * 0.1; r = torch.randn((M, N), device=DEV, generator=g) if res else None
+    ph, we, n = ops.split_planes_f16(w, allow_single=True)
+    assert n == 1
+    rows = torch.cat([torch.arange(0, 600, device=DEV), torch.randint(0, M, (2000,), device=DEV, generator=g), torch.arange(M - 300, M, device=DEV)])
+    v = a[rows].double() @ w.double().t() + b.double()
+    if res:
+        v = v + r[rows].double()
+    v = {0: v, 1: torch.relu(v), 2: v * torch.sigmoid(1.702 * v)}[act]
+    aam = a.abs().max().reshape(1)
+    monkeypatch.setenv("DBMM_GEMM_8PH", "0")
+    am0 = torch.zeros(1, device=DEV)
+    base = ops.gemm(a, w, b, r, act=act, w_planes_f16=ph, w_exp=we, a_absmax=aam, c_absmax=am0)
+    assert ops._last_igemm_tag().startswith("igemm_x3_kernel<")
+    monkeypatch.setenv("DBMM_GEMM_8PH", "1")
+    scale = max(1.0, v.abs().max().item())
+    for _ in range(4):
+        am = torch.zeros(1, device=DEV)
+        out = ops.gemm(a, w, b, r, act=act, w_planes_f16=ph, w_exp=we, a_absmax=aam, c_absmax=am)
+        assert ops._last_igemm_tag() == "gemm_pair_8ph_kernel"
+        assert (out[rows].double() - v).abs().max().item() < 1e-5 * scale
+        assert (out - base).abs().max().item() < 1e-5 * scale           # same products, another summation order
+        assert am.item() == out.abs().max().item()
+
+
 @pytest.mark.parametrize("M,N,K,single,res,act", [(25600, 768, 768, True, True, 0), (25600, 2304, 768, True, False, 0),
                                                   (25600, 3072, 768, True, False, 2), (1000, 256, 64, True, True, 0),
                                                   (4096, 512, 2048, False, True, 0), (616, 192, 96, False, False, 2)])
@@ -665,7 +697,7 @@ def test_gemm_fp16_pair(M, N, K, single, res, act):
     assert e2 < 5e-6 and e2 < 5 * e32 + 5e-7, (e2, e32, tag)
     assert c_am.item() == out.abs().max().item()
     if (M // 128) * (N // 128) >= 192:     # enough 128x128 tiles for the big-tile kernels
-        assert tag.startswith("igemm_x3_kernel<"), tag
+        assert tag.startswith(("igemm_x3_kernel<", "gemm_pair_8ph_kernel")), tag
 
 
 @pytest.mark.parametrize("B,H,Cin,Cout,k,single", [(64, 28, 128, 256, 1, True), (256, 14, 256, 512, 1, True),
