@@ -83,100 +83,114 @@ __global__ __launch_bounds__(512, 1) void gemm_pair_8ph_kernel(const PairP p) {
     const __amdgpu_buffer_rsrc_t rsW0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, 0, 0x00020000);
     __amdgpu_buffer_rsrc_t rsA = rsA0, rsW = rsW0;
     int m0 = 0, n0 = 0;
-    // stager.  A half-tile: thread -> 16-B chunk (tid + 512 i) = local row (tid >> 3) + 64 i, slot tid & 7 of a 128-B row; it
-    // fetches source chunk slot ^ ((row >> 1) & 7).  W half-tile: chunk tid = local row tid >> 2, slot tid & 3 of a 64-B row,
-    // source chunk slot ^ ((row >> 2) & 3).  Operand rows of a local row lr:
-    //   A half h: tile row (lr >> 5) * 64 + h * 32 + (lr & 31);   W half h: tile column (lr >> 6) * 128 + h * 64 + (lr & 63)
-    unsigned voffA[2][2], voffW[2];
+    // A half-tile h (128 rows x 32 k): thread -> (local row tid >> 2, k group tid & 3 of 8 k = 32 B of fp32).  Local row lr is
+    // tile row (lr >> 5) * 64 + h * 32 + (lr & 31): the h-th 32 rows of every wave row's 64.  W half-tile h by LDS-DMA: chunk
+    // tid = local row tid >> 2, slot tid & 3 of a 64-B row, source chunk slot ^ ((row >> 2) & 3); local row lr is tile column
+    // (lr >> 6) * 128 + h * 64 + (lr & 63).
+    unsigned voffA[2], voffW[2];
     auto set_tile = [&](int tile) {
         m0 = (tile / p.tiles_n) * 256; n0 = (tile % p.tiles_n) * 256;
         rsA = desc(p.a, p.a_total, (long long)m0 * p.lda * 4);
         rsW = desc(p.w, p.w_total, (long long)n0 * p.ldw * 2);
+        const int lr = tid >> 2;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int lr = (tid >> 3) + 64 * i, c = (tid & 7) ^ ((lr >> 1) & 7);
-                const int ra = (lr >> 5) * 64 + h * 32 + (lr & 31);
-                voffA[h][i] = m0 + ra < p.M ? (unsigned)ra * (unsigned)(p.lda * 4) + c * 16u : OOR;
-            }
-            const int lr = tid >> 2, c = (tid & 3) ^ ((lr >> 2) & 3);
-            voffW[h] = (unsigned)((lr >> 6) * 128 + h * 64 + (lr & 63)) * (unsigned)(p.ldw * 2) + c * 16u;
+            const int ra = (lr >> 5) * 64 + h * 32 + (lr & 31);
+            voffA[h] = m0 + ra < p.M ? (unsigned)ra * (unsigned)(p.lda * 4) + (tid & 3) * 32u : OOR;
+            voffW[h] = (unsigned)((lr >> 6) * 128 + h * 64 + (lr & 63)) * (unsigned)(p.ldw * 2) + (((tid & 3) ^ ((lr >> 2) & 3)) << 4);
         }
     };
     const int nT = p.K / 32;
-    // stage kind k = 0..3 (Ah0, Bh0, Bh1, Ah1) of K tile t into buffer `buf`; tiles past the end go through the zero-extent
-    // descriptors so that every phase issues its fixed number of DMA instructions (the vmcnt constants rely on it)
-    auto stage = [&](int kind, int buf, int t) {
-        const bool valid = t < nT;
-        unsigned char* base = lds + buf * BUF;
-        if (kind == 0 || kind == 3) {
-            const __amdgpu_buffer_rsrc_t rs = valid ? rsA : rsA0;
-            unsigned char* slot = base + (kind == 0 ? OFF_AH0 : OFF_AH1) + wid * 1024;
-#pragma unroll
-            for (int i = 0; i < 2; ++i) glds16(rs, slot + i * 8192, voffA[kind == 3][i], (unsigned)t * 128u);
-        } else {
-            const __amdgpu_buffer_rsrc_t rs = valid ? rsW : rsW0;
-            glds16(rs, base + (kind == 1 ? OFF_BH0 : OFF_BH1) + wid * 1024, voffW[kind == 2], (unsigned)t * 64u);
-        }
-    };
-    // fragment addresses inside a half-tile (bytes).  A: local row wr * 32 + fr, this lane's 8 k values of k-step ks are fp32
-    // chunks 4 ks + 2 fh and + 1 (32 B); W: local rows wc * 64 + cb * 32 + fr (two column blocks), fp16 chunk 2 ks + fh
-    int aoff[2][2], boff[2][2];
+    const int s_a = scale_exp(*p.a_absmax);
+    const float a_sc = pow2f(s_a), acc_scale = pow2f(-s_a - p.w_exp);
+    // this thread's 16-B slot inside an fp16 plane of an A half-tile (its 8 k values), and the fragment addresses: A rows
+    // wr * 32 + fr, W rows wc * 64 + cb * 32 + fr, chunk 2 ks + fh, 64-B rows swizzled by (row >> 2) & 3
+    const int cv_off = (tid >> 2) * 64 + (((tid & 3) ^ (((tid >> 2) >> 2) & 3)) << 4);
+    int aoff[2], boff[2][2];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-        const int r = wr * 32 + fr, s = (r >> 1) & 7;
-        aoff[ks][0] = r * 128 + (((4 * ks + 2 * fh) ^ s) << 4);
-        aoff[ks][1] = r * 128 + (((4 * ks + 2 * fh + 1) ^ s) << 4);
+        const int r = wr * 32 + fr;
+        aoff[ks] = r * 64 + (((2 * ks + fh) ^ ((r >> 2) & 3)) << 4);
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb) {
             const int rw = wc * 64 + cb * 32 + fr;
             boff[cb][ks] = rw * 64 + (((2 * ks + fh) ^ ((rw >> 2) & 3)) << 4);
         }
     }
-    const int s_a = scale_exp(*p.a_absmax);
-    const float a_sc = pow2f(s_a), acc_scale = pow2f(-s_a - p.w_exp);
+    // A in flight in registers: [half][tile parity][2 x 16 B]
+    f32x4 ar[2][2][2];
+    auto load_a = [&](int h, int t, int set) {
+        const __amdgpu_buffer_rsrc_t rs = t < nT ? rsA : rsA0;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            ar[h][set][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voffA[h], (unsigned)t * 128u + i * 16u, 0));
+    };
+    // split this thread's 8 values ONCE and store them into the (hi, lo) planes of the half-tile's slot
+    auto convert_a = [&](int h, int set, int buf) {
+        unsigned hi[4], lo[4];
+        split2h_pair(ar[h][set][0][0], ar[h][set][0][1], a_sc, hi[0], lo[0]);
+        split2h_pair(ar[h][set][0][2], ar[h][set][0][3], a_sc, hi[1], lo[1]);
+        split2h_pair(ar[h][set][1][0], ar[h][set][1][1], a_sc, hi[2], lo[2]);
+        split2h_pair(ar[h][set][1][2], ar[h][set][1][3], a_sc, hi[3], lo[3]);
+        unsigned char* slot = lds + buf * BUF + (h ? OFF_AH1 : OFF_AH0) + cv_off;
+        *(u32x4*)slot = (u32x4){hi[0], hi[1], hi[2], hi[3]};
+        *(u32x4*)(slot + A_HALF / 2) = (u32x4){lo[0], lo[1], lo[2], lo[3]};
+    };
+    auto dma_w = [&](int h, int t, int buf) {
+        glds16(t < nT ? rsW : rsW0, lds + buf * BUF + (h ? OFF_BH1 : OFF_BH0) + wid * 1024, voffW[h], (unsigned)t * 64u);
+    };
     f32x16 acc[2][4];                                                 // [A half (32 rows)][W half * 2 + column block]
-    unsigned fah[2][4], fal[2][4];                                    // [ks]: hi / lo planes of the A fragment
+    u32x4 fah[2], fal[2];                                             // [ks]
     u32x4 fb0[2][2], fb1[2][2];                                       // [column block][ks]
 
-    auto read_a = [&](const unsigned char* half) {
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const f32x4 x0 = *(const f32x4*)(half + aoff[ks][0]), x1 = *(const f32x4*)(half + aoff[ks][1]);
-            split2h_pair(x0[0], x0[1], a_sc, fah[ks][0], fal[ks][0]);
-            split2h_pair(x0[2], x0[3], a_sc, fah[ks][1], fal[ks][1]);
-            split2h_pair(x1[0], x1[1], a_sc, fah[ks][2], fal[ks][2]);
-            split2h_pair(x1[2], x1[3], a_sc, fah[ks][3], fal[ks][3]);
-        }
-    };
-    // one phase: j = phase within the loop trip (static), t2 = first K tile of the trip
+    // One phase.  j = phase within the loop trip (static), t2 = the trip's first K tile (even).  Tile t = t2 + (j >> 2) lives
+    // in buffer (j >> 2) & 1; the wave walks its 64 x 128 block as quadrants (A0,B0) (A0,B1) (A1,B1) (A1,B0).  Besides its
+    // fragment reads a phase does one piece of staging for later tiles:
+    //   p0: convert Ah1(t) -> LDS (read at p2);  DMA Bh1(t + 1) (read at its tile's p1, five phases on)
+    //   p1: load Ah0(t + 2) into registers (converted at p2 of t + 1)
+    //   p2: convert Ah0(t + 1) -> LDS (read at its p0);  load Ah1(t + 2) into registers (converted at p0 of t + 2);
+    //       vmcnt(5) retires the DMA of the last p3
+    //   p3: DMA Bh0(t + 2);  vmcnt(5) retires the DMA of this tile's p0
+    // (5 = the vector-memory instructions issued after the DMA being retired: 1 + 2 + 2 or 2 + 2 + 1.)  Converted data is
+    // read TWO phases after it is stored: the storing wave's lgkmcnt(0) sits behind its first barrier, and the other wave
+    // group runs one barrier behind (storing one phase ahead and waiting before the barrier stretched every other interval).
     auto phase = [&](int j, int t2) {
-        const int ph = j & 3, buf = (j >> 2) & 1;
+        const int ph = j & 3, buf = (j >> 2) & 1, t = t2 + (j >> 2);
         const unsigned char* base = lds + buf * BUF;
         if (ph == 0) {
 #pragma unroll
             for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) fb0[cb][ks] = *(const u32x4*)(base + OFF_BH0 + boff[cb][ks]);
-            read_a(base + OFF_AH0);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                fah[ks] = *(const u32x4*)(base + OFF_AH0 + aoff[ks]);
+                fal[ks] = *(const u32x4*)(base + OFF_AH0 + A_HALF / 2 + aoff[ks]);
+            }
+            convert_a(1, buf, buf);
+            __builtin_amdgcn_sched_barrier(0);
+            dma_w(1, t + 1, buf ^ 1);
         } else if (ph == 1) {
 #pragma unroll
             for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) fb1[cb][ks] = *(const u32x4*)(base + OFF_BH1 + boff[cb][ks]);
+            __builtin_amdgcn_sched_barrier(0);
+            load_a(0, t + 2, buf);
         } else if (ph == 2) {
-            read_a(base + OFF_AH1);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                fah[ks] = *(const u32x4*)(base + OFF_AH1 + aoff[ks]);
+                fal[ks] = *(const u32x4*)(base + OFF_AH1 + A_HALF / 2 + aoff[ks]);
+            }
+            convert_a(0, buf ^ 1, buf ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+            load_a(1, t + 2, buf);
+        } else {
+            dma_w(0, t + 2, buf);
         }
         __builtin_amdgcn_sched_barrier(0);
-        {
-            const int q = j + 5;                                      // stage number relative to the trip's first tile
-            stage(q & 3, (q >> 2) & 1, t2 + (q >> 2));
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        // outstanding after this wait = the last three stages: kinds (j+5, j+4, j+3) & 3 with 2 / 1 / 1 / 2 instructions each
-        if ((j & 3) == 0 || (j & 3) == 3) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        if (ph >= 2) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
@@ -186,27 +200,24 @@ __global__ __launch_bounds__(512, 1) void gemm_pair_8ph_kernel(const PairP p) {
         for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
             for (int cb = 0; cb < 2; ++cb)                            // (lo, w) first, then (hi, w)
-                acc[ai][2 * bj + cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(frag(fal[ks]), __builtin_bit_cast(f16x8, bj ? fb1[cb][ks] : fb0[cb][ks]),
+                acc[ai][2 * bj + cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fal[ks]), __builtin_bit_cast(f16x8, bj ? fb1[cb][ks] : fb0[cb][ks]),
                                                                               acc[ai][2 * bj + cb], 0, 0, 0);
 #pragma unroll
             for (int cb = 0; cb < 2; ++cb)
-                acc[ai][2 * bj + cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(frag(fah[ks]), __builtin_bit_cast(f16x8, bj ? fb1[cb][ks] : fb0[cb][ks]),
+                acc[ai][2 * bj + cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fah[ks]), __builtin_bit_cast(f16x8, bj ? fb1[cb][ks] : fb0[cb][ks]),
                                                                               acc[ai][2 * bj + cb], 0, 0, 0);
         }
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
     };
-    // prologue of a tile: stages 0 .. 4 (K tile 0 complete + Ah0 of K tile 1)
-    auto prologue = [&]() {
-#pragma unroll
-        for (int q = 0; q < 5; ++q) stage(q & 3, (q >> 2) & 1, q >> 2);
-    };
     const int wm0 = wr * 64, wn0 = wc * 128;
     float out_amax = 0.f;
 
     int tile = t_lo + slot_in_xcd;
-    if (tile < t_hi) { set_tile(tile); prologue(); }
+    // the W half-tiles a tile needs before its first phases: Bh0(0), Bh1(0) into buffer 0, Bh0(1) into buffer 1
+    auto prologue_w = [&]() { dma_w(0, 0, 0); dma_w(1, 0, 0); dma_w(0, 1, 1); };
+    if (tile < t_hi) { set_tile(tile); prologue_w(); }
     for (; tile < t_hi; tile += wg_per_xcd) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -214,9 +225,13 @@ __global__ __launch_bounds__(512, 1) void gemm_pair_8ph_kernel(const PairP p) {
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-        // everything this wave has in flight (the prologue issued before the previous tile's epilogue, that epilogue's own
-        // loads and stores) is retired here; the first waits of the phases are then satisfied at once
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // the activations of the first K tiles go through registers: Ah0(0) is converted here, Ah1(0) / Ah0(1) / Ah1(1) wait in
+        // their register sets for the phases that convert them (p0 / p2 of tile 0, p0 of tile 1)
+        load_a(0, 0, 0); load_a(1, 0, 0); load_a(0, 1, 1); load_a(1, 1, 1);
+        convert_a(0, 0, 0);
+        // everything older than those loads (the W prologue issued before the previous tile's epilogue, that epilogue's loads and
+        // stores) has been retired by the wait the conversion needed; the LDS stores are waited for before the barrier
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         if (grp == 1) __builtin_amdgcn_s_barrier();                   // the second wave group runs one barrier behind
         for (int t2 = 0; t2 < nT; t2 += 2) {
@@ -224,10 +239,10 @@ __global__ __launch_bounds__(512, 1) void gemm_pair_8ph_kernel(const PairP p) {
             for (int j = 0; j < 8; ++j) phase(j, t2);
         }
         if (grp == 0) __builtin_amdgcn_s_barrier();
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the (zero-extent) tail DMA of this tile
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the (zero-extent) tail loads / DMA of this tile
         __builtin_amdgcn_s_barrier();                                 // every wave is done with the ring
         const int em0 = m0, en0 = n0;
-        if (tile + wg_per_xcd < t_hi) { set_tile(tile + wg_per_xcd); prologue(); }   // in flight during the epilogue below
+        if (tile + wg_per_xcd < t_hi) { set_tile(tile + wg_per_xcd); prologue_w(); }   // in flight during the epilogue below
 
         // epilogue straight from the accumulators: lane (fr, fh) holds column 32 j + fr of the wave's 128 (blocks j = 0..3), rows
         // 32 i + (r & 3) + 8 (r >> 2) + 4 fh: one register = two 128-B row segments per wave instruction.  Rows >= M fall off

@@ -1673,14 +1673,16 @@ int gemm_impl(const float* a, int64_t lda, int trans_a, const float* w, int64_t 
         // wide GEMMs (transformer projections): a 128 x 256 tile halves the per-FLOP cost of fetching and splitting the fp32
         // activations (the A tile is shared by twice as many output columns); 128 accumulator registers, 2 workgroups per CU.
         // DBMM_IGEMM_BN256=0 disables.
-        // DBMM_GEMM_8PH=1: the deep-pipelined 256 x 256 kernel (gemm_pair_8ph.hip) instead.  Off by default: with the fp32 ->
-        // (hi, lo) split done when the fragments are read it only ties the two-barrier kernel (ViT-L/14@336 shapes, same box:
-        // 427 vs 388 TF-eq at N 3072 K 1024, 460 vs 501 at N 1024 K 4096, 357 vs 414 with a residual at K 1024); it needs
-        // the split done ONCE per tile (convert in place in LDS a phase before the first read) to pull ahead.  Read on every
-        // call: the tests run both.
+        // The deep-pipelined 256 x 256 kernel (gemm_pair_8ph.hip) where it measured ahead of this one on the ViT-L/14@336
+        // shapes (same box, TF fp32-equivalent): N 3072 K 1024 389 -> 466, N 4096 K 1024 QuickGELU 426 -> 455, N 1024 K 4096
+        // + residual 501 -> 529; it loses where N is narrow and K short (N 1024 K 1024 + residual 421 -> 394, the ViT-B/32
+        // shapes 0.83 - 1.0 x): its in-order prefetch is four to five phases deep and a tile's first round trip is exposed.
+        // DBMM_GEMM_8PH = 0 never, 1 (default) by that rule, 2 wherever the kernel applies (the tests run all three).
         {
             const char* e8 = getenv("DBMM_GEMM_8PH");
-            if ((e8 ? atoi(e8) : 0) && p.wh && p.nw == 1 && p.a_absmax && (N % 256) == 0 && (K % 64) == 0 && M >= 16384 && (lda & 3) == 0 &&
+            const int m8 = e8 ? atoi(e8) : 1;
+            const bool pays = m8 == 2 || (m8 == 1 && ((N >= 3072 && K >= 1024) || K >= 4096));
+            if (pays && p.wh && p.nw == 1 && p.a_absmax && (N % 256) == 0 && (K % 64) == 0 && M >= 16384 && (lda & 3) == 0 &&
                 (ldw & 7) == 0 && dbmm_aligned16(c) && (!residual || dbmm_aligned16(residual)) && 256 * (lda > ldc ? lda : ldc) * 4 < 0x7FFFFFF0LL &&
                 p.wh_bytes) {
                 const int rc = dbmm_gemm_pair_8ph(a, lda, sx.a_absmax, p.wh, p.w_exp, ldw, sx.oscale, bias, residual, ldr, c, ldc, sx.absmax_out,

@@ -234,8 +234,8 @@ int dbmm_bottleneck_block_chain_x2(const float* y1, const float* y1_absmax, cons
 
 /* The same GEMM (w_planes = 1 only) on the deep-pipelined 256 x 256 kernel (csrc/gemm_pair_8ph.hip): fp32 activations by
  * LDS-DMA, split into fp16 (hi, lo) when the fragments are read, two wave groups one barrier apart.  N % 256 == 0,
- * K % 64 == 0.  Measured on a par with the default kernel, not ahead of it: dbmm_gemm_bias_act_x2 routes the wide
- * transformer projections here only under DBMM_GEMM_8PH=1. */
+ * K % 64 == 0.  dbmm_gemm_bias_act_x2 routes the projections here where this kernel measured ahead (N >= 3072 with
+ * K >= 1024, or K >= 4096; DBMM_GEMM_8PH = 0 never / 2 wherever it applies). */
 int dbmm_gemm_pair_8ph(const float* a, int64_t lda, const float* a_absmax, const void* w_plane_f16, int w_exp, int64_t ldw,
                        const float* out_scale, const float* bias, const float* residual, int64_t ldr, float* c, int64_t ldc,
                        float* c_absmax, int64_t M, int64_t N, int64_t K, float alpha, int act, void* stream);

@@ -656,7 +656,7 @@ def test_gemm_pair_deep_pipelined_kernel(M, N, K, res, act, monkeypatch):
     am0 = torch.zeros(1, device=DEV)
     base = ops.gemm(a, w, b, r, act=act, w_planes_f16=ph, w_exp=we, a_absmax=aam, c_absmax=am0)
     assert ops._last_igemm_tag().startswith("igemm_x3_kernel<")
-    monkeypatch.setenv("DBMM_GEMM_8PH", "1")
+    monkeypatch.setenv("DBMM_GEMM_8PH", "2")
     scale = max(1.0, v.abs().max().item())
     for _ in range(4):
         am = torch.zeros(1, device=DEV)
