@@ -674,7 +674,9 @@ def gemm_f16(a, w, bias=None, residual=None, act=ACT_NONE, M=None, lda=None):
     if M is None:
         M = a.numel() // a.shape[-1]
     c = torch.empty((M, N), device=a.device, dtype=torch.float16)
-    with _TimedTag("gemm_f16_kernel", 2.0 * M * N * K, 2 * (M * K + N * K + M * N * (2 if residual is not None else 1))):
+    deep = N % 256 == 0 and K % 128 == 0 and M >= 16384 and os.environ.get("DBMM_F16_8PH", "1") != "0"   # dbmm_gemm_f16's own rule
+    with _TimedTag("gemm_f16_8ph_kernel" if deep else "gemm_f16_kernel", 2.0 * M * N * K,
+                   2 * (M * K + N * K + M * N * (2 if residual is not None else 1))):
         check(_lib.lib().dbmm_gemm_f16(ptr(a), lda, ptr(w), K, ptr(bias), ptr(residual), N if residual is not None else 0, ptr(c), N,
                                        M, N, K, act, stream()), "gemm_f16")
     return c
