@@ -121,7 +121,11 @@ constexpr int C2_W2P = 104;                                      // LDS pitch of
 template <int K>
 struct Conv2Geo {
     static constexpr int W2_OFF = 2 * C2_PLANE;                   // halves
-    static constexpr int Z_OFF = (2 * C2_PLANE * 2 + K * C2_W2P * 2 + 255) / 256 * 256;   // bytes: 256-B zero line
+    static constexpr int GROUP_BYTES = (2 * C2_PLANE * 2 + K * C2_W2P * 2 + 255) / 256 * 256;   // strip planes + W2 group
+    // K = 64: two group stages (60 KB with the zero line, still two workgroups per CU): the next group is split and stored
+    // while this one computes, one barrier per group.  K = 128 would need 87 KB: one stage, two barriers per group.
+    static constexpr int NST = K == 64 ? 2 : 1;
+    static constexpr int Z_OFF = NST * GROUP_BYTES;               // bytes: 256-B zero line
     static constexpr int BYTES = Z_OFF + 256;
     static constexpr int STAGE_BYTES = BM * 68 * 4;               // y2 staging, 64 channels at a time
 };
@@ -278,8 +282,8 @@ __global__ __launch_bounds__(256, 2) void bottleneck_chain_kernel(const ChainP p
         // 256-B zero line at their own offset modulo 256 B.
         using C2 = Conv2Geo<K>;
         constexpr int TN2 = K / 32, NG = (K / 32) * 3, W2LD = (K * 12 + 255) / 256;
-        u16* Sp = (u16*)lds_raw;                                     // [2 planes][132][32]
-        u16* W2b = Sp + C2::W2_OFF;                                  // [K][C2_W2P]
+        u16* Sp = (u16*)lds_raw;                                     // per stage: [2 planes][132][32] then [K][C2_W2P]
+        constexpr int NST = C2::NST, STH = C2::GROUP_BYTES / 2;      // stages, halves per stage
         constexpr int ZLH = C2::Z_OFF / 2;                           // zero line, halves from the LDS base
         if (tid < 16) *(u32x4*)(lds_raw + C2::Z_OFF + tid * 16) = (u32x4){0u, 0u, 0u, 0u};
         const int s_y1 = scale_exp(*p.a_absmax);
@@ -320,7 +324,9 @@ __global__ __launch_bounds__(256, 2) void bottleneck_chain_kernel(const ChainP p
                 w2q[i] = idx < K * 12 ? *(const u32x4*)(p.w2 + (size_t)row * (9 * K) + (size_t)g * 96 + c * 8) : (u32x4){0u, 0u, 0u, 0u};
             }
         };
-        auto store_group = [&]() {
+        auto store_group = [&](int st) {
+            u16* Sps = Sp + st * STH;
+            u16* W2b = Sps + C2::W2_OFF;
 #pragma unroll
             for (int i = 0; i < 5; ++i) {
                 const int row = lr + 32 * i;
@@ -329,8 +335,8 @@ __global__ __launch_bounds__(256, 2) void bottleneck_chain_kernel(const ChainP p
 #pragma unroll
                     for (int j = 0; j < 2; ++j) split2h_pair(sq[i][2 * j], sq[i][2 * j + 1], y1_sc, hp[j], lp[j]);
                     const int off = row * 32 + (((lc >> 1) ^ swz<32>(row)) << 3) + ((lc & 1) << 2);
-                    *(u32x2*)(Sp + off) = (u32x2){hp[0], hp[1]};
-                    *(u32x2*)(Sp + C2_PLANE + off) = (u32x2){lp[0], lp[1]};
+                    *(u32x2*)(Sps + off) = (u32x2){hp[0], hp[1]};
+                    *(u32x2*)(Sps + C2_PLANE + off) = (u32x2){lp[0], lp[1]};
                 }
             }
 #pragma unroll
@@ -344,11 +350,10 @@ __global__ __launch_bounds__(256, 2) void bottleneck_chain_kernel(const ChainP p
         for (int j = 0; j < TN2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc2[j][r] = 0.f;
-        load_group(0);
-        for (int g = 0; g < NG; ++g) {
-            store_group();
-            __syncthreads();
-            if (g + 1 < NG) load_group(g + 1);
+        auto compute_group = [&](int g, int st) {
+            const u16* Sps = Sp + st * STH;
+            const u16* W2b = Sps + C2::W2_OFF;
+            const int zl = ZLH - st * STH;                           // the zero line relative to this stage
             const int kh = g % 3;
 #pragma unroll
             for (int kw = 0; kw < 3; ++kw) {
@@ -357,8 +362,8 @@ __global__ __launch_bounds__(256, 2) void bottleneck_chain_kernel(const ChainP p
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
                     const int addr = row * 32 + (((2 * ks + fh) ^ swz<32>(row)) << 3);
-                    const int a0 = ok ? addr : ZLH + (addr & 127), a1 = ok ? addr + C2_PLANE : ZLH + (addr & 127);
-                    const u32x4 ah = *(const u32x4*)(Sp + a0), al = *(const u32x4*)(Sp + a1);
+                    const int a0 = ok ? addr : zl + (addr & 127), a1 = ok ? addr + C2_PLANE : zl + (addr & 127);
+                    const u32x4 ah = *(const u32x4*)(Sps + a0), al = *(const u32x4*)(Sps + a1);
                     u32x4 wf[TN2];
 #pragma unroll
                     for (int j = 0; j < TN2; ++j) wf[j] = *(const u32x4*)(W2b + (j * 32 + fr) * C2_W2P + kw * 32 + (2 * ks + fh) * 8);
@@ -370,7 +375,27 @@ __global__ __launch_bounds__(256, 2) void bottleneck_chain_kernel(const ChainP p
                         acc2[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah), __builtin_bit_cast(f16x8, wf[j]), acc2[j], 0, 0, 0);
                 }
             }
+        };
+        load_group(0);
+        if constexpr (NST == 2) {
+            // two stages: group g + 1 is fetched (registers), split and stored into the other stage while group g computes;
+            // the stage it overwrites was last read in iteration g - 1, which every wave left through that iteration's barrier
+            store_group(0);
             __syncthreads();
+            for (int g = 0; g < NG; ++g) {
+                if (g + 1 < NG) load_group(g + 1);
+                compute_group(g, g & 1);
+                if (g + 1 < NG) store_group((g + 1) & 1);
+                __syncthreads();
+            }
+        } else {
+            for (int g = 0; g < NG; ++g) {
+                store_group(0);
+                __syncthreads();
+                if (g + 1 < NG) load_group(g + 1);
+                compute_group(g, 0);
+                __syncthreads();
+            }
         }
         // y2 = relu(bn2(.)) in the accumulator layout; its fp16 scale is the wave's own maximum (the wave's 32 rows feed only
         // this wave's conv3); through a wave-private fp32 staging block, 64 channels at a time, into A fragments
