@@ -330,7 +330,11 @@ __global__ __launch_bounds__(512, 1) void gemm_f16_8ph_kernel(const GemmHP p) {
     u32x4 fa[2][4], fb0[4], fb1[4];
 
     // one phase: j = phase within the loop trip (static), t2 = first K tile of the trip
-    auto phase = [&](int j, int t2) {
+    // `first`: the tile's first trip.  Its prologue has staged both K tiles of the trip (stages 0 .. 7), so phases 0 - 2 stage
+    // nothing and phases 0 - 4 wait for nothing: the first counted wait (phase 5) is where the previous tile's epilogue stores
+    // -- older in the queue than every DMA of this tile -- have to be acknowledged, 2000+ cycles after they were issued,
+    // instead of at the top of the tile.
+    auto phase = [&](int j, int t2, bool first) {
         const int ph = j & 3, buf = (j >> 2) & 1;
         const unsigned char* base = lds + buf * 4 * PH_HALF;
         if (ph == 0) {
@@ -351,12 +355,12 @@ __global__ __launch_bounds__(512, 1) void gemm_f16_8ph_kernel(const GemmHP p) {
                 for (int ks = 0; ks < 4; ++ks) fa[b][ks] = *(const u32x4*)(base + 3 * PH_HALF + aoff[b][ks]);
         }
         __builtin_amdgcn_sched_barrier(0);
-        {
+        if (!(first && j < 3)) {
             const int q = j + 5;                                      // stage number relative to the trip's first tile
             stage(q & 3, (q >> 2) & 1, t2 + (q >> 2));
         }
         __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        if (!(first && j < 5)) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
@@ -373,14 +377,15 @@ __global__ __launch_bounds__(512, 1) void gemm_f16_8ph_kernel(const GemmHP p) {
         __builtin_amdgcn_s_barrier();
     };
 
-    // prologue of a tile: stages 0 .. 4 (K tile 0 complete + Ah0 of K tile 1)
+    // prologue of a tile: stages 0 .. 7 = its first two K tiles, both buffers
     auto prologue = [&]() {
 #pragma unroll
-        for (int q = 0; q < 5; ++q) stage(q & 3, (q >> 2) & 1, q >> 2);
+        for (int q = 0; q < 8; ++q) stage(q & 3, (q >> 2) & 1, q >> 2);
     };
     const int wm0 = wr * 128, wn0 = wc * 64;
 
     int tile = t_lo + slot_in_xcd;
+    bool first_tile = true;
     // De-phase the workgroups.  Every tile takes the same time, so persistent workgroups that start together reach their
     // epilogues together: 256 x (128 KB of C + residual + the next A tile) hit HBM in one burst while it idles during
     // the main loops -- measured as a FIXED 14-16 us per tile whatever K (K sweep, tools/bench_gemm_f16.py).  The groups
@@ -399,16 +404,19 @@ __global__ __launch_bounds__(512, 1) void gemm_f16_8ph_kernel(const GemmHP p) {
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    // everything this wave has in flight (the prologue issued before the previous tile's epilogue, that epilogue's own
-    // loads and stores) is retired here; the prologue's five half-tiles had the whole epilogue to land
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // The prologue's 16 DMA instructions must have landed; the 64 epilogue stores issued AFTER them need not have been
+    // acknowledged yet (4.6 us of a tile's fixed cost when they were waited for here): vmcnt(63) leaves at most 63 of the
+    // 80 outstanding, i.e. retires the 16 DMAs (and one store).  The first tile has no stores behind its prologue.
+    if (first_tile) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
+    first_tile = false;
     __builtin_amdgcn_s_barrier();
-    // the vmcnt(6) arithmetic of the phases wants three half-tiles in flight: re-issue nothing, the first three waits are
-    // simply satisfied at once
     if (wr == 1) __builtin_amdgcn_s_barrier();                        // the second wave row runs one barrier behind
-    for (int t2 = 0; t2 < ((GF16_ABL & 8) ? 2 : nT); t2 += 2) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) phase(j, t2);
+    for (int j = 0; j < 8; ++j) phase(j, 0, true);
+    for (int t2 = 2; t2 < ((GF16_ABL & 8) ? 2 : nT); t2 += 2) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) phase(j, t2, false);
     }
     if (wr == 0) __builtin_amdgcn_s_barrier();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // the (zero-extent) tail DMA of this tile
