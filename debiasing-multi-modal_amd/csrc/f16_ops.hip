@@ -38,6 +38,13 @@ __device__ __forceinline__ unsigned pack2(float a, float b) {
     const f16x2 v = {(_Float16)a, (_Float16)b};
     return __builtin_bit_cast(unsigned, v);
 }
+__device__ __forceinline__ float fast_exp2(float x) {       // v_exp_f32: 1 ulp, denormal results flush to zero
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_exp2f(x);
+#else
+    return exp2f(x);
+#endif
+}
 __device__ __forceinline__ float act_f(float v, int act) {
     if (act == DBMM_ACT_RELU) return fmaxf(v, 0.f);
     // QuickGELU v * sigmoid(1.702 v) on the hardware exp2 / rcp (1 ulp each; the result is rounded to fp16 anyway).
@@ -565,30 +572,39 @@ __global__ __launch_bounds__(256, 2) void mha_f16_kernel(const u16* __restrict__
                                                                            s_acc[qt][kt], 0, 0, 0);
             }
         // ---- online softmax: a lane holds keys (r&3) + 8 (r>>2) + 4 fh of each half for ITS query of every tile ----------
+        // The softmax is what bounds this kernel (32 elements per lane and tile against 16 MFMAs per wave), so its
+        // instruction count is kept down: masks only on tiles that can hold a masked key (the last one, and under the
+        // causal mask the tiles that reach past the wave's first query) -- a wave-uniform branch; the 1/8 * log2(e) scale
+        // folded into the exponent's FMA; the hardware exp2 (arguments <= 0, flushed denormals are zeros anyway); the
+        // accumulator rescale skipped while no lane's maximum moved.
         u32x4 pf[QT][2][2];
+        const bool tile_masked = (t + 1) * 64 > L || (causal && (t + 1) * 64 - 1 > qb * QB + wave * QT * 32);
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) {
             float mx = -INFINITY;
+            if (tile_masked) {
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int key = t * 64 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                        if (key >= L || (causal && key > q_idx[qt])) s_acc[qt][kt][r] = -INFINITY;
+                    }
+            }
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int key = t * 64 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-                    float v = s_acc[qt][kt][r] * scale_log2e;
-                    if (key >= L || (causal && key > q_idx[qt])) v = -INFINITY;
-                    s_acc[qt][kt][r] = v;
-                    mx = fmaxf(mx, v);
-                }
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s_acc[qt][kt][r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * scale_log2e;     // (scale > 0: the maximum commutes with it)
             const float m_new = fmaxf(m_run[qt], mx);
             const float m_use = m_new == -INFINITY ? 0.f : m_new;   // a fully masked row so far: exp2(-inf - 0) = 0
-            const float alpha = exp2f(m_run[qt] - m_use);
+            const float alpha = fast_exp2(m_run[qt] - m_use);
             float psum = 0.f;
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt) {
                 float pv[16];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) { pv[r] = exp2f(s_acc[qt][kt][r] - m_use); psum += pv[r]; }
+                for (int r = 0; r < 16; ++r) { pv[r] = fast_exp2(fmaf(s_acc[qt][kt][r], scale_log2e, -m_use)); psum += pv[r]; }
 #pragma unroll
                 for (int u = 0; u < 2; ++u)
                     pf[qt][kt][u] = (u32x4){pack2(pv[8 * u], pv[8 * u + 1]), pack2(pv[8 * u + 2], pv[8 * u + 3]),
@@ -596,10 +612,12 @@ __global__ __launch_bounds__(256, 2) void mha_f16_kernel(const u16* __restrict__
             }
             l_run[qt] = l_run[qt] * alpha + psum;
             m_run[qt] = m_new;
+            if (__builtin_amdgcn_ballot_w64(alpha != 1.f) != 0ull) {
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) o_acc[qt][j][r] *= alpha;
+                    for (int r = 0; r < 16; ++r) o_acc[qt][j][r] *= alpha;
+            }
         }
         // ---- O^T[d][query] += V^T[d][keys] P^T[keys][query]: one V^T fragment read serves every query tile ----------------
 #pragma unroll
