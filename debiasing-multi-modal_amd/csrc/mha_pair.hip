@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256, 2) void mha_pair_kernel(const float* __restric
     const int fr = lane & 31, fh = lane >> 5;
     const int qb = blockIdx.x, head = blockIdx.y, b = blockIdx.z;
     const long long row0 = (long long)b * L, ld = 3LL * E;
-    const int q_idx = qb * 128 + wave * 32 + fr;
+    const int q_idx = qb * 128 + wave * 32 + fr, q_wave0 = qb * 128 + wave * 32;   // this lane's query, the wave's first
     const int q_ld = q_idx < L ? q_idx : L - 1;
     const int s_x = scale_exp(*qkv_absmax);
     const float x_sc = pow2f(s_x);
@@ -137,18 +137,23 @@ __global__ __launch_bounds__(256, 2) void mha_pair_kernel(const float* __restric
             }
         }
         // ---- online softmax (a lane holds keys (r&3) + 8 (r>>2) + 4 fh of each half for ITS query) ----------------------------
+        // (masks only on tiles that can hold a masked key -- a wave-uniform branch --, the score scale folded into the exponent's
+        //  FMA, the accumulator rescale skipped while no lane's maximum moved: the softmax, not the MFMAs, bounds this kernel)
         float mx = -INFINITY;
+        if ((t + 1) * 64 > L || (causal && (t + 1) * 64 - 1 > q_wave0)) {
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = t * 64 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                    if (key >= L || (causal && key > q_idx)) s_acc[kt][r] = -INFINITY;
+                }
+        }
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = t * 64 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-                float v = s_acc[kt][r] * score_scale;
-                if (key >= L || (causal && key > q_idx)) v = -INFINITY;
-                s_acc[kt][r] = v;
-                mx = fmaxf(mx, v);
-            }
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s_acc[kt][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * score_scale;         // (scale > 0: the maximum commutes with it)
         const float m_new = fmaxf(m_run, mx);
         const float m_use = m_new == -INFINITY ? 0.f : m_new;
         const float alpha = exp2f(m_run - m_use);
@@ -158,7 +163,7 @@ __global__ __launch_bounds__(256, 2) void mha_pair_kernel(const float* __restric
         for (int kt = 0; kt < 2; ++kt) {
             float pv[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { pv[r] = exp2f(s_acc[kt][r] - m_use); psum += pv[r]; }
+            for (int r = 0; r < 16; ++r) { pv[r] = exp2f(fmaf(s_acc[kt][r], score_scale, -m_use)); psum += pv[r]; }
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 unsigned h[4], l[4];
@@ -169,10 +174,12 @@ __global__ __launch_bounds__(256, 2) void mha_pair_kernel(const float* __restric
         }
         l_run = l_run * alpha + psum;
         m_run = m_new;
+        if (__builtin_amdgcn_ballot_w64(alpha != 1.f) != 0ull) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) o_acc[j][r] *= alpha;
+                for (int r = 0; r < 16; ++r) o_acc[j][r] *= alpha;
+        }
         // ---- O^T[d][query] += V^T[d][keys] P^T[keys][query] -----------------------------------------------------------------
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
