@@ -486,6 +486,20 @@ constexpr int A_OROW = 72;                                       // O staging pi
 
 // QT = 32-query tiles per wave: 1 (a workgroup covers 128 queries; the default) or 2 (256: every K / V fragment read from LDS
 // and every staged K / V tile serves twice as many MFMAs -- kept behind DBMM_MHA_F16_QT2, it measured slower)
+// the 8 halves of a V^T fragment = two transposed 4 x 16 blocks 8 rows (keys) apart
+__device__ __forceinline__ u32x4 vt_frag(const unsigned char* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef short s16x4 __attribute__((__vector_size__(4 * sizeof(short))));
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
+    const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p + 8 * 128));
+    const u32x2 ua = __builtin_bit_cast(u32x2, a), ub = __builtin_bit_cast(u32x2, b);
+    return (u32x4){ua[0], ua[1], ub[0], ub[1]};
+#else
+    (void)p; return (u32x4){0u, 0u, 0u, 0u};
+#endif
+}
+
 template <int QT>
 __global__ __launch_bounds__(256, 2) void mha_f16_kernel(const u16* __restrict__ qkv, u16* __restrict__ out, int L, int E,
                                                          int heads, int causal, float scale_log2e) {
@@ -537,16 +551,23 @@ __global__ __launch_bounds__(256, 2) void mha_f16_kernel(const u16* __restrict__
         for (int i = 0; i < 2; ++i) {
             const int key = lk + 32 * i;
             *(u32x4*)(Ks + key * 64 + ((lc ^ swz64(key)) << 3)) = k_r[i];
-            // V^T: key offset o = 8a + 4h + ii inside its 16-group goes to position 8h + 4a + ii
-            const int g16 = key >> 4, oo = key & 15, chunk = 2 * g16 + ((oo >> 2) & 1), within = 4 * (oo >> 3) + (oo & 3);
-            const f16x8 v = __builtin_bit_cast(f16x8, v_r[i]);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int d = lc * 8 + j;
-                ((_Float16*)Vt)[d * 64 + ((chunk ^ swz64(d)) << 3) + within] = v[j];
-            }
+            // V stays ROW-major ([key][64 d], one 16-B store like K): the V^T fragments are formed by the hardware
+            // transpose read below.  Chunk XOR 4 on rows 2, 3 (mod 4) keeps the four rows of a transposed block on
+            // distinct bank groups.  (Staged transposed by hand this was 16 ds_write_b16 per thread and tile.)
+            *(u32x4*)(Vt + key * 64 + ((lc ^ (((key >> 1) & 1) << 2)) << 3)) = v_r[i];
         }
     };
+    // ds_read_b64_tr_b16 (cdna_hip_programming.md T10): per 16 lanes a block of 4 rows x 16 columns, lane 4q + p supplies the
+    // address of row q, columns 4p .. 4p + 3, lane i receives column i of the four rows.  For the O^T += V^T P^T operand the
+    // rows are keys and the columns d: a lane's 8 k values of step (kt, u) are keys kt*32 + 16u + 4fh + {0..3} and + 8, i.e.
+    // two blocks; its column is d = 32 j + 16 g + (lane & 15).  Byte address of this lane's piece for j = 0 / 1, without the
+    // (kt, u, block) row offset, which is a multiple of 4 rows and goes into the immediate:
+    int vtr[2];
+    {
+        const int g = (lane >> 4) & 1, pq = lane & 15, q = pq >> 2, pp = pq & 3;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) vtr[j] = (4 * fh + q) * 128 + 16 * (4 * (j ^ (q >> 1)) + 2 * g + (pp >> 1)) + 8 * (pp & 1);
+    }
     load_tile(0);
     store_tile();
     __syncthreads();
@@ -626,8 +647,7 @@ __global__ __launch_bounds__(256, 2) void mha_f16_kernel(const u16* __restrict__
             for (int u = 0; u < 2; ++u)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    const int d = j * 32 + fr, chunk = 2 * (2 * kt + u) + fh;
-                    const u32x4 vf = *(const u32x4*)(Vt + d * 64 + ((chunk ^ swz64(d)) << 3));
+                    const u32x4 vf = vt_frag((const unsigned char*)Vt + vtr[j] + (kt * 32 + 16 * u) * 128);
 #pragma unroll
                     for (int qt = 0; qt < QT; ++qt)
                         o_acc[qt][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, vf), __builtin_bit_cast(f16x8, pf[qt][kt][u]),
