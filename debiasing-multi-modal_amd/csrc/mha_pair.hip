@@ -43,12 +43,25 @@ __device__ __forceinline__ f32x16 mfma16(const u32x4& a, const u32x4& b, const f
 }
 
 constexpr int O_ROW = 68;                                        // O staging pitch in floats (272 B)
-constexpr int PL = 64 * 64;                                      // halves per K / V^T plane
+constexpr int PL = 64 * 64;                                      // halves per K / V plane
+
+// the 8 halves of a V^T fragment = two hardware-transposed 4-key x 16-d blocks 8 keys apart (cdna_hip_programming.md T10)
+__device__ __forceinline__ u32x4 vt_frag(const unsigned char* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef short s16x4 __attribute__((__vector_size__(4 * sizeof(short))));
+    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
+    const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p + 8 * 128));
+    const u32x2 ua = __builtin_bit_cast(u32x2, a), ub = __builtin_bit_cast(u32x2, b);
+    return (u32x4){ua[0], ua[1], ub[0], ub[1]};
+#else
+    (void)p; return (u32x4){0u, 0u, 0u, 0u};
+#endif
+}
 
 __global__ __launch_bounds__(256, 2) void mha_pair_kernel(const float* __restrict__ qkv, const float* __restrict__ qkv_absmax,
                                                           float* __restrict__ out, int L, int E, int causal) {
     __shared__ __attribute__((aligned(16))) u16 Ks[2 * PL];      // [hi | lo][key][64 d]
-    __shared__ __attribute__((aligned(16))) u16 Vt[2 * PL];      // [hi | lo][d][key position]
+    __shared__ __attribute__((aligned(16))) u16 Vt[2 * PL];      // [hi | lo][key][64 d]
     __shared__ __attribute__((aligned(16))) float Os[4 * 32 * O_ROW];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 31, fh = lane >> 5;
@@ -104,18 +117,23 @@ __global__ __launch_bounds__(256, 2) void mha_pair_kernel(const float* __restric
             const int koff = key * 64 + (((lc >> 1) ^ swz64(key)) << 3) + ((lc & 1) << 2);
             *(u32x2*)(Ks + koff) = (u32x2){h[0], h[1]};
             *(u32x2*)(Ks + PL + koff) = (u32x2){l[0], l[1]};
-            // V^T: key offset o = 8a + 4h + ii inside its 16-group goes to position 8h + 4a + ii
+            // V stays ROW-major ([key][64 d] per plane, 8-B stores like K): the V^T fragments come from the hardware transpose
+            // read (vt_frag).  Chunk XOR 4 on rows 2, 3 (mod 4) keeps the four rows of a transposed block on distinct bank
+            // groups.  (Staged transposed by hand this was 32 two-byte LDS stores per thread and tile.)
             split2h_pair(v_r[i][0], v_r[i][1], x_sc, h[0], l[0]); split2h_pair(v_r[i][2], v_r[i][3], x_sc, h[1], l[1]);
-            const int g16 = key >> 4, oo = key & 15, chunk = 2 * g16 + ((oo >> 2) & 1), within = 4 * (oo >> 3) + (oo & 3);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int d = lc * 4 + j;
-                const int voff = d * 64 + ((chunk ^ swz64(d)) << 3) + within;
-                Vt[voff] = (u16)((j & 1) ? (h[j >> 1] >> 16) : (h[j >> 1] & 0xffffu));
-                Vt[PL + voff] = (u16)((j & 1) ? (l[j >> 1] >> 16) : (l[j >> 1] & 0xffffu));
-            }
+            const int voff = key * 64 + (((lc >> 1) ^ (((key >> 1) & 1) << 2)) << 3) + ((lc & 1) << 2);
+            *(u32x2*)(Vt + voff) = (u32x2){h[0], h[1]};
+            *(u32x2*)(Vt + PL + voff) = (u32x2){l[0], l[1]};
         }
     };
+    // ds_read_b64_tr_b16 addressing as in mha_f16_kernel (f16_ops.hip): this lane's piece of a transposed 4-key x 16-d block
+    // for d block j = 0 / 1, without the (kt, u, block) key offset
+    int vtr[2];
+    {
+        const int g = (lane >> 4) & 1, pq = lane & 15, q = pq >> 2, pp = pq & 3;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) vtr[j] = (4 * fh + q) * 128 + 16 * (4 * (j ^ (q >> 1)) + 2 * g + (pp >> 1)) + 8 * (pp & 1);
+    }
     load_tile(0);
     store_tile();
     __syncthreads();
@@ -187,8 +205,8 @@ __global__ __launch_bounds__(256, 2) void mha_pair_kernel(const float* __restric
             for (int u = 0; u < 2; ++u)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    const int d = j * 32 + fr, chunk = 2 * (2 * kt + u) + fh, off = d * 64 + ((chunk ^ swz64(d)) << 3);
-                    const u32x4 vh = *(const u32x4*)(Vt + off), vl = *(const u32x4*)(Vt + PL + off);
+                    const unsigned char* vp = (const unsigned char*)Vt + vtr[j] + (kt * 32 + 16 * u) * 128;
+                    const u32x4 vh = vt_frag(vp), vl = vt_frag(vp + PL * 2);
                     o_acc[j] = mfma16(vh, pl[kt][u], o_acc[j]);
                     o_acc[j] = mfma16(vl, ph[kt][u], o_acc[j]);
                     o_acc[j] = mfma16(vh, ph[kt][u], o_acc[j]);
