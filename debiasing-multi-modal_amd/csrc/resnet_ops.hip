@@ -134,7 +134,10 @@ __global__ __launch_bounds__(256, STEM_MINB(NB)) void stem_s2_mfma_kernel(const 
                                                            int n_blocks) {
     constexpr int Cout = NB * 32;
     constexpr unsigned OOR = 0x80000000u;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // (the wave index through readfirstlane: the block number and with it the buffer descriptors are then PROVABLY
+    //  wave-uniform; derived from threadIdx alone the compiler wrapped each of the 48 buffer operations of a block in a
+    //  waterfall loop -- 208 v_readfirstlane in the listing)
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int fr = lane & 31, fh = lane >> 5;
     const long long M = (long long)B * Ho * Wo, img = 3LL * H * W;
     // K slot (fh, t = ks * 8 + i) -> tap.  Any bijection works as long as both operands use it; this one keeps a slot's
