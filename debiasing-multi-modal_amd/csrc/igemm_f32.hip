@@ -1530,7 +1530,12 @@ int launch_halo(IgemmP& p, hipStream_t s, void* ws, size_t ws_bytes, int* rc) {
         }
     }
     const dim3 g(p.sk_blocks ? p.sk_blocks : p.n_tiles, 1);
-    constexpr int WM = BN == 32 ? 4 : 2, WN = BN == 32 ? 1 : 2;
+#ifndef HALO64_4X1
+#define HALO64_4X1 1
+#endif
+    // 64-column tiles with the waves 4 x 1 like the 32-column ones: a wave owns 32 rows x all 64 columns, so no A fragment
+    // is read (from LDS) by two waves and a k-step is 4 reads for 4 MFMAs instead of 6
+    constexpr int WM = (BN == 32 || (BN == 64 && HALO64_4X1)) ? 4 : 2, WN = (BN == 32 || (BN == 64 && HALO64_4X1)) ? 1 : 2;
     if constexpr (POOL) {
         hipLaunchKernelGGL((igemm_halo_kernel<BN, WM, WN, MB, 0, 1>), g, dim3(256), 0, s, p);
     } else {
