@@ -635,7 +635,7 @@ def test_direct_epilogue_equals_staged_epilogue(M, N, K, res, act, monkeypatch):
         assert torch.equal(ys[0], ys[1])
 
 
-@pytest.mark.parametrize("M,N,K,res,act", [(16384 + 77, 512, 128, True, 2), (25600, 2304, 768, False, 0), (20000, 1024, 4096, True, 0),
+@pytest.mark.parametrize("M,N,K,res,act", [(16384 + 77, 512, 128, True, 2), (25600, 2304, 768, False, 0), (20000, 1024, 4096, True, 0), (16500, 256, 256, False, 0),
                                            (577 * 32, 3072, 1024, False, 2), (16384, 768, 3072, True, 1)])
 def test_gemm_pair_deep_pipelined_kernel(M, N, K, res, act, monkeypatch):
     """parity-mode GEMM on the 256 x 256 eight-phase kernel (gemm_pair_8ph.hip; N % 256 == 0, K % 64 == 0, M >= 16384):
