@@ -931,7 +931,8 @@ __device__ __forceinline__ void igemm_tile_x3(const IgemmP& p, float* lds, int t
     }
     const float acc_scale = NP == 2 ? igemm_acc_scale(p) : 1.f;
     {
-constexpr bool EPI_DIRECT = NP == 2 && EPID && TM * TN <= 4;   // fp16-pair kernels with <= 64 accumulator registers, not the stream-K builds (register budget)
+constexpr bool EPI_DIRECT = NP == 2 && EPID && TM * TN <= 4;   // fp16-pair kernels with <= 64 accumulator registers, not the stream-K builds (register
+                                                                 // budget); on the 128 x 256 GEMM tile it measured -1.7 % (ViT-B/32 parity): 28 registers spill around it
 #include "igemm_epilogue.inc"
     }
 }
