@@ -290,7 +290,7 @@ def main():
             "vs_baseline": None, "dtype": args.dtype,
             "dtype_detail": ("fp16 weights and activations in HBM, one fp16 MFMA per product, fp32 accumulate, fp32 LayerNorm / "
                              "softmax statistics (the reference's GPU path); adapter step in fp32 on the .float() embeddings; "
-                             "parity unpinned vs the reference's fp16 path, pinned to the fp32 goldens at 1e-2"
+                             "pinned to the reference's own fp16 path run on CPU (tests/golden/clip_*_f16.npz) at 3 x its fp16-vs-fp32 distance"
                              if args.dtype == "f16" else
                              "fp32 activations/accumulators; products on 16-bit MFMA as fp16 hi+lo pair (22-bit mantissa, "
                              "exact per-tensor power-of-two scale) x fp16-exact checkpoint weight; parity suite at 1e-3 logits"),

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include "../../include/dbmm.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));

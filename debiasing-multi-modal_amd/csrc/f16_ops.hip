@@ -450,27 +450,38 @@ __global__ __launch_bounds__(512, 1) void gemm_f16_8ph_kernel(const GemmHP p) {
         const __amdgpu_buffer_rsrc_t rsR = p.res ? desc(p.res, rows_left > 0 ? ((rows_left - 1) * p.ldr + p.N) * 2 + (long long)mw * p.ldr * 2 : 0, (long long)mw * p.ldr * 2)
                                                  : __builtin_amdgcn_make_buffer_rsrc((void*)p.c, 0, 0, 0x00020000);
         const unsigned vc = (unsigned)((4 * fh * p.ldc + n) * 2), vr = (unsigned)((4 * fh * p.ldr + n) * 2);
-        // all 64 residual loads in flight together (the fragment registers are dead here): one round trip, not four
-        unsigned rvv[RES ? 4 : 1][16];
-        if constexpr (RES) {
+        // Rows >= M of a ragged last tile are masked BY LANE (an out-of-range voffset) instead of being left to the extent:
+        // their row offset travels in soffset, which can exceed num_records there (range check: offset >= num_records -
+        // soffset).  A full tile pays nothing.
+        const int row_lim = (int)(rows_left < 1024 ? rows_left : 1024) - 4 * fh;     // row u of this lane is valid iff u < row_lim
+        auto epilogue = [&](auto full_tag) {
+            constexpr bool FULL = decltype(full_tag)::value;
+            // all 64 residual loads in flight together (the fragment registers are dead here): one round trip, not four
+            unsigned rvv[RES ? 4 : 1][16];
+            if constexpr (RES) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    rvv[i][r] = __builtin_amdgcn_raw_buffer_load_b32(rsR, vr, (unsigned)((32 * i + (r & 3) + 8 * (r >> 2)) * p.ldr * 2), 0);
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const f16x2 rh = __builtin_bit_cast(f16x2, RES ? rvv[i][r] : 0u);
-                float o0 = act_f(acc[i][0][r] + bn0, ACT), o1 = act_f(acc[i][1][r] + bn1, ACT);
-                if (RES) { o0 += (float)rh[0]; o1 += (float)rh[1]; }
-                if (GF16_ABL & 2) { asm volatile("" ::"v"(acc[i][0][r]), "v"(acc[i][1][r]), "v"(rh)); continue; }
-                if (GF16_ABL & 1) { asm volatile("" ::"v"(pack2(o0, o1))); continue; }
-                __builtin_amdgcn_raw_buffer_store_b32(pack2(o0, o1), rsC, vc, (unsigned)((32 * i + (r & 3) + 8 * (r >> 2)) * p.ldc * 2), 0);
+                    for (int r = 0; r < 16; ++r) {
+                        const int ru = 32 * i + (r & 3) + 8 * (r >> 2);
+                        rvv[i][r] = __builtin_amdgcn_raw_buffer_load_b32(rsR, (FULL || ru < row_lim) ? vr : OOR, (unsigned)(ru * p.ldr * 2), 0);
+                    }
             }
-        }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const f16x2 rh = __builtin_bit_cast(f16x2, RES ? rvv[i][r] : 0u);
+                    float o0 = act_f(acc[i][0][r] + bn0, ACT), o1 = act_f(acc[i][1][r] + bn1, ACT);
+                    if (RES) { o0 += (float)rh[0]; o1 += (float)rh[1]; }
+                    if (GF16_ABL & 2) { asm volatile("" ::"v"(acc[i][0][r]), "v"(acc[i][1][r]), "v"(rh)); continue; }
+                    if (GF16_ABL & 1) { asm volatile("" ::"v"(pack2(o0, o1))); continue; }
+                    const int ru = 32 * i + (r & 3) + 8 * (r >> 2);
+                    __builtin_amdgcn_raw_buffer_store_b32(pack2(o0, o1), rsC, (FULL || ru < row_lim) ? vc : OOR, (unsigned)(ru * p.ldc * 2), 0);
+                }
+            }
+        };
+        if (rows_left >= 128) epilogue(std::true_type{}); else epilogue(std::false_type{});
     }
     }
 }

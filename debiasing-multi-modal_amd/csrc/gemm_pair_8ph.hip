@@ -265,35 +265,46 @@ __global__ __launch_bounds__(512, 1) void gemm_pair_8ph_kernel(const PairP p) {
             bv[j] = p.bias ? p.bias[n] : 0.f;
         }
         float rv[RES ? 2 : 1][2][16];
-        auto load_res = [&](int u, int slot) {                        // unit u = (i = u >> 1, column blocks 2 (u & 1), + 1)
+        // Rows >= M of a ragged last tile are masked BY LANE (an out-of-range voffset), not left to the descriptor's extent:
+        // their row offset travels in soffset, which can exceed num_records there, and the range check is
+        // `offset >= num_records - soffset`.  A full tile (FULL) pays nothing for it.
+        const int row_lim = (int)(rows_left < 1024 ? rows_left : 1024) - 4 * fh;     // row u of this lane is valid iff u < row_lim
+        auto epilogue = [&](auto full_tag) {
+            constexpr bool FULL = decltype(full_tag)::value;
+            auto load_res = [&](int u, int slot) {                    // unit u = (i = u >> 1, column blocks 2 (u & 1), + 1)
 #pragma unroll
-            for (int jj = 0; jj < 2; ++jj)
+                for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    rv[slot][jj][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                        rsR, vr[2 * (u & 1) + jj], (unsigned)((32 * (u >> 1) + (r & 3) + 8 * (r >> 2)) * p.ldr * 4), 0));
-        };
-        if constexpr (RES) load_res(0, 0);
-        const bool full = rows_left >= 64;
+                    for (int r = 0; r < 16; ++r) {
+                        const int ru = 32 * (u >> 1) + (r & 3) + 8 * (r >> 2);
+                        const unsigned vo = (FULL || ru < row_lim) ? vr[2 * (u & 1) + jj] : 0x80000000u;
+                        rv[slot][jj][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsR, vo, (unsigned)(ru * p.ldr * 4), 0));
+                    }
+            };
+            if constexpr (RES) load_res(0, 0);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            if constexpr (RES) { if (u + 1 < 4) load_res(u + 1, (u + 1) & 1); }
-            const int i = u >> 1;
+            for (int u = 0; u < 4; ++u) {
+                if constexpr (RES) { if (u + 1 < 4) load_res(u + 1, (u + 1) & 1); }
+                const int i = u >> 1;
 #pragma unroll
-            for (int jj = 0; jj < 2; ++jj) {
-                const int j = 2 * (u & 1) + jj;
+                for (int jj = 0; jj < 2; ++jj) {
+                    const int j = 2 * (u & 1) + jj;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float v = (acc[i][j][r] * sv[j] + bv[j]) * p.alpha;
-                    if constexpr (RES) v += rv[u & 1][jj][r];
-                    if (ACT == DBMM_ACT_RELU) v = fmaxf(v, 0.f);
-                    else if (ACT == DBMM_ACT_QUICKGELU) v = v / (1.f + expf(-1.702f * v));
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsC, vc[j],
-                                                          (unsigned)((32 * i + (r & 3) + 8 * (r >> 2)) * p.ldc * 4), 0);
-                    if (full || 32 * i + (r & 3) + 8 * (r >> 2) + 4 * fh < rows_left) out_amax = fmaxf(out_amax, fabsf(v));
+                    for (int r = 0; r < 16; ++r) {
+                        float v = (acc[i][j][r] * sv[j] + bv[j]) * p.alpha;
+                        if constexpr (RES) v += rv[u & 1][jj][r];
+                        if (ACT == DBMM_ACT_RELU) v = fmaxf(v, 0.f);
+                        else if (ACT == DBMM_ACT_QUICKGELU) v = v / (1.f + expf(-1.702f * v));
+                        const int ru = 32 * i + (r & 3) + 8 * (r >> 2);
+                        const bool valid = FULL || ru < row_lim;
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsC, valid ? vc[j] : 0x80000000u,
+                                                              (unsigned)(ru * p.ldc * 4), 0);
+                        if (valid) out_amax = fmaxf(out_amax, fabsf(v));
+                    }
                 }
             }
-        }
+        };
+        if (rows_left >= 64) epilogue(std::true_type{}); else epilogue(std::false_type{});
     }
     if (p.c_absmax) {                                                 // one (filtered) atomic per workgroup
         out_amax = wave_max(out_amax);

@@ -248,11 +248,15 @@ __global__ __launch_bounds__(256, STEM_MINB(NB)) void stem_s2_mfma_kernel(const 
             const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)(y + mb * Cout), 0, (int)bytes, 0x00020000);
             const unsigned voff = (unsigned)((4 * fh * Cout + j * 32 + fr) * 4);
             float bmax = 0.f;
+            // rows >= M (only a ragged last block has any) are masked by lane: their row offset sits in soffset and may
+            // exceed num_records, which the range check `offset >= num_records - soffset` should not be asked to survive
+            const int row_lim = (int)(rows_left < 32 ? rows_left : 32) - 4 * fh;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row0 = (r & 3) + 8 * (r >> 2);                          // + 4 fh
                 const float v = fmaxf(fmaf(acc[r], osc, bv[j]), 0.f);
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ry, voff, (unsigned)(row0 * Cout * 4), 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ry, row0 < row_lim ? voff : OOR,
+                                                      (unsigned)(row0 * Cout * 4), 0);
                 bmax = fmaxf(bmax, v);
             }
             // rows past M exist only in the very last block: their lanes gathered zeros, so v = relu(bias) there

@@ -13,6 +13,10 @@ from ._lib import check, ptr, require_cuda, stream
 
 ACT_NONE, ACT_RELU, ACT_QUICKGELU = 0, 1, 2
 
+# every output / workspace of this module comes from here (torch's caching allocator); tests swap in an allocator
+# that surrounds each tensor with guard zones to catch writes outside the tensor (tests/test_gpu_headline.py)
+_empty = torch.empty
+
 # ---- optional per-launch timing of the MFMA kernel family (bench.py roofline leg) ----------
 _prof = None
 _prof_conv_only = False
@@ -85,7 +89,7 @@ def igemm_workspace(device):
     key = (device.type, device.index)
     ws = _ws_cache.get(key)
     if ws is None:
-        ws = torch.empty(_lib.lib().dbmm_workspace_bytes_igemm() // 4, device=device, dtype=torch.float32)
+        ws = _empty(_lib.lib().dbmm_workspace_bytes_igemm() // 4, device=device, dtype=torch.float32)
         _ws_cache[key] = ws
     return ws
 
@@ -101,7 +105,7 @@ def split_planes(w):
     require_cuda(w)
     _f32c(w)
     N, K = w.shape[0], w.numel() // w.shape[0]
-    planes = torch.empty((3, N, K), device=w.device, dtype=torch.bfloat16)
+    planes = _empty((3, N, K), device=w.device, dtype=torch.bfloat16)
     check(_lib.lib().dbmm_split_weight_planes(ptr(w), ptr(planes), N, K, stream()), "split_weight_planes")
     return planes
 
@@ -122,7 +126,7 @@ def split_planes_f16(w, allow_single=False):
         h = ws.half()
         if torch.equal(h.float(), ws):
             return h.reshape(1, N, K).contiguous(), w_exp, 1
-    planes = torch.empty((2, N, K), device=w.device, dtype=torch.float16)
+    planes = _empty((2, N, K), device=w.device, dtype=torch.float16)
     check(_lib.lib().dbmm_split_weight_planes_f16(ptr(w), ptr(planes), N, K, w_exp, stream()), "split_weight_planes_f16")
     return planes, w_exp, 2
 
@@ -147,7 +151,7 @@ def gemm(a, w, bias=None, residual=None, act=ACT_NONE, alpha=1.0, trans_a=False,
     if N is None:
         N = w.shape[1] if trans_w else w.shape[0]
     if out is None:
-        out = torch.empty((M, N), device=a.device, dtype=torch.float32)
+        out = _empty((M, N), device=a.device, dtype=torch.float32)
     ldr = residual.shape[-1] if residual is not None else 0
     ws = igemm_workspace(a.device)
     # algorithmic bytes: A and the residual read once, C written once, W once in the form the kernel reads it
@@ -225,7 +229,7 @@ def conv_bn_act(x, w, bias, residual, kh, kw, stride, pad, act, w_layout=WL_TAP_
             and w_planes_f16 is not None and w_planes_f16.shape[0] == 1 and out_scale is not None and x_absmax is not None
             and Cout in (32, 64) and H % 4 == 0 and W % 28 == 0 and (pool == 1 or (H % 2 == 0 and W % 2 == 0))
             and w_layout in (WL_TAP_MAJOR, WL_CHUNK32_MAJOR) and os.environ.get("DBMM_CONV_PATCH", "1") != "0"):
-        y = torch.empty((B, H // pool, W // pool, Cout), device=x.device, dtype=torch.float32)
+        y = _empty((B, H // pool, W // pool, Cout), device=x.device, dtype=torch.float32)
         global _chain_tag
         _chain_tag = f"conv3x3_c32_kernel<{Cout}, {int(pool == 2)}>"
         with _Timed(B * H * W, Cout, 9 * Cin, -1, 0, 4 * (x.numel() + y.numel()) + 2 * Cout * 9 * Cin):
@@ -234,8 +238,8 @@ def conv_bn_act(x, w, bias, residual, kh, kw, stride, pad, act, w_layout=WL_TAP_
             check(rc, "conv3x3_c32_bn_relu_x2")
         return y
     if pool == 2 and split and Ho % 2 == 0 and Wo % 2 == 0:
-        y = torch.empty((B, Ho // 2, Wo // 2, Cout), device=x.device, dtype=torch.float32)
-        yf = torch.empty((B, Ho, Wo, Cout), device=x.device, dtype=torch.float32) if keep_full else None
+        y = _empty((B, Ho // 2, Wo // 2, Cout), device=x.device, dtype=torch.float32)
+        yf = _empty((B, Ho, Wo, Cout), device=x.device, dtype=torch.float32) if keep_full else None
         t = _Timed(B * Ho * Wo, Cout, kh * kw * Cin, 0 if plain else 1, 0, nby_pool)
         t.__enter__()
         rc = _conv_x2(x, w, bias, residual, y, kh, kw, stride, pad, act, w_layout, w_planes_f16, w_exp, x_absmax,
@@ -245,7 +249,7 @@ def conv_bn_act(x, w, bias, residual, kh, kw, stride, pad, act, w_layout=WL_TAP_
             return (y, yf) if keep_full else y
         if rc != _lib.E_UNSUPPORTED:
             check(rc, "conv_bn_act_x2(pool)")
-    y = torch.empty((B, Ho, Wo, Cout), device=x.device, dtype=torch.float32)
+    y = _empty((B, Ho, Wo, Cout), device=x.device, dtype=torch.float32)
     with _Timed(B * Ho * Wo, Cout, kh * kw * Cin, 0 if plain else 1, 0, nby):
         ws = igemm_workspace(x.device)
         if split:
@@ -286,7 +290,7 @@ def gemm_dual(a, a_absmax, w_plane, w_exp, out_scale, a2, a2_absmax, w2_plane, r
     M, N = a.numel() // K, w_plane.shape[1]
     if a2.numel() // K2 != M:
         raise _lib.DbmmError("gemm_dual: operand row counts differ")
-    c = torch.empty(tuple(a.shape[:-1]) + (N,), device=a.device, dtype=torch.float32)
+    c = _empty(tuple(a.shape[:-1]) + (N,), device=a.device, dtype=torch.float32)
     ws = igemm_workspace(a.device)
     t = _Timed(M, N, K + K2, 0, 0, 4 * (M * K + M * K2 + M * N) + 2 * (N * K + N * K2))
     t.__enter__()
@@ -314,9 +318,9 @@ def bottleneck_chain(y2, y2_absmax, c3, residual, c1, x_absmax=None, y1_absmax=N
     if K not in (64, 128) or N % 64 or P not in (64, 128) or (pooled and (H % 2 or W % 2)):     # shapes the library serves
         return None
     dev = y2.device
-    x = torch.empty((B, H, W, N), device=dev, dtype=torch.float32)
-    y1 = torch.empty((B, H, W, P), device=dev, dtype=torch.float32)
-    xp = torch.empty((B, H // 2, W // 2, N), device=dev, dtype=torch.float32) if pooled else None
+    x = _empty((B, H, W, N), device=dev, dtype=torch.float32)
+    y1 = _empty((B, H, W, P), device=dev, dtype=torch.float32)
+    xp = _empty((B, H // 2, W // 2, N), device=dev, dtype=torch.float32) if pooled else None
     M = B * H * W
     # tagged like an igemm launch for bench.py's per-kernel table: FLOPs of both GEMMs, algorithmic bytes
     global _chain_tag
@@ -354,8 +358,8 @@ def bottleneck_block_chain(y1, y1_absmax, c2, c3, c1, residual=None, dual=None, 
             return None
     elif (K, P) != (64, 64) or dual["ds"]["ph"].shape[0] != 1 or tuple(dual["a2"].shape) != (B, H, W, 64):
         return None
-    x = torch.empty((B, H, W, N), device=y1.device, dtype=torch.float32)
-    y1n = torch.empty((B, H, W, P), device=y1.device, dtype=torch.float32)
+    x = _empty((B, H, W, N), device=y1.device, dtype=torch.float32)
+    y1n = _empty((B, H, W, P), device=y1.device, dtype=torch.float32)
     global _chain_tag
     _chain_tag = f"bottleneck_chain_kernel<{K}, {P}, 0, {int(dual is not None)}, 1>"
     K2 = 64 if dual is not None else 0
@@ -387,8 +391,8 @@ def bottleneck_chain_dual(y2, y2_absmax, c3, a2, a2_absmax, ds, ratio, bias, c1,
     if (c3["ph"].shape[0] != 1 or ds["ph"].shape[0] != 1 or c1["ph"].shape[0] != 1 or a2.numel() // K2 != M
             or K != 64 or K2 != 64 or N % 64 or P not in (64, 128) or M % 4):
         return None
-    x = torch.empty(tuple(y2.shape[:-1]) + (N,), device=y2.device, dtype=torch.float32)
-    y1 = torch.empty(tuple(y2.shape[:-1]) + (P,), device=y2.device, dtype=torch.float32)
+    x = _empty(tuple(y2.shape[:-1]) + (N,), device=y2.device, dtype=torch.float32)
+    y1 = _empty(tuple(y2.shape[:-1]) + (P,), device=y2.device, dtype=torch.float32)
     global _chain_tag
     _chain_tag = f"bottleneck_chain_kernel<{K}, {P}, 0, 1>"
     t = _Timed(M, N, K + K2 + P, -1, 0, 4 * (M * K + M * K2 + M * N + M * P) + 2 * (N * K + N * K2 + P * N))
@@ -411,7 +415,7 @@ def conv_stem_s2(x_nchw, w, bias, y_absmax=None):
     if C != 3:
         raise _lib.DbmmError("stem conv expects 3 input channels")
     Cout = w.shape[-1]
-    y = torch.empty((B, (H - 1) // 2 + 1, (W - 1) // 2 + 1, Cout), device=x_nchw.device, dtype=torch.float32)
+    y = _empty((B, (H - 1) // 2 + 1, (W - 1) // 2 + 1, Cout), device=x_nchw.device, dtype=torch.float32)
     check(_lib.lib().dbmm_conv_stem_s2(ptr(x_nchw), ptr(w), ptr(bias), ptr(y), ptr(y_absmax), B, H, W, Cout, stream()),
           "conv_stem_s2")
     return y
@@ -421,7 +425,7 @@ def avgpool2d(x, k):
     require_cuda(x)
     _f32c(x)
     B, H, W, C = x.shape
-    y = torch.empty((B, H // k, W // k, C), device=x.device, dtype=torch.float32)
+    y = _empty((B, H // k, W // k, C), device=x.device, dtype=torch.float32)
     check(_lib.lib().dbmm_avgpool2d(ptr(x), ptr(y), B, H, W, C, k, stream()), "avgpool2d")
     return y
 
@@ -434,8 +438,8 @@ def attnpool(x, pos, wq, bq, wkv, bkv, wc, bc, heads):
     HW = H * W
     Dout = wc.shape[0]
     nbytes = _lib.lib().dbmm_workspace_bytes_attnpool(B, HW, C)
-    ws = torch.empty(nbytes // 4, device=x.device, dtype=torch.float32)
-    out = torch.empty((B, Dout), device=x.device, dtype=torch.float32)
+    ws = _empty(nbytes // 4, device=x.device, dtype=torch.float32)
+    out = _empty((B, Dout), device=x.device, dtype=torch.float32)
     check(_lib.lib().dbmm_attnpool(ptr(x), ptr(pos), ptr(wq), ptr(bq), ptr(wkv), ptr(bkv), ptr(wc), ptr(bc),
                                    ptr(out), B, HW, C, heads, Dout, ptr(ws), nbytes, stream()), "attnpool")
     return out
@@ -448,7 +452,7 @@ def layernorm(x, gamma, beta, rows=None, ldx=None, eps=1e-5, y_absmax=None):
         rows = x.numel() // E
     if ldx is None:
         ldx = E
-    y = torch.empty((rows, E), device=x.device, dtype=torch.float32)
+    y = _empty((rows, E), device=x.device, dtype=torch.float32)
     check(_lib.lib().dbmm_layernorm(ptr(x), ldx, ptr(gamma), ptr(beta), ptr(y), E, rows, E, eps, ptr(y_absmax), stream()),
           "layernorm")
     return y
@@ -459,7 +463,7 @@ def mha_core(qkv, B, L, E, heads, causal, qkv_absmax=None):
     fp16-pair kernel runs (16-bit matrix cores, three partial products, fp32 accuracy); without it, or with
     DBMM_MHA_X2=0, the fp32-input-MFMA kernel."""
     require_cuda(qkv)
-    out = torch.empty((B * L, E), device=qkv.device, dtype=torch.float32)
+    out = _empty((B * L, E), device=qkv.device, dtype=torch.float32)
     if qkv_absmax is not None and os.environ.get("DBMM_MHA_X2", "1") != "0":
         with _TimedTag("mha_pair_kernel", 4.0 * B * heads * L * L * 64, 4 * (B * L * 4 * E)):
             check(_lib.lib().dbmm_mha_core_x2(ptr(qkv), ptr(qkv_absmax), ptr(out), B, L, E, heads, int(causal), stream()),
@@ -477,7 +481,7 @@ def embed_gather(tokens, table, pos):
     tokens = tokens.contiguous()
     n, L = tokens.shape
     W = table.shape[1]
-    out = torch.empty((n, L, W), device=table.device, dtype=torch.float32)
+    out = _empty((n, L, W), device=table.device, dtype=torch.float32)
     check(_lib.lib().dbmm_embed_gather(ptr(tokens), ptr(table), ptr(pos), ptr(out), n, L, W, table.shape[0], stream()),
           "embed_gather")
     return out, tokens
@@ -489,21 +493,21 @@ def im2col_patch(x_nchw, P, out_absmax=None):
     _f32c(x_nchw)
     B, C, R, _ = x_nchw.shape
     g = R // P
-    out = torch.empty((B * g * g, 3 * P * P), device=x_nchw.device, dtype=torch.float32)
+    out = _empty((B * g * g, 3 * P * P), device=x_nchw.device, dtype=torch.float32)
     check(_lib.lib().dbmm_im2col_patch(ptr(x_nchw), ptr(out), ptr(out_absmax), B, R, P, stream()), "im2col_patch")
     return out
 
 
 def vit_tokens(patches, cls, pos, B):
     L, W = pos.shape
-    out = torch.empty((B, L, W), device=patches.device, dtype=torch.float32)
+    out = _empty((B, L, W), device=patches.device, dtype=torch.float32)
     check(_lib.lib().dbmm_vit_tokens(ptr(patches), ptr(cls), ptr(pos), ptr(out), B, L, W, stream()), "vit_tokens")
     return out
 
 
 def gather_eot(tokens_i32, x):
     n, L, W = x.shape
-    out = torch.empty((n, W), device=x.device, dtype=torch.float32)
+    out = _empty((n, W), device=x.device, dtype=torch.float32)
     check(_lib.lib().dbmm_gather_eot(ptr(tokens_i32), ptr(x), ptr(out), n, L, W, stream()), "gather_eot")
     return out
 
@@ -513,7 +517,7 @@ def text_colnorm(text):
     require_cuda(text)
     _f32c(text)
     D, C = text.shape
-    tn = torch.empty((C, D), device=text.device, dtype=torch.float32)
+    tn = _empty((C, D), device=text.device, dtype=torch.float32)
     check(_lib.lib().dbmm_text_colnorm(ptr(text), ptr(tn), D, C, stream()), "text_colnorm")
     return tn
 
@@ -524,14 +528,14 @@ def l2norm_sim_ce_fwd(z, tn, temperature, labels=None, z_old=None, ebd_weight=0.
     B, D = z.shape
     C = tn.shape[0]
     dev = z.device
-    logits = torch.empty((B, C), device=dev, dtype=torch.float32)
-    inv_norm = torch.empty((B,), device=dev, dtype=torch.float32)
+    logits = _empty((B, C), device=dev, dtype=torch.float32)
+    inv_norm = _empty((B,), device=dev, dtype=torch.float32)
     loss_rows = loss_mean = pred = None
     if labels is not None and want_loss:
-        loss_rows = torch.empty((B,), device=dev, dtype=torch.float32)
-        loss_mean = torch.empty((), device=dev, dtype=torch.float32)
+        loss_rows = _empty((B,), device=dev, dtype=torch.float32)
+        loss_mean = _empty((), device=dev, dtype=torch.float32)
     if want_pred:
-        pred = torch.empty((B,), device=dev, dtype=torch.int64)
+        pred = _empty((B,), device=dev, dtype=torch.int64)
     check(_lib.lib().dbmm_l2norm_sim_ce_fwd(ptr(z), ptr(z_old), float(ebd_weight), ptr(tn), ptr(labels),
                                             float(temperature), ptr(logits), ptr(loss_rows), ptr(loss_mean), ptr(pred),
                                             ptr(inv_norm), B, D, C, stream()), "l2norm_sim_ce_fwd")
@@ -542,7 +546,7 @@ def l2norm_sim_ce_bwd(z, inv_norm, tn, temperature, logits=None, labels=None, dl
                       ebd_weight=0.5, grad_scale=1.0):
     B, D = z.shape
     C = tn.shape[0]
-    dz = torch.empty_like(z)
+    dz = _empty(tuple(z.shape), device=z.device, dtype=z.dtype)
     check(_lib.lib().dbmm_l2norm_sim_ce_bwd(ptr(z), ptr(inv_norm), float(ebd_weight), int(blended), ptr(tn), ptr(logits),
                                             ptr(labels), ptr(dlogits), float(temperature), float(grad_scale), ptr(dz),
                                             B, D, C, stream()), "l2norm_sim_ce_bwd")
@@ -555,11 +559,11 @@ def adapter_fwd(x, w1, b1, gamma, beta, running_mean, running_var, nbt, w2, b2, 
     B, D = x.shape
     H = w1.shape[0]
     dev = x.device
-    h = torch.empty((B, H), device=dev, dtype=torch.float32)
-    r = torch.empty((B, H), device=dev, dtype=torch.float32)
-    z = torch.empty((B, D), device=dev, dtype=torch.float32)
-    mean = torch.empty((H,), device=dev, dtype=torch.float32) if train else None
-    invstd = torch.empty((H,), device=dev, dtype=torch.float32) if train else None
+    h = _empty((B, H), device=dev, dtype=torch.float32)
+    r = _empty((B, H), device=dev, dtype=torch.float32)
+    z = _empty((B, D), device=dev, dtype=torch.float32)
+    mean = _empty((H,), device=dev, dtype=torch.float32) if train else None
+    invstd = _empty((H,), device=dev, dtype=torch.float32) if train else None
     check(_lib.lib().dbmm_adapter_fwd(ptr(x), ptr(w1), ptr(b1), ptr(gamma), ptr(beta), ptr(running_mean),
                                       ptr(running_var), ptr(nbt), ptr(w2), ptr(b2), ptr(h), ptr(mean), ptr(invstd),
                                       ptr(r), ptr(z), B, D, H, int(train), eps, momentum, stream()), "adapter_fwd")
@@ -571,11 +575,11 @@ def adapter_bwd(x, dz, h, mean, invstd, r, gamma, beta, w2):
     H = h.shape[1]
     dev = x.device
     f = dict(device=dev, dtype=torch.float32)
-    dw1, db1 = torch.empty((H, D), **f), torch.empty((H,), **f)
-    dgamma, dbeta = torch.empty((H,), **f), torch.empty((H,), **f)
-    dw2, db2 = torch.empty((D, H), **f), torch.empty((D,), **f)
+    dw1, db1 = _empty((H, D), **f), _empty((H,), **f)
+    dgamma, dbeta = _empty((H,), **f), _empty((H,), **f)
+    dw2, db2 = _empty((D, H), **f), _empty((D,), **f)
     nbytes = _lib.lib().dbmm_workspace_bytes_adapter_bwd(B, D, H)
-    ws = torch.empty(nbytes // 4, **f)
+    ws = _empty(nbytes // 4, **f)
     check(_lib.lib().dbmm_adapter_bwd(ptr(x), ptr(dz), ptr(h), ptr(mean), ptr(invstd), ptr(r), ptr(gamma), ptr(beta),
                                       ptr(w2), ptr(dw1), ptr(db1), ptr(dgamma), ptr(dbeta), ptr(dw2), ptr(db2), B, D, H,
                                       ptr(ws), nbytes, stream()), "adapter_bwd")
@@ -627,13 +631,13 @@ def adapter_train_step(x, labels, new, bufs, old, ebd_weight, tn, temperature, l
     ws = _step_ws.get(key)
     if ws is None:
         nbytes = _lib.lib().dbmm_workspace_bytes_adapter_train_step(B, D, H, int(old is not None))
-        ws = torch.empty(nbytes // 4, device=dev, dtype=torch.float32)
+        ws = _empty(nbytes // 4, device=dev, dtype=torch.float32)
         if len(_step_ws) > 8:
             _step_ws.clear()
         _step_ws[key] = ws
-    logits = torch.empty((B, C), device=dev, dtype=torch.float32)
-    loss_rows = torch.empty((B,), device=dev, dtype=torch.float32)
-    loss_mean = torch.empty((), device=dev, dtype=torch.float32)
+    logits = _empty((B, C), device=dev, dtype=torch.float32)
+    loss_rows = _empty((B,), device=dev, dtype=torch.float32)
+    loss_mean = _empty((), device=dev, dtype=torch.float32)
     o = [ptr(t) for t in old] if old is not None else [None] * 9
     check(_lib.lib().dbmm_adapter_train_step(
         ptr(x), ptr(labels), *[ptr(t) for t in new], *[ptr(t) for t in bufs], *o, float(ebd_weight), ptr(tn),
@@ -647,7 +651,7 @@ def gather_rows(table, idx):
     require_cuda(table, idx)
     _f32c(table)
     idx = idx.contiguous()
-    out = torch.empty((idx.numel(), table.shape[1]), device=table.device, dtype=torch.float32)
+    out = _empty((idx.numel(), table.shape[1]), device=table.device, dtype=torch.float32)
     check(_lib.lib().dbmm_gather_rows(ptr(table), ptr(idx), ptr(out), table.shape[0], idx.numel(), table.shape[1],
                                       stream()), "gather_rows")
     return out
@@ -673,7 +677,7 @@ def gemm_f16(a, w, bias=None, residual=None, act=ACT_NONE, M=None, lda=None):
         lda = a.shape[-1]
     if M is None:
         M = a.numel() // a.shape[-1]
-    c = torch.empty((M, N), device=a.device, dtype=torch.float16)
+    c = _empty((M, N), device=a.device, dtype=torch.float16)
     deep = N % 256 == 0 and K % 128 == 0 and M >= 16384 and os.environ.get("DBMM_F16_8PH", "1") != "0"   # dbmm_gemm_f16's own rule
     with _TimedTag("gemm_f16_8ph_kernel" if deep else "gemm_f16_kernel", 2.0 * M * N * K,
                    2 * (M * K + N * K + M * N * (2 if residual is not None else 1))):
@@ -685,7 +689,7 @@ def gemm_f16(a, w, bias=None, residual=None, act=ACT_NONE, M=None, lda=None):
 def mha_core_f16(qkv, B, L, E, heads, causal):
     require_cuda(qkv)
     _f16c(qkv)
-    out = torch.empty((B * L, E), device=qkv.device, dtype=torch.float16)
+    out = _empty((B * L, E), device=qkv.device, dtype=torch.float16)
     with _TimedTag("mha_f16_kernel", 4.0 * B * heads * L * L * 64, 2 * (B * L * 4 * E)):
         check(_lib.lib().dbmm_mha_core_f16(ptr(qkv), ptr(out), B, L, E, heads, int(causal), stream()), "mha_core_f16")
     return out
@@ -698,7 +702,7 @@ def layernorm_f16(x, gamma, beta, rows=None, ldx=None, eps=1e-5):
         rows = x.numel() // E
     if ldx is None:
         ldx = E
-    y = torch.empty((rows, E), device=x.device, dtype=torch.float16)
+    y = _empty((rows, E), device=x.device, dtype=torch.float16)
     check(_lib.lib().dbmm_layernorm_f16(ptr(x), ldx, ptr(gamma), ptr(beta), ptr(y), E, rows, E, eps, stream()), "layernorm_f16")
     return y
 
@@ -709,7 +713,7 @@ def im2col_patch_f16(x_nchw, P, Kp):
         raise _lib.DbmmError("im2col_patch_f16 needs a contiguous float16 / float32 image batch")
     B, C, R, _ = x_nchw.shape
     g = R // P
-    out = torch.empty((B * g * g, Kp), device=x_nchw.device, dtype=torch.float16)
+    out = _empty((B * g * g, Kp), device=x_nchw.device, dtype=torch.float16)
     check(_lib.lib().dbmm_im2col_patch_f16(ptr(x_nchw), int(x_nchw.dtype == torch.float16), ptr(out), B, R, P, Kp, stream()),
           "im2col_patch_f16")
     return out
@@ -717,7 +721,7 @@ def im2col_patch_f16(x_nchw, P, Kp):
 
 def vit_tokens_f16(patches, cls, pos, B):
     L, W = pos.shape
-    out = torch.empty((B, L, W), device=patches.device, dtype=torch.float16)
+    out = _empty((B, L, W), device=patches.device, dtype=torch.float16)
     check(_lib.lib().dbmm_vit_tokens_f16(ptr(patches), ptr(cls), ptr(pos), ptr(out), B, L, W, stream()), "vit_tokens_f16")
     return out
 
@@ -729,7 +733,7 @@ def embed_gather_f16(tokens, table, pos):
     tokens = tokens.contiguous()
     n, L = tokens.shape
     W = table.shape[1]
-    out = torch.empty((n, L, W), device=table.device, dtype=torch.float16)
+    out = _empty((n, L, W), device=table.device, dtype=torch.float16)
     check(_lib.lib().dbmm_embed_gather_f16(ptr(tokens), ptr(table), ptr(pos), ptr(out), n, L, W, table.shape[0], stream()),
           "embed_gather_f16")
     return out, tokens
@@ -737,7 +741,7 @@ def embed_gather_f16(tokens, table, pos):
 
 def gather_eot_f16(tokens_i32, x):
     n, L, W = x.shape
-    out = torch.empty((n, W), device=x.device, dtype=torch.float16)
+    out = _empty((n, W), device=x.device, dtype=torch.float16)
     check(_lib.lib().dbmm_gather_eot_f16(ptr(tokens_i32), ptr(x), ptr(out), n, L, W, stream()), "gather_eot_f16")
     return out
 

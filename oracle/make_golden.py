@@ -136,6 +136,47 @@ def gen_clip(M, only=None):
         np.savez_compressed(os.path.join(GOLD, "clip_" + arch.replace("/", "-").replace("@", "-") + ".npz"), **out)
 
 
+def gen_clip_f16(M, only=None):
+    """The reference's fp16 path (what `clip.load` leaves on a GPU: `build_model` WITHOUT `.float()`,
+    clip/clip.py:139-141 -- conv / linear / attention weights fp16 via convert_weights, clip/model.py:375-396,433;
+    activations fp16 because encode_image casts the image to `self.dtype`, :341; LayerNorm in fp32 and cast back,
+    :157-163; BatchNorm parameters fp32) run HERE on the CPU, same seeds / inputs as the fp32 fixtures.
+    Writes clip_<arch>_f16.npz: image + text embeddings (fp16 values stored as fp32), RN per-stage samples, and
+    `f16_vs_f32` = the distance of the reference's own fp16 result from its fp32 result (relative to the embedding
+    maximum) -- the size of one rounding history; the tests' tolerance is a small multiple of it."""
+    cases = [("tiny-RN", 3, 2), ("tiny-RN-w32", 3, 2), ("RN50", 2, 2), ("tiny-ViT", 3, 2), ("ViT-B/32", 2, 2),
+             ("ViT-L/14@336px", 2, 1)]
+    if only:
+        cases = [c for c in cases if c[0] in only]
+    for arch, seed, B in cases:
+        sd = synth.clip_state_dict(seed, arch)
+        model = M.build_model({k: v.clone() for k, v in sd.items()}).eval()          # no .float(): the GPU-path dtypes
+        assert model.dtype == torch.float16
+        res = model.visual.input_resolution
+        img = synth.images(seed + 100, B, res)
+        g32 = np.load(os.path.join(GOLD, "clip_" + arch.replace("/", "-").replace("@", "-") + ".npz"))
+        with torch.no_grad():
+            ref = model.encode_image(img)
+            assert ref.dtype == torch.float16
+            out = {"embedding": ref.float().numpy(), "seed": seed, "batch": B, "res": res,
+                   "f16_vs_f32": np.float64(relerr(ref.float(), torch.from_numpy(g32["embedding"])))}
+            if arch.startswith(("RN", "tiny-RN")):
+                v = model.visual
+                x = img.type(v.conv1.weight.dtype)
+                x = v.relu1(v.bn1(v.conv1(x))); x = v.relu2(v.bn2(v.conv2(x))); x = v.relu3(v.bn3(v.conv3(x)))
+                x = v.avgpool(x); rstages = {"stem": x}
+                for li in (1, 2, 3, 4):
+                    x = getattr(v, f"layer{li}")(x); rstages[f"layer{li}"] = x
+                for k, t in rstages.items():
+                    out[f"{k}_sums"], out[f"{k}_sample"] = summary(t.float().permute(0, 2, 3, 1))  # NHWC order
+            toks = torch.from_numpy(g32["tokens"])
+            tref = model.encode_text(toks)
+            out["tokens"] = toks.numpy(); out["text_embedding"] = tref.float().numpy()
+            out["text_f16_vs_f32"] = np.float64(relerr(tref.float(), torch.from_numpy(g32["text_embedding"])))
+        print(f"[clip f16] {arch:14s} image f16-vs-f32 {out['f16_vs_f32']:.2e}  text {out['text_f16_vs_f32']:.2e}")
+        np.savez_compressed(os.path.join(GOLD, "clip_" + arch.replace("/", "-").replace("@", "-") + "_f16.npz"), **out)
+
+
 def gen_tokens():
     T = ref_tokenizer()
     tok = T.SimpleTokenizer()
@@ -432,13 +473,17 @@ def gen_fp16_keys(M):
 
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ["clip", "tokens", "adapter", "adapter_vit", "indices", "ckpt", "fp16keys", "split", "lr"]
+    which_all = ["clip", "clip_vitl", "clip_f16", "tokens", "adapter", "adapter_vit", "indices", "ckpt", "fp16keys", "split", "lr"]
+    which = [a for a in sys.argv[1:] if a in which_all] or ["clip", "clip_f16", "tokens", "adapter", "adapter_vit", "indices", "ckpt",
+                                                              "fp16keys", "split", "lr"]
     if "fp16keys" in which:
         gen_fp16_keys(ref_model_module())
     if "clip" in which:
         gen_clip(ref_model_module())
     if "clip_vitl" in which:                      # only the full-depth ViT-L/14@336px case (minutes on CPU)
         gen_clip(ref_model_module(), only=("ViT-L/14@336px",))
+    if "clip_f16" in which:                       # the reference's fp16 path on the CPU (needs the fp32 fixtures above)
+        gen_clip_f16(ref_model_module(), only=[a for a in sys.argv[1:] if a not in which_all] or None)
     if "split" in which:
         gen_split()
     if "lr" in which:

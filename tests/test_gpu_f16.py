@@ -1,13 +1,14 @@
-"""fp16 throughput mode of the transformer towers (csrc/f16_ops.hip; the reference's GPU path, convert_weights +
-fp16 activations, clip/model.py:157-163, 375-396).
+"""fp16 throughput mode (csrc/f16_ops.hip; the reference's GPU path, convert_weights + fp16 activations,
+clip/model.py:146, 157-163, 341, 375-396).
 
-PARITY UNPINNED vs the reference's fp16 path: that path only runs on a GPU the reference never had here, so no fixture
-of it exists.  What is pinned instead:
-  * every fp16 kernel against an fp64 evaluation of the same op on the SAME fp16-rounded inputs -- the only differences
-    are fp32 accumulation order and the single fp16 rounding of the stored result (2^-11 relative);
-  * whole towers against the reference-generated fp32 goldens at a tolerance that follows from fp16 storage of the
-    activations: about 2^-11 relative per stored tensor, accumulating over 2 x layers residual updates; measured
-    1-3e-3 of the embedding maximum, bound set at 1e-2, cosine to the fp32 embedding > 0.9999."""
+Pinned to the reference's OWN fp16 path: oracle/make_golden.py builds the reference model without `.float()` (fp16
+weights and activations, fp32 LayerNorm statistics, fp32 BatchNorm parameters) and runs it on the build container's
+CPU; tests/golden/clip_<arch>_f16.npz hold its image / text embeddings and `f16_vs_f32`, the distance of that fp16
+result from the reference's fp32 result.  Two fp16 evaluations of the same network differ by their rounding histories
+(where a tensor is rounded to fp16, the order of the fp32 accumulation), i.e. by about sqrt(2) x that distance; the
+tower tests hold the HIP path to 3 x `f16_vs_f32` (2.4e-3 ... 3.3e-3 of the embedding maximum) and print what they
+measured.  Kernel tests: every fp16 kernel against an fp64 evaluation of the same op on the SAME fp16-rounded inputs --
+the only differences are fp32 accumulation order and the single fp16 rounding of the stored result (2^-11 relative)."""
 import numpy as np
 import pytest
 import torch
@@ -117,25 +118,36 @@ def test_layernorm_f16(rows, E):
         assert relerr(strided.double().cpu(), F.layer_norm(x[:, :64].double(), (64,), ga[:64].double(), be[:64].double(), 1e-5).cpu()) < 1e-3
 
 
+def gname16(arch):
+    return gname(arch).replace(".npz", "_f16.npz")
+
+
 @pytest.mark.parametrize("arch", ["tiny-ViT", "ViT-B/32", "ViT-L/14@336px"])
-def test_fp16_mode_towers_vs_fp32_goldens(arch, golden):
-    g = golden(gname(arch))
-    seed, B, res = int(g["seed"]), int(g["batch"]), int(g["res"])
+def test_fp16_mode_towers_vs_reference_fp16_path(arch, golden):
+    g, h = golden(gname(arch)), golden(gname16(arch))
+    seed, B, res = int(h["seed"]), int(h["batch"]), int(h["res"])
     model = convert_weights(build_model(synth.clip_state_dict(seed, arch)).cuda())
     assert model.dtype == torch.float16
     img = synth.images(seed + 100, B, res).cuda()
     out = model.encode_image(img)
-    assert out.dtype == torch.float16 and tuple(out.shape) == g["embedding"].shape
-    ref = torch.from_numpy(g["embedding"])
-    assert relerr(out.float().cpu(), ref) < 1e-2
-    assert F.cosine_similarity(out.float().cpu(), ref, dim=1).min() > 0.9999
-    txt = model.encode_text(torch.from_numpy(g["tokens"]).cuda())
-    tref = torch.from_numpy(g["text_embedding"])
-    assert txt.dtype == torch.float16 and relerr(txt.float().cpu(), tref) < 1e-2
-    assert F.cosine_similarity(txt.float().cpu(), tref, dim=1).min() > 0.9999
+    assert out.dtype == torch.float16 and tuple(out.shape) == h["embedding"].shape
+    ref16, ref32 = torch.from_numpy(h["embedding"]), torch.from_numpy(g["embedding"])
+    tol = 3.0 * float(h["f16_vs_f32"])
+    e16, e32 = relerr(out.float().cpu(), ref16), relerr(out.float().cpu(), ref32)
+    print(f"{arch}: image vs reference fp16 path {e16:.2e} (tol {tol:.2e}), vs fp32 golden {e32:.2e}")
+    assert e16 < tol, f"{arch}: image embedding {e16:.2e} from the reference's fp16 path (tolerance {tol:.2e})"
+    assert e32 < tol, f"{arch}: image embedding {e32:.2e} from the fp32 golden (tolerance {tol:.2e})"
+    assert F.cosine_similarity(out.float().cpu(), ref16, dim=1).min() > 0.99999
+    txt = model.encode_text(torch.from_numpy(h["tokens"]).cuda())
+    tref16 = torch.from_numpy(h["text_embedding"])
+    ttol = 3.0 * float(h["text_f16_vs_f32"])
+    t16 = relerr(txt.float().cpu(), tref16)
+    print(f"{arch}: text vs reference fp16 path {t16:.2e} (tol {ttol:.2e})")
+    assert txt.dtype == torch.float16 and t16 < ttol, f"{arch}: text embedding {t16:.2e} (tolerance {ttol:.2e})"
+    assert F.cosine_similarity(txt.float().cpu(), tref16, dim=1).min() > 0.99999
     # back to the parity mode
     model.float()
-    assert model.dtype == torch.float32 and relerr(model.encode_image(img).cpu(), ref) < 5e-5
+    assert model.dtype == torch.float32 and relerr(model.encode_image(img).cpu(), ref32) < 5e-5
 
 
 def test_fp16_mode_rn_tower_rounds_its_fp32_accurate_output():
@@ -163,7 +175,7 @@ def test_model_half_is_the_same_mode_as_convert_weights(golden):
     b = m.encode_image(img)
     t = m.encode_text(torch.from_numpy(g["tokens"]).cuda())
     assert b.dtype == torch.float16 and relerr(b.float().cpu(), a.float().cpu()) < 5e-3
-    assert relerr(t.float().cpu(), torch.from_numpy(g["text_embedding"])) < 1e-2
+    assert relerr(t.float().cpu(), torch.from_numpy(golden(gname16(arch))["text_embedding"])) < 5e-3
     # fp16 input images are accepted as they are (the reference casts the image to model.dtype, clip/model.py:341)
     c = m.encode_image(img.half())
     assert relerr(c.float().cpu(), b.float().cpu()) < 5e-3
