@@ -22,7 +22,11 @@ Besides the contract line, rank 0 reports
                 top kernel is reported against its own binding roof: `bound` = whichever of algorithmic
                 FLOPs / MFMA peak and algorithmic bytes / 8 TB/s is the larger time; `kernels` holds the same
                 for the top five.  `traffic` / `mfma_busy` / `hbm_tbps` come from the committed rocprofv3 PMC
-                passes of this command (profiles/r02_pmc.json), when they match this configuration.
+                passes of this command (profiles/r0N_pmc.json) when they match this configuration AND the
+                kernel's sources still hash to the value stamped there.
+  extra_legs    N = 1 only: the other configurations, each measured the same way in the same process:
+                RN50 bs = 512 (the per-GPU-batch-matched baseline of the N >= 2 lines), RN50 in fp16 mode,
+                ViT-B/32 parity + fp16, ViT-L/14@336px fp16, and the adapter-only train step at bs 256 / 1024.
   cpu_baseline  the oracle (torch-CPU restatement, proved == reference) on the host cores, bounded sample,
                 N = 1 only
 """
@@ -160,7 +164,7 @@ def cpu_baseline(sd, D, paths_unused, bs=32, iters=3):
             "sample": f"oracle (torch-CPU fp32) RN50 encode_image + adapter step, bs={bs}, median of {iters}"}
 
 
-def build_step(arch, dev, world, rank, Bl, D_hidden=128, dtype="f32"):
+def build_step(arch, dev, world, rank, Bl, D_hidden=128, dtype="f32", micro_batches=1):
     sd = synth.clip_state_dict(2, arch)
     model = build_model(sd).to(dev)
     if dtype == "f16":
@@ -172,7 +176,144 @@ def build_step(arch, dev, world, rank, Bl, D_hidden=128, dtype="f32"):
     clf = adapter.CustomCLIP(ad, *paths, temperature=0.01).to(dev).train()
     from types import SimpleNamespace
     opt = optim.set_optimizer(SimpleNamespace(learning_rate=0.1, momentum=0.9, weight_decay=5e-5), clf)
-    return sd, model, D, R, paths, dp.EmbedAdapterStep(model.encode_image, clf, opt)
+    return sd, model, D, R, paths, dp.EmbedAdapterStep(model.encode_image, clf, opt, micro_batches=micro_batches)
+
+
+def synthetic_batch(R, Bl, world, rank, dev):
+    """this rank's shard of the global synthetic batch (rows [rank*Bl, (rank+1)*Bl)) + its labels, resident in HBM"""
+    base = synth.images(1000 + rank, min(Bl, 64), R)
+    reps = (Bl + base.shape[0] - 1) // base.shape[0]
+    scale = torch.linspace(0.8, 1.2, reps).repeat_interleave(base.shape[0])[:Bl].view(-1, 1, 1, 1)
+    images = (base.repeat(reps, 1, 1, 1)[:Bl] * scale).to(dev).contiguous()
+    y, c, g = synth.labels(6, Bl * world)
+    lo, hi = dp.shard_rows(Bl * world, world, rank)
+    return images, y[lo:hi].to(dev), g[lo:hi].to(dev)
+
+
+def pmc_table(arch, Bl, dtype):
+    """committed rocprofv3 --pmc passes of this configuration (newest profiles/r0N_pmc*.json that matches); every kernel's
+    counters are stamped with the hash of the sources that define it and dropped here when those changed since"""
+    import glob
+    from dbmm_amd import _lib
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*_pmc*.json")), reverse=True):
+        try:
+            pmc = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        if pmc.get("arch") != arch or pmc.get("batch_per_gpu") != Bl or pmc.get("dtype", "f32") != dtype:
+            continue
+        kept = {k: v for k, v in pmc.get("kernels", {}).items()
+                if v.get("source_hash") and v["source_hash"] == _lib.kernel_source_hash(k)}
+        return {"kernels": kept, "file": os.path.relpath(path, ROOT), "dropped_stale": len(pmc.get("kernels", {})) - len(kept)}
+    return None
+
+
+def roofline_of(prof, steps, step_ms, value, world, arch, pmc):
+    rows = kernel_rows(prof, steps, step_ms, pmc)
+    top = rows[0] if rows else {"kernel": None, "bound": "hbm", "achieved": 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                "frac": 0.0, "traffic": None}
+    all_fl = sum(v[1] for v in prof.values()); all_ms = sum(v[2] for v in prof.values()); all_by = sum(v[3] for v in prof.values())
+    roof = {k: top.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "share_of_step",
+                                    "launches_per_step", "avg_launch_ms", "flops_per_launch", "bytes_per_launch",
+                                    "frac_of_mfma_roof", "frac_of_hbm_roof", "traffic_over_algorithmic", "mfma_busy",
+                                    "hbm_tbps")}
+    roof["how"] = ("kernel = largest measured time share among the timed launches (HIP events on the launch stream inside "
+                   "the timed region); achieved = algorithmic bytes (operands read once, outputs written once) or "
+                   "2*M*N*K FLOPs / measured time; bound = the larger of bytes/8 TB/s and FLOPs/(2500 TF / partial "
+                   "products per fp32 product); traffic / mfma_busy / hbm_tbps from the committed rocprofv3 --pmc passes "
+                   + (f"({pmc['file']}, {pmc['dropped_stale']} kernels dropped: sources changed since)" if pmc else "(none match)"))
+    roof["kernels"] = rows[:5]
+    roof["timed_launches"] = {"ms_per_step": round(all_ms / steps, 3), "share_of_step": round(all_ms / (step_ms * steps), 4),
+                              "algorithmic_tflops": round(all_fl / (all_ms * 1e-3) / 1e12, 2) if all_ms else 0.0,
+                              "algorithmic_gbs": round(all_by / (all_ms * 1e-3) / 1e9, 1) if all_ms else 0.0}
+    if arch in GFLOP_PER_IMG:
+        tf = value / world * GFLOP_PER_IMG[arch] * 1e9 / 1e12
+        roof["end_to_end_algorithmic_tflops"] = round(tf, 1)
+        roof["end_to_end_over_fp32_mfma_peak"] = round(tf / FP32_MFMA_PEAK_TFLOPS, 4)
+    return roof
+
+
+DTYPE_DETAIL = {
+    "f16": ("fp16 weights and activations in HBM, one fp16 MFMA per product, fp32 accumulate, fp32 LayerNorm / softmax / "
+            "BatchNorm arithmetic (the reference's GPU path); adapter step in fp32 on the .float() embeddings; pinned to the "
+            "reference's own fp16 path run on CPU (tests/golden/clip_*_f16.npz) at 3 x its fp16-vs-fp32 distance"),
+    "f32": ("fp32 activations/accumulators; products on 16-bit MFMA as fp16 hi+lo pair (22-bit mantissa, exact per-tensor "
+            "power-of-two scale) x fp16-exact checkpoint weight; parity suite at 1e-3 logits"),
+}
+
+
+def timed_steps(stepper, images, y_l, g_l, steps, warmup, barrier, profiling):
+    for _ in range(warmup):
+        stepper.step(images, y_l, g_l)
+    barrier()
+    if profiling:
+        ops.profile_begin(conv_only=False)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss, logits, emb = stepper.step(images, y_l, g_l)
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = ops.profile_end() if profiling else {}
+    if not torch.isfinite(loss).item():
+        raise SystemExit("non-finite loss in the timed region")
+    return dt, prof
+
+
+def extra_leg(arch, dtype, Bl, steps, warmup, dev, note):
+    """one more configuration on this GPU (N = 1), same step, same measurement, reported under `extra_legs`"""
+    t_build = time.perf_counter()
+    sd, model, D, R, paths, stepper = build_step(arch, dev, 1, 0, Bl, dtype=dtype)
+    images, y_l, g_l = synthetic_batch(R, Bl, 1, 0, dev)
+    if dtype == "f16":
+        images = images.half()
+    sync = torch.cuda.synchronize
+    dt, prof = timed_steps(stepper, images, y_l, g_l, steps, warmup, sync, True)
+    value, step_ms = Bl * steps / dt, dt / steps * 1e3
+    roof = roofline_of(prof, steps, step_ms, value, 1, arch, pmc_table(arch, Bl, dtype))
+    keep = ("kernel", "bound", "achieved", "peak", "unit", "frac", "share_of_step", "launches_per_step", "avg_launch_ms",
+            "frac_of_mfma_roof", "frac_of_hbm_roof", "end_to_end_algorithmic_tflops")
+    leg = {"config": {"workload": f"CLIP-{arch} {R}px encode_image + adapter({D}-128-{D}) CE/SGD step, {Bl} images on one GPU ({note})",
+                      "global_batch": Bl, "batch_per_gpu": Bl},
+           "dtype": dtype, "value": round(value, 2), "unit": "images/sec", "steps": steps, "warmup": warmup,
+           "ms_per_step": round(step_ms, 3), "roofline": {k: roof.get(k) for k in keep},
+           "setup_s": round(time.perf_counter() - t_build - dt, 1)}
+    del sd, model, stepper, images
+    torch.cuda.empty_cache()
+    return leg
+
+
+def adapter_only_leg(B, D, dev, steps=200, warmup=20):
+    """BASELINE configs[0]: the adapter-only train step (final_main.py:455-466) on precomputed embeddings resident in HBM:
+    forward, mean CE, backward, SGD as the one-call fused step.  Launch-bound: figure of merit = us/step against
+    (launches x ~1.5 us) and against the algorithmic bytes at 8 TB/s."""
+    from types import SimpleNamespace
+    paths = write_text_jsons(D)
+    ad = adapter.Adapter(D, 128); ad.load_state_dict(synth.adapter_state_dict(3, D, 128))
+    clf = adapter.CustomCLIP(ad, *paths, temperature=0.01).to(dev).train()
+    opt = optim.set_optimizer(SimpleNamespace(learning_rate=0.1, momentum=0.9, weight_decay=5e-5), clf)
+    x = synth.normal(5, f"x{B}", (B, D), 0.5).to(dev)
+    y, c, g = (t.to(dev) for t in synth.labels(6, B))
+    for _ in range(warmup):
+        clf.train_step(x, y, opt)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss, logits, rows = clf.train_step(x, y, opt)
+    torch.cuda.synchronize()
+    us = (time.perf_counter() - t0) / steps * 1e6
+    if not torch.isfinite(loss).item():
+        raise SystemExit("non-finite adapter loss")
+    P, C = 2 * D * 128 + 3 * 128 + D, 2
+    alg_bytes = 8 * B * D + 4 * B * C + 20 * P                     # SURVEY section 8d
+    launches = getattr(ops, "adapter_step_launches", lambda *a: None)(B, D, 128, False)
+    return {"config": {"workload": f"adapter-only train step (Adapter({D},128) + cosine logits + CE + SGD) on precomputed embeddings, bs={B} "
+                                   "(BASELINE configs[0] shape)", "global_batch": B},
+            "dtype": "f32", "value": round(us, 2), "unit": "us/step", "higher_is_better": False, "samples_per_sec": round(B / us * 1e6, 1),
+            "steps": steps, "launches_per_step": launches,
+            "roofline": {"bound": "hbm", "kernel": "adapter train step (all launches)", "achieved": round(alg_bytes / (us * 1e-6) / 1e9, 2),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg_bytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 5),
+                         "algorithmic_bytes": alg_bytes,
+                         "launch_floor_us": None if launches is None else round(launches * 1.5, 1)}}
 
 
 def main():
@@ -184,10 +325,13 @@ def main():
                     help="default: 1024 at one GPU (the metric's bs=1024), 512 per GPU otherwise (BASELINE configs[2])")
     ap.add_argument("--arch", default="RN50")
     ap.add_argument("--dtype", default="f32", choices=["f32", "f16"],
-                    help="f32 = parity mode (the headline); f16 = the reference's GPU-path arithmetic, transformer towers only "
+                    help="f32 = parity mode (the headline); f16 = the reference's GPU-path arithmetic "
                          "(BASELINE configs[4]: --arch 'ViT-L/14@336px' --dtype f16)")
+    ap.add_argument("--micro-batches", type=int, default=0,
+                    help="encode in k row chunks, each chunk's all-gather in flight while the next encodes (default: 4 when N > 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fp32-mfma-leg", action="store_true")
+    ap.add_argument("--no-extra-legs", action="store_true", help="N = 1: skip the other configurations reported under extra_legs")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -206,20 +350,12 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
-    if args.dtype == "f16" and args.arch.startswith("RN"):
-        raise SystemExit("--dtype f16 serves the transformer towers (ViT-B/32, ViT-L/14@336px)")
     default_bl = {"RN50": 1024 if world == 1 else 512, "ViT-B/32": 512, "ViT-L/14@336px": 1024 if args.dtype == "f16" else 128}
     Bl = args.batch_per_gpu or default_bl.get(args.arch, 512)
     B = Bl * world
-    sd, model, D, R, paths, stepper = build_step(args.arch, dev, world, rank, Bl, dtype=args.dtype)
-    # this rank's shard of the global synthetic batch (rows [rank*Bl, (rank+1)*Bl))
-    base = synth.images(1000 + rank, min(Bl, 64), R)
-    reps = (Bl + base.shape[0] - 1) // base.shape[0]
-    scale = torch.linspace(0.8, 1.2, reps).repeat_interleave(base.shape[0])[:Bl].view(-1, 1, 1, 1)
-    images = (base.repeat(reps, 1, 1, 1)[:Bl] * scale).to(dev).contiguous()
-    y, c, g = synth.labels(6, B)
-    lo, hi = dp.shard_rows(B, world, rank)
-    y_l, g_l = y[lo:hi].to(dev), g[lo:hi].to(dev)
+    micro = args.micro_batches or (4 if world > 1 else 1)
+    sd, model, D, R, paths, stepper = build_step(args.arch, dev, world, rank, Bl, dtype=args.dtype, micro_batches=micro)
+    images, y_l, g_l = synthetic_batch(R, Bl, world, rank, dev)
 
     def barrier():
         if world > 1:
@@ -229,56 +365,26 @@ def main():
                 dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        stepper.step(images, y_l, g_l)
-    barrier()
     # every igemm launch of the timed region is bracketed by HIP events (an event pair is ~4 us of stream time:
-    # ~70 launches per RN50 step = 0.3 ms of a ~38 ms step); DBMM_BENCH_PROFILE=0 times none
+    # ~60 launches per RN50 step = 0.25 ms of a ~30 ms step); DBMM_BENCH_PROFILE=0 times none
     profiling = os.environ.get("DBMM_BENCH_PROFILE", "1") != "0"
-    if profiling:
-        ops.profile_begin(conv_only=False)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss, logits, emb = stepper.step(images, y_l, g_l)
-    barrier()
-    dt = time.perf_counter() - t0
-    prof = ops.profile_end() if profiling else {}
+    dt, prof = timed_steps(stepper, images, y_l, g_l, args.steps, args.warmup, barrier, profiling)
 
     tmax = torch.tensor([dt], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
+    dist_info = None
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        # proof of what ran: the backend torch.distributed reports, its world size, and every rank's device
+        devs = [None] * world
+        dist.all_gather_object(devs, {"rank": rank, "device": torch.cuda.current_device(), "name": torch.cuda.get_device_name(dev_index)})
+        dist_info = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "ranks": devs, "micro_batches": micro,
+                     "gather": "all_gather_into_tensor(async_op) per micro-batch on a side stream, overlapped with the next micro-batch's encode"}
     dt = tmax.item()
-    if not torch.isfinite(loss).item():
-        raise SystemExit("non-finite loss in the timed region")
 
     if rank == 0:
         value = B * args.steps / dt
         step_ms = dt / args.steps * 1e3
-        pmc = None
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc.json")))
-            if pmc.get("arch") != args.arch or pmc.get("batch_per_gpu") != Bl or pmc.get("dtype", "f32") != args.dtype:
-                pmc = None
-        except (OSError, ValueError):
-            pass
-        rows = kernel_rows(prof, args.steps, step_ms, pmc)
-        top = rows[0] if rows else {"kernel": None, "bound": "hbm", "achieved": 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                    "frac": 0.0, "traffic": None}
-        all_fl = sum(v[1] for v in prof.values()); all_ms = sum(v[2] for v in prof.values()); all_by = sum(v[3] for v in prof.values())
-        roof = {k: top.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "share_of_step",
-                                        "launches_per_step", "avg_launch_ms", "flops_per_launch", "bytes_per_launch",
-                                        "frac_of_mfma_roof", "frac_of_hbm_roof", "traffic_over_algorithmic", "mfma_busy",
-                                        "hbm_tbps")}
-        roof["how"] = ("kernel = largest measured time share among all igemm launches (HIP events on the launch stream inside "
-                       "the timed region); achieved = algorithmic bytes (operands read once, outputs written once) or "
-                       "2*M*N*K FLOPs / measured time; bound = the larger of bytes/8 TB/s and FLOPs/(2500 TF / partial "
-                       "products per fp32 product)")
-        roof["kernels"] = rows[:5]
-        roof["timed_igemm_launches"] = {"ms_per_step": round(all_ms / args.steps, 3), "share_of_step": round(all_ms / (dt * 1e3), 4),
-                                        "algorithmic_tflops": round(all_fl / (all_ms * 1e-3) / 1e12, 2) if all_ms else 0.0,
-                                        "algorithmic_gbs": round(all_by / (all_ms * 1e-3) / 1e9, 1) if all_ms else 0.0}
-        roof["end_to_end_over_fp32_mfma_peak"] = round(
-            value / world * GFLOP_PER_IMG.get(args.arch, float("nan")) * 1e9 / (FP32_MFMA_PEAK_TFLOPS * 1e12), 4)
+        roof = roofline_of(prof, args.steps, step_ms, value, world, args.arch, pmc_table(args.arch, Bl, args.dtype))
         cfgs = {("RN50", 1, 1024): "the metric's configuration, CLIP-RN50 224px bs=1024 on one GPU",
                 ("RN50", 1, 512): "BASELINE configs[1]", ("RN50", 2, 512): "BASELINE configs[2]",
                 ("ViT-B/32", 8, 512): "BASELINE configs[3]", ("ViT-L/14@336px", 8, 1024): "BASELINE configs[4]",
@@ -287,13 +393,7 @@ def main():
             "metric": f"images/sec (embed+adapter step), CLIP-{args.arch} {R}px bs={B}", "value": round(value, 2),
             "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(step_ms, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": args.dtype,
-            "dtype_detail": ("fp16 weights and activations in HBM, one fp16 MFMA per product, fp32 accumulate, fp32 LayerNorm / "
-                             "softmax statistics (the reference's GPU path); adapter step in fp32 on the .float() embeddings; "
-                             "pinned to the reference's own fp16 path run on CPU (tests/golden/clip_*_f16.npz) at 3 x its fp16-vs-fp32 distance"
-                             if args.dtype == "f16" else
-                             "fp32 activations/accumulators; products on 16-bit MFMA as fp16 hi+lo pair (22-bit mantissa, "
-                             "exact per-tensor power-of-two scale) x fp16-exact checkpoint weight; parity suite at 1e-3 logits"),
+            "vs_baseline": None, "dtype": args.dtype, "dtype_detail": DTYPE_DETAIL[args.dtype],
             "data": "synthetic",
             "config": {"workload": f"CLIP-{args.arch} {R}px encode_image + adapter({D}-128-{D}) CE/SGD step, {Bl} images/GPU, "
                                    f"global batch {B}" + (f" ({cfgs[(args.arch, world, Bl)]})" if (args.arch, world, Bl) in cfgs else ""),
@@ -301,8 +401,26 @@ def main():
                        "collective": "all_gather(embeddings+labels) per step" if world > 1 else "none"},
             "roofline": roof,
         }
+        if dist_info:
+            line["dist"] = dist_info
+            line["config"]["weak_scaling_note"] = (f"{Bl} images per GPU at every N >= 2; the N = 1 line runs the metric's bs = 1024, and "
+                                                   "carries the per-GPU-batch-matched single-GPU figure as extra_legs.rn50_bs512")
         if world == 1 and not args.no_fp32_mfma_leg and args.arch.startswith("RN") and args.dtype == "f32":
             line["fp32_input_mfma"] = fp32_mfma_leg(args.arch, dev, Bl, images, y_l, g_l)
+        if world == 1 and not args.no_extra_legs and args.arch == "RN50" and args.dtype == "f32" and not args.batch_per_gpu:
+            del stepper, model, images
+            torch.cuda.empty_cache()
+            legs = {}
+            legs["rn50_bs512"] = extra_leg("RN50", "f32", 512, 4, 1, dev, "BASELINE configs[1]; the matched single-GPU baseline "
+                                           "of the N >= 2 lines, which run 512 images per GPU")
+            legs["rn50_f16_bs1024"] = extra_leg("RN50", "f16", 1024, 4, 1, dev, "the metric's batch in the reference's GPU-path arithmetic")
+            legs["vit_b32_f32_bs512"] = extra_leg("ViT-B/32", "f32", 512, 4, 1, dev, "one GPU's share of BASELINE configs[3], parity mode")
+            legs["vit_b32_f16_bs512"] = extra_leg("ViT-B/32", "f16", 512, 4, 1, dev, "one GPU's share of BASELINE configs[3], fp16 mode")
+            legs["vit_l14_336_f16_bs256"] = extra_leg("ViT-L/14@336px", "f16", 256, 2, 1, dev,
+                                                      "BASELINE configs[4]'s tower and arithmetic, a quarter of one GPU's 1024-image share")
+            legs["adapter_only_bs256"] = adapter_only_leg(256, 1024, dev)
+            legs["adapter_only_bs1024"] = adapter_only_leg(1024, 1024, dev)
+            line["extra_legs"] = legs
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(sd, D, paths)
         print(json.dumps(line), flush=True)

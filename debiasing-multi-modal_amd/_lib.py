@@ -22,6 +22,36 @@ def sources():
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
 
 
+# which sources define a kernel family (rocprofv3 / ops profile tag prefix -> files under csrc/): profiles/r0N_pmc.json
+# stamps every kernel's counters with kernel_source_hash(), bench.py drops counters whose stamp no longer matches
+KERNEL_SOURCES = (
+    ("igemm_", ("igemm_f32.hip", "igemm_epilogue.inc", "common.h")),
+    ("bottleneck_chain_kernel", ("bottleneck_chain.hip", "common.h")),
+    ("conv3x3_c32_kernel", ("conv_patch.hip", "common.h")),
+    ("gemm_pair_8ph_kernel", ("gemm_pair_8ph.hip", "common.h")),
+    ("mha_pair_kernel", ("mha_pair.hip", "common.h")),
+    ("gemm_f16", ("f16_ops.hip", "common.h")), ("mha_f16", ("f16_ops.hip", "common.h")), ("layernorm_f16", ("f16_ops.hip", "common.h")),
+    ("conv_f16", ("conv_f16.hip", "common.h")), ("stem_f16", ("conv_f16.hip", "common.h")),
+    ("stem_s2", ("resnet_ops.hip", "common.h")), ("attnpool", ("resnet_ops.hip", "common.h")),
+    ("adapter_step", ("adapter_step.hip", "common.h")),
+)
+
+
+def kernel_source_hash(kernel_name):
+    """sha256 (16 hex digits) of the sources that define `kernel_name`'s family; None for an unknown family"""
+    import hashlib
+    for prefix, files in KERNEL_SOURCES:
+        if kernel_name.startswith(prefix):
+            h = hashlib.sha256()
+            for f in files:
+                path = os.path.join(CSRC, f)
+                if not os.path.exists(path):
+                    return None
+                h.update(open(path, "rb").read())
+            return h.hexdigest()[:16]
+    return None
+
+
 def build(force=False, verbose=False):
     """hipcc --offload-arch=gfx950 -> libdbmm_hip.so (in-tree, so it travels with the repo).  Incremental: a source
     is recompiled when it, a shared header or include/dbmm.h is newer than its object; `force` recompiles all.
@@ -59,6 +89,8 @@ _F, _I, _L, _P, _Z = c_float, c_int, c_int64, c_void_p, c_size_t
 
 # name -> argtypes (restype is int unless listed in _RESTYPES)
 _SIGS = {
+    "dbmm_set_option": [ctypes.c_char_p, _I],
+    "dbmm_get_option": [ctypes.c_char_p, ctypes.POINTER(ctypes.c_int)],
     "dbmm_version": [],
     "dbmm_error_string": [_I],
     "dbmm_conv_bn_act": [_P, _P, _P, _P, _P, _L, _L, _L, _L, _L, _L, _L, _L, _L, _I, _P],
@@ -158,6 +190,7 @@ class DbmmError(RuntimeError):
 
 
 E_UNSUPPORTED = -5      # DBMM_E_UNSUPPORTED: nothing was launched, the caller composes the unfused calls
+E_ALIGN = -2            # DBMM_E_ALIGN
 
 
 def check(rc, what=""):

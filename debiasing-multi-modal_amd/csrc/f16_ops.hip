@@ -846,13 +846,11 @@ extern "C" int dbmm_gemm_f16(const void* a, int64_t lda, const void* w, int64_t 
     p.lda = lda; p.ldw = ldw; p.ldr = ldr; p.ldc = ldc;
     p.a_total = ((M - 1) * lda + K) * 2; p.w_total = ((N - 1) * ldw + K) * 2;
     p.M = (int)M; p.N = (int)N; p.K = (int)K; p.act = act;
-    // developer A/B knobs: DBMM_F16_BK = 32 | 64 (K depth of a chunk), DBMM_F16_BN256 = 0 | 1 (128 x 256 tile for wide GEMMs)
-    static const int bk = [] { const char* e = getenv("DBMM_F16_BK"); return e ? atoi(e) : 64; }();
-    static const int bn256 = [] { const char* e = getenv("DBMM_F16_BN256"); return e ? atoi(e) : 1; }();
-    // DBMM_F16_8PH=0: without the deep-pipelined 256 x 256 kernel (read on every call: the tests compare both)
+    // options: f16_bn256 = 0 | 1 (128 x 256 tile for wide GEMMs), f16_8ph = 0: without the deep-pipelined 256 x 256 kernel
+    // (a 32-deep chunk at four workgroups per CU measured the same as the 64-deep one and is gone)
+    const int bn256 = dbmm_opt(OPT_F16_BN256);
     {
-        const char* e8 = getenv("DBMM_F16_8PH");
-        if ((e8 ? atoi(e8) : 1) && (N % 256) == 0 && (K % 128) == 0 && M >= 16384) {
+        if (dbmm_opt(OPT_F16_8PH) && (N % 256) == 0 && (K % 128) == 0 && M >= 16384) {
             p.tiles_n = (int)(N / 256);
             p.n_tiles = (int)((M + 255) / 256) * p.tiles_n;
             const int grid = p.n_tiles < 256 ? p.n_tiles : 256;   // persistent: one workgroup per CU
@@ -870,7 +868,6 @@ extern "C" int dbmm_gemm_f16(const void* a, int64_t lda, const void* w, int64_t 
     p.tiles_n = (int)((N + bn - 1) / bn);
     p.n_tiles = (int)((M + GBM - 1) / GBM) * p.tiles_n;
     if (wide) hipLaunchKernelGGL((gemm_f16_kernel<32, 256, 2>), dim3(p.n_tiles), dim3(256), 0, (hipStream_t)stream, p);
-    else if (bk == 32) hipLaunchKernelGGL((gemm_f16_kernel<32, 128, 4>), dim3(p.n_tiles), dim3(256), 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL((gemm_f16_kernel<64, 128, 2>), dim3(p.n_tiles), dim3(256), 0, (hipStream_t)stream, p);
     DBMM_CHECK_LAUNCH();
     return DBMM_OK;
@@ -882,18 +879,11 @@ extern "C" int dbmm_mha_core_f16(const void* qkv, void* out, int64_t B, int64_t 
     if (B <= 0 || L <= 0 || E <= 0 || heads <= 0 || B > 65535 || heads > 65535) return DBMM_E_SHAPE;
     if (E != heads * 64) return DBMM_E_UNSUPPORTED;              // head_dim 64 (every CLIP tower)
     if (!dbmm_aligned16(qkv) || !dbmm_aligned16(out)) return DBMM_E_ALIGN;
-    // developer A/B knob, off: 64 queries per wave measured 8 % SLOWER on ViT-L/14@336 (106 -> 115 ms per step of attention):
-    // 256 registers hold occupancy at 2 workgroups per CU where the 32-query form (161 registers) runs 3
-    static const int qt2 = [] { const char* e = getenv("DBMM_MHA_F16_QT2"); return e ? atoi(e) : 0; }();
-    if (qt2 && L > 128) {
-        const dim3 grid((unsigned)((L + 255) / 256), (unsigned)heads, (unsigned)B);
-        hipLaunchKernelGGL(mha_f16_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, (const u16*)qkv, (u16*)out, (int)L, (int)E,
-                           (int)heads, causal ? 1 : 0, 0.125f * 1.4426950408889634f);
-    } else {
-        const dim3 grid((unsigned)((L + 127) / 128), (unsigned)heads, (unsigned)B);
-        hipLaunchKernelGGL(mha_f16_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, (const u16*)qkv, (u16*)out, (int)L, (int)E,
-                           (int)heads, causal ? 1 : 0, 0.125f * 1.4426950408889634f);
-    }
+    // (64 queries per wave measured 8 % slower on ViT-L/14@336 -- 256 registers hold occupancy at 2 workgroups per CU where
+    // this 32-query form, 161 registers, runs 3 -- and is not instantiated)
+    const dim3 grid((unsigned)((L + 127) / 128), (unsigned)heads, (unsigned)B);
+    hipLaunchKernelGGL(mha_f16_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, (const u16*)qkv, (u16*)out, (int)L, (int)E,
+                       (int)heads, causal ? 1 : 0, 0.125f * 1.4426950408889634f);
     DBMM_CHECK_LAUNCH();
     return DBMM_OK;
 }

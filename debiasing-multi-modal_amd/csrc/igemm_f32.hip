@@ -89,11 +89,7 @@ struct IgemmP {
     int epi_direct;                     // epilogue straight from the accumulator layout (igemm_epilogue.inc); DBMM_IGEMM_EPI_DIRECT=0: staged
 };
 
-// read on every call: tests compare the two epilogues in one process
-inline int epi_direct_env() {
-    const char* e = getenv("DBMM_IGEMM_EPI_DIRECT");
-    return e ? atoi(e) : 1;
-}
+inline int epi_direct_env() { return dbmm_opt(OPT_IGEMM_EPI_DIRECT); }
 
 // fp16-pair path: A is scaled by 2^s so that max|A| * 2^s lies in [2^13, 2^14) (fp16 tops out at
 // 65504; the fp32 accumulator is rescaled by 2^-(s + w_exp) in the epilogue -- powers of two,
@@ -1343,8 +1339,7 @@ __global__ __launch_bounds__(256) void igemm_fixup_kernel(const IgemmP p) {
 // FAST loader eligibility (see the header comment); `DBMM_IGEMM_FAST=0` forces the fallback.
 template <int AMODE, int WMODE, int BK>
 bool fast_ok(const IgemmP& p) {
-    static const int allow = [] { const char* e = getenv("DBMM_IGEMM_FAST"); return e ? atoi(e) : 1; }();
-    if (!allow || AMODE == 2 || WMODE != 0 || (p.K % BK) != 0) return false;
+    if (!dbmm_opt(OPT_IGEMM_FAST) || AMODE == 2 || WMODE != 0 || (p.K % BK) != 0) return false;
     if (AMODE == 1 && ((p.Cin % BK) != 0 || p.KH * p.KW > 32)) return false;
     if (AMODE == 1 && p.slab && BK > p.slab) return false;   // a chunk must not straddle taps
     return p.a_bytes != 0 && p.w_bytes != 0;
@@ -1358,10 +1353,7 @@ thread_local int g_last_cfg[11] = {0};
 
 // resident workgroups per CU of the fp16-pair kernels: the 128x128 tile with two W planes is held
 // to 2 by its 64 KB of LDS; with one W plane (48 KB, <= 168 VGPRs) and for the narrower tiles it is 3
-inline int sk_mode_env() {
-    static const int m = [] { const char* e = getenv("DBMM_IGEMM_STREAMK"); return e ? atoi(e) : 1; }();
-    return m;
-}
+inline int sk_mode_env() { return dbmm_opt(OPT_IGEMM_STREAMK); }
 // The split-precision kernels keep 2-4 workgroups resident per CU, which already smooths the tile
 // quantisation the one-round model predicts: a CU that runs a leftover tile alone runs it ~3x
 // faster.  Same-box A/B at B = 512: stream-K was +4..5 % on two layer shapes and -6..-52 % on
@@ -1381,7 +1373,7 @@ int launch_cfg(IgemmP& p, hipStream_t s, int nbatch, void* ws, size_t ws_bytes) 
     p.sk_blocks = 0; p.sk_ws = nullptr;
     // stream-K when whole tiles leave >7 % of the chip idle in the last round and the tile's K
     // loop is long enough to be worth cutting (DBMM_IGEMM_STREAMK=0 disables, =2 forces)
-    static const int sk_mode = sk_mode_env();
+    const int sk_mode = sk_mode_env();
     const int nk = (p.K + BK - 1) / BK;
     const int grid_sk = NUM_CUS * MINB;
     const size_t need = (size_t)grid_sk * 2 * BM * BN * sizeof(float);
@@ -1400,9 +1392,7 @@ int launch_cfg(IgemmP& p, hipStream_t s, int nbatch, void* ws, size_t ws_bytes) 
     }
     if constexpr ((AMODE == 0 || AMODE == 1) && WMODE == 0 && BK == 16 && BM == 128 && (BN == 128 || BN == 64 || BN == 32)) {
         // split-precision path: needs pre-split weights and the FAST loader's preconditions
-        static const int x3_allow = [] { const char* e = getenv("DBMM_IGEMM_X3"); return e ? atoi(e) : 1; }();
-        static const int x2_allow = [] { const char* e = getenv("DBMM_IGEMM_X2"); return e ? atoi(e) : 1; }();
-        static const int x2_bk = [] { const char* e = getenv("DBMM_IGEMM_X2_BK"); return e ? atoi(e) : 32; }();
+        const int x3_allow = dbmm_opt(OPT_IGEMM_X3), x2_allow = dbmm_opt(OPT_IGEMM_X2), x2_bk = dbmm_opt(OPT_IGEMM_X2_BK);
         // 32-deep K chunks (half the barriers) when a chunk never straddles a filter tap
         const bool bk32 = x2_bk == 32 && (p.K % 32) == 0 &&
                           (AMODE == 0 || ((p.Cin % 32) == 0 && (p.slab == 0 || p.slab == 32)));
@@ -1473,19 +1463,12 @@ int launch_cfg(IgemmP& p, hipStream_t s, int nbatch, void* ws, size_t ws_bytes) 
     p.a_absmax = nullptr;
     if constexpr (AMODE != 2 && WMODE == 0) {
         if (fast_ok<AMODE, WMODE, BK>(p)) {
-            static const int dma = [] { const char* e = getenv("DBMM_IGEMM_DMA"); return e ? atoi(e) : 1; }();
-            g_last_cfg[8] = 1; g_last_cfg[10] = dma ? 1 : 0;
-            if (dma) {
-                if (p.sk_blocks)
-                    hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN, AMODE, WMODE, BK, MINB, 1, 1, 1>), grid, dim3(256), 0, s, p);
-                else
-                    hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN, AMODE, WMODE, BK, MINB, 1, 0, 1>), grid, dim3(256), 0, s, p);
-            } else {
-                if (p.sk_blocks)
-                    hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN, AMODE, WMODE, BK, MINB, 1, 1, 0>), grid, dim3(256), 0, s, p);
-                else
-                    hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN, AMODE, WMODE, BK, MINB, 1, 0, 0>), grid, dim3(256), 0, s, p);
-            }
+            // operands reach LDS by `buffer_load ... lds` (the register-staged variant measured the same and is gone)
+            g_last_cfg[8] = 1; g_last_cfg[10] = 1;
+            if (p.sk_blocks)
+                hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN, AMODE, WMODE, BK, MINB, 1, 1, 1>), grid, dim3(256), 0, s, p);
+            else
+                hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN, AMODE, WMODE, BK, MINB, 1, 0, 1>), grid, dim3(256), 0, s, p);
             launched = true;
         }
     }
@@ -1504,15 +1487,12 @@ int launch_cfg(IgemmP& p, hipStream_t s, int nbatch, void* ws, size_t ws_bytes) 
 }
 
 // developer knob: DBMM_IGEMM_BK=32 forces the 64-KB / 2-workgroups-per-CU variants
-inline int forced_bk() {
-    static const int v = [] { const char* e = getenv("DBMM_IGEMM_BK"); return e ? atoi(e) : 0; }();
-    return v;
-}
+inline int forced_bk() { return dbmm_opt(OPT_IGEMM_BK); }
 
 // 3x3 / stride 1 / pad 1 convs on the halo kernel (see igemm_tile_halo).  Returns 1 when it launched.
 template <int BN, int POOL = 0>
 int launch_halo(IgemmP& p, hipStream_t s, void* ws, size_t ws_bytes, int* rc) {
-    constexpr int BM = 128, MB = BN == 32 ? 4 : (BN == 256 ? 2 : 3);   // 37 / 42 / 50 / 67 KB of LDS per workgroup (POOL: + 2 KB)
+    constexpr int BM = 128, MB = BN == 32 ? 4 : 3;   // 37 / 42 / 50 KB of LDS per workgroup (POOL: + 2 KB)
     const int tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = (p.N + BN - 1) / BN;
     p.n_tiles = tiles_m * p.tiles_n;
@@ -1520,7 +1500,7 @@ int launch_halo(IgemmP& p, hipStream_t s, void* ws, size_t ws_bytes, int* rc) {
     const int nu = (p.K / 32 + 5) / 6;
     const bool whole_units = (p.K % 192) == 0;           // stream-K cuts at unit boundaries
     p.sk_blocks = 0; p.sk_ws = nullptr; p.sk_nk = 0;
-    static const int sk_mode = [] { const char* e = getenv("DBMM_IGEMM_STREAMK"); return e ? atoi(e) : 1; }();
+    const int sk_mode = sk_mode_env();
     const int grid_sk = NUM_CUS * MB;
     const size_t need = (size_t)grid_sk * 2 * BM * BN * sizeof(float);
     if (!POOL && sk_mode && whole_units && ws && ws_bytes >= need && dbmm_aligned16(ws) && nu >= 4) {
@@ -1560,16 +1540,7 @@ int launch_halo(IgemmP& p, hipStream_t s, void* ws, size_t ws_bytes, int* rc) {
 // DBMM_IGEMM_HALO_POOL: pooled (2x2-window-major) 3x3 convs on the halo kernel: 0 never, 1 where the 128 x 256
 // per-tap tile does not apply (Cout % 256 != 0: layer 2's first block), 2 (default) every pooled 3x3 conv.
 // RN50, B = 1024, same box: 32.44 k / 32.78 k / 33.34 k images/s for 0 / 1 / 2.
-inline int halo_pool() {   // read on every call: tests compare the variants in one process
-    const char* e = getenv("DBMM_IGEMM_HALO_POOL");
-    return e ? atoi(e) : 2;
-}
-
-// DBMM_IGEMM_HALO256=1: 256-column tiles in the halo kernel for layers with N % 256 == 0 (developer A/B knob)
-inline int halo256() {
-    static const int v = [] { const char* e = getenv("DBMM_IGEMM_HALO256"); return e ? atoi(e) : 0; }();
-    return v;
-}
+inline int halo_pool() { return dbmm_opt(OPT_IGEMM_HALO_POOL); }
 
 template <int AMODE, int WMODE>
 int launch_modes(IgemmP& p, hipStream_t s, int nbatch = 1, void* ws = nullptr, size_t wsb = 0) {
@@ -1577,23 +1548,21 @@ int launch_modes(IgemmP& p, hipStream_t s, int nbatch = 1, void* ws = nullptr, s
     // leave most of the 256 CUs idle (small-M projections).
     const long long t128 = (long long)((p.M + 127) / 128) * ((p.N + 127) / 128) * nbatch;
     if constexpr (AMODE == 1 && WMODE == 0) {
-        // DBMM_IGEMM_HALO=0 selects the per-tap kernel (read on every call: tests compare both in one process)
-        const char* e = getenv("DBMM_IGEMM_HALO");
-        if ((e ? atoi(e) : 1) && nbatch == 1 && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && p.slab == 32 &&
+        // option igemm_halo = 0 selects the per-tap kernel
+        const int use_halo = dbmm_opt(OPT_IGEMM_HALO);
+        if (use_halo && nbatch == 1 && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && p.slab == 32 &&
             p.wh && p.nw == 1 && p.a_absmax && (p.Cin % 32) == 0 && p.a_bytes && p.wh_bytes && (p.N & 3) == 0 &&
             p.pool2 && p.N > 32 && (p.M & 3) == 0 && (p.ldc & 3) == 0 && (!p.res || (p.ldr & 3) == 0) &&
             (halo_pool() == 2 || (halo_pool() == 1 && (p.N % 256) != 0))) {
             int rc = 0;
             if (p.N <= 64 ? launch_halo<64, 1>(p, s, ws, wsb, &rc) : launch_halo<128, 1>(p, s, ws, wsb, &rc)) return rc;
         }
-        if ((e ? atoi(e) : 1) && nbatch == 1 && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && p.slab == 32 &&
+        if (use_halo && nbatch == 1 && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && p.slab == 32 &&
             p.wh && p.nw == 1 && p.a_absmax && !p.pool2 && (p.Cin % 32) == 0 && p.a_bytes && p.wh_bytes &&
             (p.N & 3) == 0) {
             int rc = 0;
             if (p.N <= 32 ? launch_halo<32>(p, s, ws, wsb, &rc)
-                          : (p.N <= 64 ? launch_halo<64>(p, s, ws, wsb, &rc)
-                                       : (halo256() && (p.N % 256) == 0 ? launch_halo<256>(p, s, ws, wsb, &rc)
-                                                                        : launch_halo<128>(p, s, ws, wsb, &rc))))
+                          : (p.N <= 64 ? launch_halo<64>(p, s, ws, wsb, &rc) : launch_halo<128>(p, s, ws, wsb, &rc)))
                 return rc;
         }
     }
@@ -1685,8 +1654,7 @@ int gemm_impl(const float* a, int64_t lda, int trans_a, const float* w, int64_t 
         // shapes 0.83 - 1.0 x): its in-order prefetch is four to five phases deep and a tile's first round trip is exposed.
         // DBMM_GEMM_8PH = 0 never, 1 (default) by that rule, 2 wherever the kernel applies (the tests run all three).
         {
-            const char* e8 = getenv("DBMM_GEMM_8PH");
-            const int m8 = e8 ? atoi(e8) : 1;
+            const int m8 = dbmm_opt(OPT_GEMM_8PH);
             const bool pays = m8 == 2 || (m8 == 1 && ((N >= 3072 && K >= 1024) || K >= 4096));
             if (pays && p.wh && p.nw == 1 && p.a_absmax && (N % 256) == 0 && (K % 64) == 0 && M >= 16384 && (lda & 3) == 0 &&
                 (ldw & 7) == 0 && dbmm_aligned16(c) && (!residual || dbmm_aligned16(residual)) && 256 * (lda > ldc ? lda : ldc) * 4 < 0x7FFFFFF0LL &&
@@ -1700,7 +1668,7 @@ int gemm_impl(const float* a, int64_t lda, int trans_a, const float* w, int64_t 
                 if (rc != DBMM_E_UNSUPPORTED) return rc;
             }
         }
-        static const int bn256 = [] { const char* e = getenv("DBMM_IGEMM_BN256"); return e ? atoi(e) : 1; }();
+        const int bn256 = dbmm_opt(OPT_IGEMM_BN256);
         if (bn256 && p.wh && p.nw == 1 && p.a_absmax && p.a_bytes && (K % 32) == 0 && N >= 768 && (N % 256) == 0 && M >= 8192 &&
             (ldc & 3) == 0 && (!residual || (ldr & 3) == 0)) {
             p.tiles_n = (int)(N / 256);
@@ -1756,29 +1724,15 @@ int conv_impl(const float* x, const float* w, const float* bias, const float* re
     }
     hipStream_t s = (hipStream_t)stream;
     if (KH == 1 && KW == 1 && stride == 1 && pad == 0) {                                           // plain GEMM
-        // developer A/B knob: the 128 x 256 tile (see gemm_impl) for wide 1x1 convs.  Off by default: measured on RN50
-        // layers 3-4 at B = 1024 it is neutral (32.7 k vs 32.7-32.8 k images/s): residual epilogue of a 128-register tile, fewer tiles per round.
-        static const int bn256 = [] { const char* e = getenv("DBMM_IGEMM_BN256_CONV"); return e ? atoi(e) : 0; }();
-        // bn256: 1 = every 1x1 conv with Cout % 256 == 0, 2 = only the deep-K ones (K >= 512: conv1 of layers 3-4)
-        if (bn256 && !p.pool2 && p.wh && p.nw == 1 && p.a_absmax && p.a_bytes && (K % 32) == 0 && (Cout % 256) == 0 &&
-            (bn256 == 1 || K >= 512) && M >= 8192) {
-            p.tiles_n = (int)(Cout / 256);
-            p.n_tiles = (int)((M + 127) / 128) * p.tiles_n;
-            hipLaunchKernelGGL((igemm_x3_kernel<128, 256, 2, 2, 0, 2, 0, 2, 1, 32>), dim3(p.n_tiles), dim3(256), 0, s, p);
-            const int c[11] = {128, 256, 2, 2, 0, 0, 32, 2, 2, 0, 1};
-            for (int i = 0; i < 11; ++i) g_last_cfg[i] = c[i];
-            DBMM_CHECK_LAUNCH();
-            return DBMM_OK;
-        }
+        // (the 128 x 256 tile of gemm_impl was measured here too, on RN50 layers 3-4 at B = 1024: neutral, not kept)
         return launch_modes<0, 0>(p, s, 1, ws, wsb);
     }
     {
         // KxK convs that the halo kernel does not take (pooled 3x3 convs under DBMM_IGEMM_HALO_POOL < 2, strided or
         // larger windows) with >= 256 output channels: the 128 x 256 tile halves the per-FLOP cost of the gather + split
         // of the activations, which is what bounds the per-tap kernel.  DBMM_IGEMM_BN256_KXK=0 disables.
-        static const int bn256 = [] { const char* e = getenv("DBMM_IGEMM_BN256_KXK"); return e ? atoi(e) : 1; }();
-        const char* he = getenv("DBMM_IGEMM_HALO");
-        const bool halo_takes_it = (he ? atoi(he) : 1) && KH == 3 && KW == 3 && stride == 1 && pad == 1 &&
+        const int bn256 = dbmm_opt(OPT_IGEMM_BN256_KXK);
+        const bool halo_takes_it = dbmm_opt(OPT_IGEMM_HALO) && KH == 3 && KW == 3 && stride == 1 && pad == 1 &&
                                    (!p.pool2 || halo_pool() == 2);
         const bool pool_ok = !p.pool2 || ((Cout & 3) == 0 && (!residual || true));
         if (bn256 && !halo_takes_it && p.wh && p.nw == 1 && p.a_absmax && p.a_bytes && p.slab == 32 && (Cin % 32) == 0 && KH * KW <= 32 &&
@@ -1963,7 +1917,7 @@ extern "C" int dbmm_gemm_dual_bn_act_x2(const float* a, int64_t lda, const float
     p.n_tiles = ((p.M + BM - 1) / BM) * p.tiles_n;
     if (p.n_tiles < 192) return DBMM_E_UNSUPPORTED;
     const int nk = (int)(K / 32 + K2 / 32);
-    static const int sk_mode = [] { const char* e = getenv("DBMM_IGEMM_STREAMK"); return e ? atoi(e) : 1; }();
+    const int sk_mode = sk_mode_env();
     const int grid_sk = NUM_CUS * MB;
     const size_t need = (size_t)grid_sk * 2 * BM * BN * sizeof(float);
     if (sk_mode && workspace && workspace_bytes >= need && dbmm_aligned16(workspace) && nk >= 8) {

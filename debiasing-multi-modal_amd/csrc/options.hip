@@ -1,0 +1,78 @@
+// Library options (include/dbmm.h: dbmm_set_option / dbmm_get_option).
+//
+// Every switch the kernels' launchers consult lives in ONE table, read with dbmm_opt(id): no getenv on a launch path.
+// A C caller sets an option by name; for developer A/B runs each option is seeded ONCE, when the library is loaded, from
+// the environment variable DBMM_<NAME IN UPPER CASE> if that is set.  Defaults are the measured best; no option changes
+// results beyond fp32 rounding (DESIGN.md "Switches").
+#include <atomic>
+#include <ctype.h>
+#include <stdlib.h>
+#include <string.h>
+#include "common.h"
+
+namespace {
+
+struct OptDef { const char* name; int def; };
+// order = enum DbmmOpt (common.h)
+const OptDef kOpts[DBMM_OPT_COUNT] = {
+    {"igemm_epi_direct", 1},   // fp16-pair kernels: epilogue straight from the accumulator layout (0: staged through LDS)
+    {"igemm_fast", 1},         // buffer-load operand loader (0: guarded global loads)
+    {"igemm_streamk", 1},      // 0 never / 1 where a grid cannot fill the resident slots / 2 always
+    {"igemm_x3", 1},           // bf16-triple kernels when bf16 planes are given
+    {"igemm_x2", 1},           // fp16-pair kernels when fp16 planes + a_absmax are given
+    {"igemm_x2_bk", 32},       // K depth of the fp16-pair chunks (16 | 32)
+    {"igemm_bk", 0},           // 32: force the 64-KB fp32-MFMA tiles
+    {"igemm_halo", 1},         // stride-1 3x3 convs on the halo kernel (0: per-tap kernel)
+    {"igemm_halo_pool", 2},    // pooled 3x3 convs on the window-major halo kernel: 0 never / 1 where Cout % 256 != 0 / 2 all
+    {"igemm_bn256", 1},        // 128x256 tiles for wide GEMMs
+    {"igemm_bn256_kxk", 1},    // ... and for pooled KxK convs that are not on the halo kernel
+    {"gemm_8ph", 1},           // parity GEMMs on gemm_pair_8ph_kernel: 0 never / 1 where it measured ahead / 2 wherever it applies
+    {"f16_8ph", 1},            // fp16 GEMMs on the deep-pipelined 256x256 kernel
+    {"f16_bn256", 1},          // fp16 GEMMs: 128x256 tiles for wide N
+    {"stem_mfma", 1},          // stride-2 stem conv on the MFMA gather kernel (0: FMA kernels)
+    {"mha_valu", 0},           // 1: lane-per-query attention kernel instead of the MFMA one
+    {"conv_patch", 1},         // (host wrappers) 32-channel stem convs on the persistent patch kernel
+    {"mha_x2", 1},             // (host wrappers) parity attention core on fp16-pair products
+    {"adapter_step_fused", 1}, // adapter train step as the single cooperative launch where it applies (0: the multi-launch step)
+    {"conv_f16_halo", 1},      // fp16 mode: 3x3 convs on the strip-reuse kernel (0: per-tap)
+};
+
+std::atomic<int> g_val[DBMM_OPT_COUNT];
+
+struct Seed {
+    Seed() {
+        for (int i = 0; i < DBMM_OPT_COUNT; ++i) {
+            char env[64] = "DBMM_";
+            size_t n = strlen(env);
+            for (const char* c = kOpts[i].name; *c && n + 1 < sizeof(env); ++c) env[n++] = (char)toupper((unsigned char)*c);
+            env[n] = 0;
+            const char* e = getenv(env);
+            g_val[i].store(e ? atoi(e) : kOpts[i].def, std::memory_order_relaxed);
+        }
+    }
+} g_seed;
+
+int find(const char* name) {
+    if (!name) return -1;
+    for (int i = 0; i < DBMM_OPT_COUNT; ++i)
+        if (!strcmp(name, kOpts[i].name)) return i;
+    return -1;
+}
+
+}  // namespace
+
+int dbmm_opt(int id) { return g_val[id].load(std::memory_order_relaxed); }
+
+extern "C" int dbmm_set_option(const char* name, int value) {
+    const int i = find(name);
+    if (i < 0) return DBMM_E_ARG;
+    g_val[i].store(value, std::memory_order_relaxed);
+    return DBMM_OK;
+}
+
+extern "C" int dbmm_get_option(const char* name, int* value) {
+    const int i = find(name);
+    if (i < 0 || !value) return DBMM_E_ARG;
+    *value = g_val[i].load(std::memory_order_relaxed);
+    return DBMM_OK;
+}

@@ -418,9 +418,8 @@ extern "C" int dbmm_conv_stem_s2(const float* x_nchw, const float* w, const floa
     const dim3 g((unsigned)((M + 255) / 256));
     hipStream_t s = (hipStream_t)stream;
 #define DBMM_STEM(C) hipLaunchKernelGGL(stem_s2_kernel<C>, g, dim3(256), 0, s, x_nchw, w, bias, y_nhwc, y_absmax, (int)B, (int)H, (int)W, (int)Ho, (int)Wo)
-    // DBMM_STEM_MFMA=0: the FMA kernels (read on every call: the tests compare both)
-    const char* e = getenv("DBMM_STEM_MFMA");
-    if ((e ? atoi(e) : 1) && (Cout == 32 || Cout == 64) && 3 * H * W * 8 < 0x7FFFFFF0LL && (M + 31) / 32 <= INT32_MAX) {
+    // option stem_mfma = 0: the FMA kernels
+    if (dbmm_opt(OPT_STEM_MFMA) && (Cout == 32 || Cout == 64) && 3 * H * W * 8 < 0x7FFFFFF0LL && (M + 31) / 32 <= INT32_MAX) {
         const int n_blocks = (int)((M + 31) / 32);
         const int wgs = (n_blocks + 3) / 4 < 256 * 8 ? (n_blocks + 3) / 4 : 256 * 8;
         if (Cout == 32)

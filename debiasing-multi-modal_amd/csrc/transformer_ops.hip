@@ -485,8 +485,8 @@ extern "C" int dbmm_mha_core(const float* qkv, float* out, int64_t B, int64_t L,
     if (!qkv || !out) return DBMM_E_ARG;
     if (B <= 0 || L <= 0 || heads <= 0 || E != heads * 64 || B > 65535 || heads > 65535) return DBMM_E_SHAPE;
     if (!dbmm_aligned16(qkv) || !dbmm_aligned16(out)) return DBMM_E_ALIGN;
-    // matrix-core kernel by default; DBMM_MHA_VALU=1 selects the lane-per-query VALU kernel (ablation)
-    static const int valu = [] { const char* e = getenv("DBMM_MHA_VALU"); return e ? atoi(e) : 0; }();
+    // matrix-core kernel by default; option mha_valu = 1 selects the lane-per-query VALU kernel (ablation)
+    const int valu = dbmm_opt(OPT_MHA_VALU);
     const dim3 grid((unsigned)((L + 63) / 64), (unsigned)heads, (unsigned)B);
     const int qt = (int)((L + 63) / 64);
     if (valu)

@@ -7,6 +7,11 @@ reference), so each rank all-gathers the per-rank embeddings [B_l, D] and labels
 RCCL/xGMI and then runs the identical full-batch adapter step redundantly: parameters stay
 bit-identical on every rank by construction -- no gradient all-reduce, no SyncBN, and the
 N-GPU result equals the 1-GPU result.  Rank-major gather order = the original row order.
+
+Overlap (BASELINE configs[3], "overlap all-gather with adapter GEMM"): with `micro_batches = k` the local batch is encoded
+in k row chunks; as soon as chunk j is encoded its all-gather is issued asynchronously from a side stream (RCCL runs it
+on its own stream over xGMI) while chunk j + 1 encodes on the compute stream; the compute stream waits for the k
+collectives once, in front of the adapter step.  Only the last chunk's gather (B_l / k rows) is exposed.
 """
 import torch
 import torch.distributed as dist
@@ -52,10 +57,12 @@ class EmbedAdapterStep:
     optimizer:   dbmm_amd.optim.SGD over the classifier's trainable parameters
     """
 
-    def __init__(self, encode_fn, classifier, optimizer, n_groups=4, group=None, fused=True):
+    def __init__(self, encode_fn, classifier, optimizer, n_groups=4, group=None, fused=True, micro_batches=1):
         self.encode_fn, self.classifier, self.optimizer = encode_fn, classifier, optimizer
         self.n_groups, self.group, self.fused = n_groups, group, fused
+        self.micro_batches = int(micro_batches)
         self.counts = None
+        self._side = None
 
     def gather(self, emb_local, y_local, g_local):
         labels = torch.stack([y_local, g_local], dim=1)             # int64 [B_l, 2]: one message
@@ -63,9 +70,52 @@ class EmbedAdapterStep:
         labels = all_gather_rows(labels, self.group)
         return emb, labels[:, 0].contiguous(), labels[:, 1].contiguous()
 
+    def encode_gather_overlapped(self, images_local, y_local, g_local):
+        """encode in `micro_batches` row chunks; chunk j's all-gather is in flight while chunk j + 1 encodes.
+        Returns (emb [B, D], y [B], g [B]) in the original global row order (rank-major, chunks in order within a rank)."""
+        world, _ = _world(self.group)
+        k, Bl = self.micro_batches, images_local.shape[0]
+        if Bl % k:
+            raise ValueError(f"local batch {Bl} is not divisible by micro_batches {k}")
+        m = Bl // k
+        chunk = lambda j: images_local[j * m:(j + 1) * m].contiguous()
+        if world == 1:
+            return torch.cat([self.encode_fn(chunk(j)) for j in range(k)]), y_local, g_local
+        labels = torch.stack([y_local, g_local], dim=1)             # int64 [B_l, 2]: one message
+        rccl = images_local.is_cuda and dist.get_backend(self.group) != "gloo"
+        works, G = [], None
+        if rccl:
+            main = torch.cuda.current_stream()
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=images_local.device)
+            side = self._side
+        for j in range(k):
+            e = self.encode_fn(chunk(j)).contiguous()
+            if G is None:
+                G = torch.empty((k, world * m) + tuple(e.shape[1:]), dtype=e.dtype, device=e.device)
+                if rccl:
+                    G.record_stream(side)
+            if rccl:
+                side.wait_stream(main)                              # chunk j is complete when the collective starts
+                with torch.cuda.stream(side):
+                    works.append(dist.all_gather_into_tensor(G[j], e, group=self.group, async_op=True))
+                e.record_stream(side)
+            else:                                                   # gloo rehearsal (ranks sharing one GPU / CPU tests): same data flow
+                G[j].copy_(all_gather_rows(e, self.group))
+        labels = all_gather_rows(labels, self.group)
+        for w in works:
+            w.wait()                                                # stream-level: the compute stream waits, the host does not
+        if rccl:
+            main.wait_stream(side)
+        emb = G.view((k, world, m) + tuple(G.shape[2:])).transpose(0, 1).reshape((world * Bl,) + tuple(G.shape[2:]))
+        return emb, labels[:, 0].contiguous(), labels[:, 1].contiguous()
+
     def step(self, images_local, y_local, g_local, use_group=False):
-        emb_local = self.encode_fn(images_local)
-        emb, y, g = self.gather(emb_local, y_local, g_local)
+        if self.micro_batches > 1:
+            emb, y, g = self.encode_gather_overlapped(images_local, y_local, g_local)
+        else:
+            emb_local = self.encode_fn(images_local)
+            emb, y, g = self.gather(emb_local, y_local, g_local)
         if emb.dtype != torch.float32:                 # fp16 mode: the adapter consumes .float() embeddings, like the
             emb = emb.float()                          # reference's readers do (data/celeba_embeddings_reg.py:74)
         labels = g if use_group else y

@@ -13,6 +13,20 @@ from ._lib import check, ptr, require_cuda, stream
 
 ACT_NONE, ACT_RELU, ACT_QUICKGELU = 0, 1, 2
 
+
+def set_option(name, value):
+    """library option by name (include/dbmm.h dbmm_set_option; names in csrc/options.hip); returns the previous value"""
+    old = get_option(name)
+    check(_lib.lib().dbmm_set_option(name.encode(), int(value)), f"set_option({name})")
+    return old
+
+
+def get_option(name):
+    v = ctypes.c_int()
+    check(_lib.lib().dbmm_get_option(name.encode(), ctypes.byref(v)), f"get_option({name})")
+    return v.value
+
+
 # every output / workspace of this module comes from here (torch's caching allocator); tests swap in an allocator
 # that surrounds each tensor with guard zones to catch writes outside the tensor (tests/test_gpu_headline.py)
 _empty = torch.empty
@@ -224,19 +238,24 @@ def conv_bn_act(x, w, bias, residual, kh, kw, stride, pad, act, w_layout=WL_TAP_
     oel = B * Ho * Wo * Cout
     nby_pool = 4 * (x.numel() + (residual.numel() if residual is not None else 0) + oel // 4 + (oel if keep_full else 0)) + wby
     nby = 4 * (x.numel() + (residual.numel() if residual is not None else 0) + oel) + wby
-    # the 32-channel stem convs: persistent patch kernel (csrc/conv_patch.hip); DBMM_CONV_PATCH=0 disables (read per call)
+    # the 32-channel stem convs: persistent patch kernel (csrc/conv_patch.hip); option conv_patch = 0 disables
     if (Cin == 32 and kh == 3 and kw == 3 and stride == 1 and pad == 1 and act == ACT_RELU and residual is None and not keep_full
             and w_planes_f16 is not None and w_planes_f16.shape[0] == 1 and out_scale is not None and x_absmax is not None
             and Cout in (32, 64) and H % 4 == 0 and W % 28 == 0 and (pool == 1 or (H % 2 == 0 and W % 2 == 0))
-            and w_layout in (WL_TAP_MAJOR, WL_CHUNK32_MAJOR) and os.environ.get("DBMM_CONV_PATCH", "1") != "0"):
+            and w_layout in (WL_TAP_MAJOR, WL_CHUNK32_MAJOR) and get_option("conv_patch")):
         y = _empty((B, H // pool, W // pool, Cout), device=x.device, dtype=torch.float32)
         global _chain_tag
         _chain_tag = f"conv3x3_c32_kernel<{Cout}, {int(pool == 2)}>"
-        with _Timed(B * H * W, Cout, 9 * Cin, -1, 0, 4 * (x.numel() + y.numel()) + 2 * Cout * 9 * Cin):
-            rc = _lib.lib().dbmm_conv3x3_c32_bn_relu_x2(ptr(x), ptr(x_absmax), ptr(w_planes_f16), int(w_exp), ptr(out_scale), ptr(bias),
-                                                       ptr(y), ptr(y_absmax), B, H, W, Cin, Cout, 2 if pool == 2 else 0, stream())
+        t = _Timed(B * H * W, Cout, 9 * Cin, -1, 0, 4 * (x.numel() + y.numel()) + 2 * Cout * 9 * Cin)
+        t.__enter__()
+        rc = _lib.lib().dbmm_conv3x3_c32_bn_relu_x2(ptr(x), ptr(x_absmax), ptr(w_planes_f16), int(w_exp), ptr(out_scale), ptr(bias),
+                                                   ptr(y), ptr(y_absmax), B, H, W, Cin, Cout, 2 if pool == 2 else 0, stream())
+        if rc == 0:
+            t.__exit__(None, None, None)
+            return y
+        if rc not in (_lib.E_UNSUPPORTED, _lib.E_ALIGN):      # a shape / alignment the patch kernel does not serve: the general kernels below do
             check(rc, "conv3x3_c32_bn_relu_x2")
-        return y
+        del y
     if pool == 2 and split and Ho % 2 == 0 and Wo % 2 == 0:
         y = _empty((B, Ho // 2, Wo // 2, Cout), device=x.device, dtype=torch.float32)
         yf = _empty((B, Ho, Wo, Cout), device=x.device, dtype=torch.float32) if keep_full else None
@@ -461,10 +480,10 @@ def layernorm(x, gamma, beta, rows=None, ldx=None, eps=1e-5, y_absmax=None):
 def mha_core(qkv, B, L, E, heads, causal, qkv_absmax=None):
     """softmax(q k^T / 8) v per (image, head).  With qkv_absmax (device scalar >= max|qkv|, the qkv GEMM's c_absmax) the
     fp16-pair kernel runs (16-bit matrix cores, three partial products, fp32 accuracy); without it, or with
-    DBMM_MHA_X2=0, the fp32-input-MFMA kernel."""
+    option mha_x2 = 0, the fp32-input-MFMA kernel."""
     require_cuda(qkv)
     out = _empty((B * L, E), device=qkv.device, dtype=torch.float32)
-    if qkv_absmax is not None and os.environ.get("DBMM_MHA_X2", "1") != "0":
+    if qkv_absmax is not None and get_option("mha_x2"):
         with _TimedTag("mha_pair_kernel", 4.0 * B * heads * L * L * 64, 4 * (B * L * 4 * E)):
             check(_lib.lib().dbmm_mha_core_x2(ptr(qkv), ptr(qkv_absmax), ptr(out), B, L, E, heads, int(causal), stream()),
                   "mha_core_x2")
@@ -678,7 +697,7 @@ def gemm_f16(a, w, bias=None, residual=None, act=ACT_NONE, M=None, lda=None):
     if M is None:
         M = a.numel() // a.shape[-1]
     c = _empty((M, N), device=a.device, dtype=torch.float16)
-    deep = N % 256 == 0 and K % 128 == 0 and M >= 16384 and os.environ.get("DBMM_F16_8PH", "1") != "0"   # dbmm_gemm_f16's own rule
+    deep = N % 256 == 0 and K % 128 == 0 and M >= 16384 and get_option("f16_8ph")   # dbmm_gemm_f16's own rule
     with _TimedTag("gemm_f16_8ph_kernel" if deep else "gemm_f16_kernel", 2.0 * M * N * K,
                    2 * (M * K + N * K + M * N * (2 if residual is not None else 1))):
         check(_lib.lib().dbmm_gemm_f16(ptr(a), lda, ptr(w), K, ptr(bias), ptr(residual), N if residual is not None else 0, ptr(c), N,

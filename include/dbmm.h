@@ -51,6 +51,14 @@ extern "C" {
 int dbmm_version(void);
 const char* dbmm_error_string(int code);
 
+/* Library options: the switches the launchers consult (which kernel family serves a shape; every setting gives the same
+ * results up to fp32 rounding).  Names are listed in csrc/options.hip ("igemm_halo", "gemm_8ph", "f16_8ph",
+ * "adapter_step_fused", ...).  Defaults are the measured best; each option is seeded once, at load time, from the
+ * environment variable DBMM_<NAME IN UPPER CASE> when that is set -- no launch path reads the environment.
+ * Returns DBMM_E_ARG for an unknown name.  The reference has no counterpart (it has no native code). */
+int dbmm_set_option(const char* name, int value);
+int dbmm_get_option(const char* name, int* value);
+
 /* ---------------------------------------------------------------------------------------
  * Dense contractions on fp32 MFMA (v_mfma_f32_32x32x2_f32), LDS-tiled implicit GEMM.
  * ------------------------------------------------------------------------------------ */

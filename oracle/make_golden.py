@@ -202,11 +202,26 @@ def _write_text_json(path, mat, names):
         json.dump({n: mat[:, i].numpy().tolist() for i, n in enumerate(names)}, f)
 
 
+TIE_MARGIN = 1e-5      # |BatchNorm output| below this at step 0 = a ReLU input whose sign rounding decides
+
+
 def gen_adapter(FM, D=1024, Bs=(4, 256, 1024), fname="adapter.npz"):
     """D = 1024 is the reference's hard-coded RN50 width (final_main.py:31,304); D = 512 / 768 are the
     ViT-B/32 and ViT-L/14 widths BASELINE configs[3] / [4] need (D becomes a parameter),
-    run through the reference's own Adapter(D, 128) / CustomCLIP / MultipleAdapter classes."""
+    run through the reference's own Adapter(D, 128) / CustomCLIP / MultipleAdapter classes.
+
+    Stored WITH every case, all measured on the reference itself:
+      * `ties`  [n, 2] int64 (row, hidden unit): BatchNorm outputs of the trainable adapter within TIE_MARGIN of 0 at
+        step 0.  ReLU'(+-1e-7) is a tie; which side an implementation lands on decides that unit's rank-one term of the
+        layer-0 / BatchNorm gradients, so tests leave exactly those units out and hold everything else tight.
+      * `traj_tol` / `eval_tol`: the reference re-run from the same start on an input perturbed by ONE ulp -- largest
+        relative parameter difference after the three steps (x 4) / largest absolute eval-logit difference (x 4).  At
+        T = 0.01 some trajectories amplify 6e-8 to 1e-3; the stage-2 start seed is chosen (and stored, `new_seed`) so
+        that the committed case is well conditioned where one of a few seeds is.
+      * `stage1/<key>`: the complete stage-1 end state of the B = 256 run (or the smallest B >= 256): every stage-2 case
+        of the file starts from it, so that step-0 logits of stage 2 are a pure forward pass on identical parameters."""
     from demo.util import set_optimizer, set_optimizer_reg  # reference's own helpers
+    import copy, io, contextlib
     tmp = tempfile.mkdtemp(prefix="dbmm_golden_")
     H = 128
     tcls, tsp, tgrp = (synth.text_matrix(1, D, 2, "class"), synth.text_matrix(1, D, 2, "spurious"),
@@ -225,34 +240,65 @@ def gen_adapter(FM, D=1024, Bs=(4, 256, 1024), fname="adapter.npz"):
             else:
                 out[f"{tag}/{k}_sums"], out[f"{tag}/{k}_sample"] = summary(t)
 
+    def three_steps(model, optim, bn, xin, labels, use_group, tag=None, osd=None, obufs=None, text=None, lr=None, multiple=False):
+        """the reference's step body x 3 (final_main.py:455-466 / 610-623); with `tag`, records step 0 and checks the oracle"""
+        model.train()
+        seen = []
+        hook = bn.register_forward_hook(lambda m, i, o: seen.append(o.detach().clone()))
+        for step in range(3):
+            logits = model(xin.detach(), use_group)
+            loss = crit(logits, labels)
+            optim.zero_grad(); loss.backward()
+            if step == 0:
+                hook.remove()
+                if tag is not None:
+                    out[f"{tag}/step0/ties"] = (seen[0].abs() < TIE_MARGIN).nonzero().numpy().astype(np.int64).reshape(-1, 2)
+                    out[f"{tag}/step0/relu_margin"] = np.float64(seen[0].abs().min().item())
+                    record(tag + "/step0", {"logits": logits, "loss": loss})
+                    record(tag + "/step0/grad", {n: p.grad for n, p in model.named_parameters() if p.grad is not None})
+            optim.step()
+            if osd is not None:
+                ol, ologits, _ = AO.train_step(osd, obufs, xin, labels, text, lr, multiple=multiple)
+                assert relerr(ologits, logits.detach()) < 2e-5, tag
+                if not multiple:
+                    assert abs(ol.item() - loss.item()) < 1e-5 * max(1, abs(loss.item())), tag
+
+    def sensitivity(make, xin, labels, use_group, base_model):
+        """(4 x max relative parameter difference, 4 x max |eval logit| difference) of the reference re-run on x * (1 + 2^-23)"""
+        m2, o2, bn2 = make()
+        three_steps(m2, o2, bn2, xin * (1.0 + 2.0 ** -23), labels, use_group)
+        sens = max(relerr(m2.state_dict()[k], v) for k, v in base_model.state_dict().items() if v.dtype.is_floating_point)
+        m2.eval(); base_model.eval()
+        with torch.no_grad():
+            es = (m2(xin) - base_model(xin)).abs().max().item()
+        return max(2e-5, 4 * sens), max(2e-4, 4 * es)
+
+    stage1_B = min(b for b in Bs if b >= 256)
+    stage1 = None
+    inputs = {}
     for B in Bs:
         x = synth.normal(5, f"x{B}", (B, D), 0.5)
         y, c, g = synth.labels(6, B)
-        # ---- stage 1: CustomCLIP, class prompt, 3 SGD steps in train mode -------------
+        inputs[B] = (x, y, g)
+        # ---- stage 1: CustomCLIP, 3 SGD steps in train mode (class / group prompts) -------------
         for use_group in (False, True):
             tag = f"custom_B{B}_{'group' if use_group else 'class'}"
-            ad = FM.Adapter(D, H); ad.load_state_dict(synth.adapter_state_dict(3, D, H))
-            clf = FM.CustomCLIP(ad, *paths, temperature=0.01)
-            optim = set_optimizer(opt_ns, clf)
+
+            def make():
+                ad = FM.Adapter(D, H); ad.load_state_dict(synth.adapter_state_dict(3, D, H))
+                clf = FM.CustomCLIP(ad, *paths, temperature=0.01)
+                return clf, set_optimizer(opt_ns, clf), clf.adapter.layers[1]
+            clf, optim, bn = make()
             osd = {"adapter." + k: v.clone() for k, v in synth.adapter_state_dict(3, D, H).items()}
-            obufs = {}
             labels = g if use_group else y
             text = tgrp if use_group else tcls
-            clf.train()
-            for step in range(3):
-                logits = clf(x.detach(), use_group)
-                loss = crit(logits, labels)
-                optim.zero_grad(); loss.backward()
-                if step == 0:
-                    record(tag + "/step0", {"logits": logits, "loss": loss})
-                    record(tag + "/step0/grad", {n: p.grad for n, p in clf.named_parameters()})
-                optim.step()
-                ol, ologits, ograds = AO.train_step(osd, obufs, x, labels, text, 0.1)
-                assert relerr(ologits, logits.detach()) < 2e-5 and abs(ol.item() - loss.item()) < 1e-5 * max(1, abs(loss.item())), tag
+            three_steps(clf, optim, bn, x, labels, use_group, tag, osd, {}, text, 0.1)
             record(tag + "/after3", dict(clf.state_dict()))
             for k, v in clf.state_dict().items():
                 if v.dtype.is_floating_point:
                     assert relerr(osd[k], v) < 2e-5, (tag, k, relerr(osd[k], v))
+            tt, et = sensitivity(make, x, labels, use_group, clf)
+            out[f"{tag}/traj_tol"], out[f"{tag}/eval_tol"] = np.float64(tt), np.float64(et)
             # eval-mode logits (validate path, running stats)
             clf.eval()
             with torch.no_grad():
@@ -276,60 +322,44 @@ def gen_adapter(FM, D=1024, Bs=(4, 256, 1024), fname="adapter.npz"):
                 for k in res:
                     assert res[k] == ores[k], (k, res[k], ores[k])
                 out[f"{tag}/results"] = np.array([res[k] for k in sorted(res)], dtype=np.float64)
-            stage1 = clf
-        # ---- stage 2: MultipleAdapter on top of the trained stage-1 classifier ---------
+            if B == stage1_B and use_group:
+                stage1 = clf
+                for k, v in clf.state_dict().items():
+                    out[f"stage1/{k}"] = v.detach().numpy().copy()          # complete, bit for bit
+    # ---- stage 2: MultipleAdapter on top of the trained stage-1 classifier (the stored one), every B ---------
+    for B in Bs:
+        x, y, g = inputs[B]
         for near_identity in (True, False):
             for use_group in (False, True):
                 tag = f"multi_B{B}_{'ni' if near_identity else 'rn'}_{'group' if use_group else 'class'}"
-                import copy
-                old = copy.deepcopy(stage1)
-                new_ad = FM.Adapter(D, H); new_ad.load_state_dict(synth.adapter_state_dict(4, D, H))
-                import io, contextlib
-                with contextlib.redirect_stdout(io.StringIO()):
-                    ma = FM.MultipleAdapter(old, new_ad, init_near_identity=near_identity, ebd_weight=0.5)
-                optim = set_optimizer_reg(opt_ns, ma)
-                osd = {k: v.clone() for k, v in ma.state_dict().items()}
-                obufs = {}
                 labels = g if use_group else y
                 text = tgrp if use_group else tcls
-                ma.train()
-                # smallest |BatchNorm output| of the trainable adapter at step 0 = distance of the nearest ReLU input
-                # from its kink.  ReLU'(0) is a tie: an implementation whose pre-activation lands 1e-8 on the other side
-                # has a different (equally valid) gradient in layers 0 / 1, so tests skip those when the margin is ~0.
-                margins = []
-                hook = ma.new_adapter.layers[1].register_forward_hook(lambda m, i, o: margins.append(o.detach().abs().min().item()))
-                for step in range(3):
-                    logits = ma(x.detach(), use_group)
-                    loss = crit(logits, labels)
-                    optim.zero_grad(); loss.backward()
-                    if step == 0:
-                        hook.remove()
-                        out[f"{tag}/step0/relu_margin"] = np.float64(margins[0])
-                        record(tag + "/step0", {"logits": logits, "loss": loss})
-                        record(tag + "/step0/grad", {n: p.grad for n, p in ma.named_parameters() if p.grad is not None})
-                    optim.step()
-                    ol, ologits, _ = AO.train_step(osd, obufs, x, labels, text, 0.05, multiple=True)
-                    assert relerr(ologits, logits.detach()) < 2e-5, tag
+                best = None
+                for new_seed in (4, 14, 24, 34):
+                    def make():
+                        new_ad = FM.Adapter(D, H); new_ad.load_state_dict(synth.adapter_state_dict(new_seed, D, H))
+                        with contextlib.redirect_stdout(io.StringIO()):
+                            ma = FM.MultipleAdapter(copy.deepcopy(stage1), new_ad, init_near_identity=near_identity, ebd_weight=0.5)
+                        return ma, set_optimizer_reg(opt_ns, ma), ma.new_adapter.layers[1]
+                    ma, optim, bn = make()
+                    three_steps(ma, optim, bn, x, labels, use_group)
+                    tt, et = sensitivity(make, x, labels, use_group, ma)
+                    if best is None or tt < best[1]:
+                        best = (new_seed, tt, et)
+                    if tt <= 1e-4:
+                        break
+                new_seed, tt, et = best
+                ma, optim, bn = make()
+                osd = {k: v.clone() for k, v in ma.state_dict().items()}
+                three_steps(ma, optim, bn, x, labels, use_group, tag, osd, {}, text, 0.05, multiple=True)
                 record(tag + "/after3", dict(ma.state_dict()))
-                # conditioning of this trajectory: the REFERENCE itself re-run from the same start on an input
-                # perturbed by one ulp.  At T = 0.01 a few cases amplify 6e-8 to 6e-4 in three steps; no
-                # implementation can be held to less than that, so the tolerance is stored with the case.
-                with contextlib.redirect_stdout(io.StringIO()):
-                    new_ad2 = FM.Adapter(D, H); new_ad2.load_state_dict(synth.adapter_state_dict(4, D, H))
-                    ma2 = FM.MultipleAdapter(copy.deepcopy(stage1), new_ad2, init_near_identity=near_identity, ebd_weight=0.5)
-                optim2 = set_optimizer_reg(opt_ns, ma2); ma2.train()
-                xp = x * (1.0 + 2.0 ** -23)
-                for step in range(3):
-                    l2 = crit(ma2(xp.detach(), use_group), labels)
-                    optim2.zero_grad(); l2.backward(); optim2.step()
-                sens = max(relerr(ma2.state_dict()[k], v) for k, v in ma.state_dict().items() if v.dtype.is_floating_point)
-                tol = max(2e-5, 4 * sens)
-                out[f"{tag}/traj_tol"] = np.float64(tol)
-                if tol > 2e-5:
-                    print(f"[adapter] {tag}: ill-conditioned trajectory, 1-ulp sensitivity {sens:.2e} -> tol {tol:.2e}")
+                out[f"{tag}/new_seed"] = np.int64(new_seed)
+                out[f"{tag}/traj_tol"], out[f"{tag}/eval_tol"] = np.float64(tt), np.float64(et)
+                if tt > 1e-4:
+                    print(f"[adapter] {tag}: ill-conditioned for every seed tried, best seed {new_seed}: traj_tol {tt:.2e} eval_tol {et:.2e}")
                 for k, v in ma.state_dict().items():
                     if v.dtype.is_floating_point:
-                        assert relerr(osd[k], v) < tol, (tag, k, relerr(osd[k], v))
+                        assert relerr(osd[k], v) < tt, (tag, k, relerr(osd[k], v))
                 ma.eval()
                 with torch.no_grad():
                     record(tag + "/eval", {"logits": ma(x), "logits_spurious": ma.forward_spurious(x)})

@@ -44,3 +44,17 @@ def summary(t, nsample=256):
     f = t.detach().double().flatten().cpu()
     step = max(1, f.numel() // nsample)
     return np.array([f.sum().item(), f.abs().sum().item()]), f[::step][:nsample].float().numpy()
+
+
+@pytest.fixture
+def option():
+    """set a library option (dbmm_set_option) for the duration of a test: option("igemm_halo", 0)"""
+    from dbmm_amd import ops
+    saved = {}
+
+    def set_(name, value):
+        old = ops.set_option(name, int(value))
+        saved.setdefault(name, old)
+    yield set_
+    for name, old in saved.items():
+        ops.set_option(name, old)

@@ -55,6 +55,10 @@ def _worker(rank, world, port, q):
         # two replicated steps (group counting needs the HIP kernel -> exercise use_group path)
         for _ in range(2):
             loss, logits, _ = step.step(images[lo:hi], y[lo:hi], g[lo:hi], use_group=True)
+        # micro-batched gather (the overlap path's data flow; gloo runs it synchronously): same rows in the same order
+        mstep = dp.EmbedAdapterStep(enc, clf, opt, micro_batches=4)
+        emb4, y4, g4 = mstep.encode_gather_overlapped(images[lo:hi], y[lo:hi], g[lo:hi])
+        ok = ok and torch.equal(emb4, enc(images)) and torch.equal(y4, y) and torch.equal(g4, g)
         flat = torch.cat([p.detach().flatten() for p in clf.parameters()] + [clf.bn.running_mean, clf.bn.running_var])
         q.put((rank, ok, loss.item(), flat.numpy().tobytes()))   # bytes, not a tensor: shared-memory
         # tensor handles die with the worker and race the parent's q.get

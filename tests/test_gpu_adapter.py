@@ -10,7 +10,7 @@ import pytest
 import torch
 
 import adapter_oracle as AO
-from conftest import relerr, summary
+from conftest import relerr
 from dbmm_amd import adapter, optim, synth
 
 pytestmark = pytest.mark.gpu
@@ -46,25 +46,37 @@ def text_paths_by_dim(tmp_path_factory):
     return get
 
 
-def _check(g, tag, name, t, tol=1e-4):
+def _err(g, key, t, skip_units=(), unit_axis_len=None):
+    """(max |t - fixture|, max |fixture|) -- over the whole tensor when the fixture holds it, else over the 256 strided
+    samples make_golden.record() keeps of a tensor above 8192 elements.  skip_units: hidden units (rows of layers.0.weight,
+    elements of the [H] vectors) left out of the comparison (ReLU ties, see the fixture generator)."""
     t = t.detach().float().cpu()
-    if tag.endswith("/grad") and name.endswith("layers.0.bias"):
-        assert t.abs().max() < 1e-5          # analytically zero (bias in front of train-mode BN)
-    elif f"{tag}/{name}" in g.files:
-        assert relerr(t, g[f"{tag}/{name}"]) < tol, (tag, name, relerr(t, g[f"{tag}/{name}"]))
-    else:
-        _, sample = summary(t)
-        ref = g[f"{tag}/{name}_sample"]
-        assert np.abs(sample - ref).max() <= tol * max(np.abs(ref).max(), 1e-6), (tag, name)
-
-
-def _abs_err(g, key, t):
-    """max |t - fixture|; fixtures hold tensors above 8192 elements as 256 strided samples (make_golden.record)"""
-    t = t.detach().float().cpu()
+    skip = sorted(set(int(u) for u in skip_units))
     if key in g.files:
-        return (t - torch.from_numpy(g[key])).abs().max().item()
-    _, sample = summary(t)
-    return float(np.abs(sample - g[key + "_sample"]).max())
+        ref = torch.from_numpy(np.asarray(g[key])).float().reshape(t.shape)
+        if skip and t.dim() >= 1 and t.shape[0] == unit_axis_len:
+            keep = torch.ones(t.shape[0], dtype=torch.bool); keep[skip] = False
+            t, ref = t[keep], ref[keep]
+        return (t - ref).abs().max().item(), ref.abs().max().item()
+    f = t.flatten()
+    step = max(1, f.numel() // 256)
+    idx = torch.arange(0, f.numel(), step)[:256]
+    sample, ref = f[idx], torch.from_numpy(g[key + "_sample"])
+    if skip and t.dim() == 2 and t.shape[0] == unit_axis_len:
+        keep = ~torch.isin(idx // t.shape[1], torch.tensor(skip))
+        sample, ref = sample[keep], ref[keep]
+    return (sample - ref).abs().max().item(), ref.abs().max().item()
+
+
+def _check(g, tag, name, t, tol, skip_units=()):
+    if tag.endswith("/grad") and name.endswith("layers.0.bias"):
+        assert t.detach().abs().max().item() < 1e-5          # analytically zero (bias in front of train-mode BN)
+        return
+    # a tied hidden unit u touches row u of layers.0.weight and element u of layers.0.bias / layers.1.weight / layers.1.bias
+    per_unit = any(name.endswith(sfx) for sfx in ("layers.0.weight", "layers.0.bias", "layers.1.weight", "layers.1.bias",
+                                                   "layers.1.running_mean", "layers.1.running_var"))
+    err, scale = _err(g, f"{tag}/{name}", t, skip_units if per_unit else (), H)
+    assert err <= tol * max(scale, 1e-6), f"{tag}/{name}: |diff| {err:.3e} = {err / max(scale, 1e-30):.2e} of max |ref| (tolerance {tol:.1e})"
 
 
 def _ns(**k):
@@ -76,23 +88,34 @@ def _ns(**k):
 # configs[3]'s global batch; 768 / 8192 = ViT-L/14 at configs[4]'s.  All fixtures come from the reference's own
 # Adapter(D, 128) / CustomCLIP / MultipleAdapter classes (oracle/make_golden.py).
 CASES = [(1024, 4), (1024, 256), (1024, 1024), (512, 256), (512, 4096), (768, 256), (768, 8192)]
+LOGIT_TOL = 1e-3           # BASELINE.json north_star: cosine logits within 1e-3 (absolute, at T = 0.01)
 
 
 @pytest.mark.parametrize("D,B", CASES)
 @pytest.mark.parametrize("fused", [False, True])
 def test_custom_clip_and_multiple_adapter(D, B, fused, golden, text_paths_by_dim):
+    """Tolerances: every forward-only logit (step 0 of either stage: same parameters as the reference, bit for bit) within
+    1e-3 absolute; eval logits after three SGD steps within max(1e-3, eval_tol), eval_tol = 4 x what ONE ulp on the input
+    does to the reference's own eval logits (stored with the case; 2e-4 ... 2.3e-4 for every committed case, so 1e-3
+    binds); gradients and parameters-after-3 within 3e-4 of the tensor maximum, hidden units whose ReLU input sat within
+    1e-5 of zero in the reference run (`ties`, 0 - 10 of 128 units) left out of the layer-0 / BatchNorm comparisons."""
     g = golden("adapter.npz" if D == 1024 else f"adapter_D{D}.npz")
     text_paths = text_paths_by_dim(D)
     x = synth.normal(5, f"x{B}", (B, D), 0.5).cuda()
     y, c, grp = (t.cuda() for t in synth.labels(6, B))
     crit = torch.nn.CrossEntropyLoss()
-    stage1 = None
+    worst = {}
+
+    def note(kind, v):
+        worst[kind] = max(worst.get(kind, 0.0), v)
+
     for use_group in (False, True):
         tag = f"custom_B{B}_{'group' if use_group else 'class'}"
         ad = adapter.Adapter(D, H); ad.load_state_dict(synth.adapter_state_dict(3, D, H))
         clf = adapter.CustomCLIP(ad, *text_paths, temperature=0.01).cuda()
         opt = optim.set_optimizer(_ns(), clf)
         labels = grp if use_group else y
+        ties = g[tag + "/step0/ties"][:, 1] if g[tag + "/step0/ties"].size else ()
         clf.train()
         for step in range(3):
             if fused:
@@ -102,21 +125,24 @@ def test_custom_clip_and_multiple_adapter(D, B, fused, golden, text_paths_by_dim
                 loss = crit(logits, labels)
             opt.zero_grad(); loss.backward()
             if step == 0:
-                assert _abs_err(g, tag + "/step0/logits", logits) < 1e-3
+                e, _ = _err(g, tag + "/step0/logits", logits); note("step0 logits", e)
+                assert e < LOGIT_TOL, f"{tag}: step-0 logits off by {e:.2e}"
                 assert abs(loss.item() - float(g[tag + "/step0/loss"])) < 1e-4 * max(1.0, abs(loss.item()))
                 for n, p in clf.named_parameters():
-                    _check(g, tag + "/step0/grad", n, p.grad, 2e-4)
+                    _check(g, tag + "/step0/grad", n, p.grad, 2e-4, ties)
             opt.step()
         for k, v in clf.state_dict().items():
             if v.dtype.is_floating_point:
-                _check(g, tag + "/after3", k, v, 2e-4)
+                _check(g, tag + "/after3", k, v, 2e-4, ties)
             else:
                 assert int(v) == int(g[f"{tag}/after3/{k}"])
         clf.eval()
+        etol = max(LOGIT_TOL, float(g[tag + "/eval_tol"]))
         with torch.no_grad():
             ev, evs = clf(x), clf.forward_spurious(x)
-        assert _abs_err(g, tag + "/eval/logits", ev) < 2e-3
-        assert _abs_err(g, tag + "/eval/logits_spurious", evs) < 2e-3
+        e1, _ = _err(g, tag + "/eval/logits", ev); e2, _ = _err(g, tag + "/eval/logits_spurious", evs)
+        note("eval logits after 3 steps", max(e1, e2))
+        assert e1 < etol and e2 < etol, f"{tag}: eval logits after 3 steps off by {e1:.2e} / {e2:.2e} (tolerance {etol:.1e})"
         if not use_group:
             meters = {i: adapter.AverageMeter() for i in range(4)}
             # counts are pinned on the REFERENCE's logits when the fixture holds them in full, else on our own
@@ -128,19 +154,24 @@ def test_custom_clip_and_multiple_adapter(D, B, fused, golden, text_paths_by_dim
             from functools import partial
             res = adapter.get_results(meters, partial(adapter.get_y_p, n_places=2))
             assert np.array_equal(np.array([res[k] for k in sorted(res)]), g[tag + "/results"])
-        stage1 = clf        # like the fixture generator: stage 2 starts from the last stage-1 run
+    # stage 2 starts from the reference's own stage-1 end state, stored complete in the fixture: step 0 is forward-only
+    s1 = adapter.Adapter(D, H)
+    s1.load_state_dict({k[len("stage1/adapter."):]: torch.from_numpy(g[k]) for k in g.files if k.startswith("stage1/adapter.")})
+    stage1 = adapter.CustomCLIP(s1, *text_paths, temperature=0.01)
+    assert not [k for k in g.files if k.startswith("stage1/") and not k.startswith("stage1/adapter.")]
     for ni in (True, False):
         for use_group in (False, True):
             tag = f"multi_B{B}_{'ni' if ni else 'rn'}_{'group' if use_group else 'class'}"
             old = copy.deepcopy(stage1)
-            new_ad = adapter.Adapter(D, H); new_ad.load_state_dict(synth.adapter_state_dict(4, D, H))
+            new_ad = adapter.Adapter(D, H); new_ad.load_state_dict(synth.adapter_state_dict(int(g[tag + "/new_seed"]), D, H))
             import contextlib, io
             with contextlib.redirect_stdout(io.StringIO()):
                 ma = adapter.MultipleAdapter(old, new_ad, init_near_identity=ni, ebd_weight=0.5).cuda()
             opt = optim.set_optimizer_reg(_ns(), ma)
             assert sum(len(gr["params"]) for gr in opt.param_groups) == 6
             labels = grp if use_group else y
-            tie = tag + "/step0/relu_margin" in g.files and float(g[tag + "/step0/relu_margin"]) < 3e-6
+            ties = g[tag + "/step0/ties"][:, 1] if g[tag + "/step0/ties"].size else ()
+            assert float(g[tag + "/traj_tol"]) <= 1e-4, tag          # the generator commits well-conditioned trajectories only
             ma.train()
             for step in range(3):
                 if fused:
@@ -149,26 +180,23 @@ def test_custom_clip_and_multiple_adapter(D, B, fused, golden, text_paths_by_dim
                     logits = ma(x.detach(), use_group); loss = crit(logits, labels)
                 opt.zero_grad(); loss.backward()
                 if step == 0:
-                    assert _abs_err(g, tag + "/step0/logits", logits) < 2e-3
+                    e, _ = _err(g, tag + "/step0/logits", logits); note("step0 logits", e)
+                    assert e < LOGIT_TOL, f"{tag}: step-0 logits (forward only) off by {e:.2e}"
                     for n, p in ma.named_parameters():
                         if "old_cls" in n:
                             assert p.grad is None
                         else:
-                            # a ReLU input within rounding distance of 0 (margin recorded from the reference run) is a
-                            # tie: ReLU'(+-1e-7) decides one rank-one term of the layer-0 / BatchNorm gradients
-                            _check(g, tag + "/step0/grad", n, p.grad, 5e-2 if tie and (".0." in n or ".1." in n) else 3e-4)
+                            _check(g, tag + "/step0/grad", n, p.grad, 3e-4, ties)
                 opt.step()
-            # ill-conditioned trajectories carry the reference's own 1-ulp input sensitivity (x 4) as tolerance
-            ttol = float(g[tag + "/traj_tol"]) if tag + "/traj_tol" in g.files else 0.0
-            if tie:
-                ttol = max(ttol, 2e-4)
             for k, v in ma.state_dict().items():
                 if v.dtype.is_floating_point:
-                    _check(g, tag + "/after3", k, v, max(3e-4, 10 * ttol))
+                    _check(g, tag + "/after3", k, v, 3e-4, () if "old_cls" in k else ties)
             ma.eval()
+            etol = max(LOGIT_TOL, float(g[tag + "/eval_tol"]))
             with torch.no_grad():
-                etol = 3e-3 if ttol <= 2e-5 else 3e-3 * ttol / 2e-5
-                assert _abs_err(g, tag + "/eval/logits", ma(x)) < etol
+                e, _ = _err(g, tag + "/eval/logits", ma(x)); note("eval logits after 3 steps", e)
+                assert e < etol, f"{tag}: eval logits after 3 steps off by {e:.2e} (tolerance {etol:.1e})"
+    print(f"D={D} B={B} fused={fused}: " + ", ".join(f"max {k} error {v:.2e}" for k, v in worst.items()))
 
 
 def test_per_group_loss_and_flags(text_paths):

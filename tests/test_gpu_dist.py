@@ -61,14 +61,14 @@ def _state_bytes(clf, opt, step, loss):
     return torch.cat([t.cpu() for t in parts]).numpy().tobytes()
 
 
-def _worker(rank, world, port, tmp, q):
+def _worker(rank, world, port, tmp, q, micro=1):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from dbmm_amd import dp
         model, clf, opt, images, y, g = _setup(tmp)
         lo, hi = dp.shard_rows(B, world, rank)
-        step = dp.EmbedAdapterStep(model.encode_image, clf, opt)
+        step = dp.EmbedAdapterStep(model.encode_image, clf, opt, micro_batches=micro)
         for _ in range(STEPS):
             loss, logits, emb = step.step(images[lo:hi].contiguous(), y[lo:hi], g[lo:hi])
         torch.cuda.synchronize()
@@ -77,12 +77,16 @@ def _worker(rank, world, port, tmp, q):
         dist.destroy_process_group()
 
 
-def test_two_ranks_one_gpu_equal_single_process(tmp_path):
+@pytest.mark.parametrize("micro", [1, 2])
+def test_two_ranks_one_gpu_equal_single_process(tmp_path, micro):
+    """micro = 2: dp.EmbedAdapterStep(micro_batches=2), the gather-overlap path of BASELINE configs[3] (each rank encodes its
+    shard in two chunks and gathers each as soon as it is encoded; under gloo the gathers run synchronously, the data flow
+    and row order are the overlap path's)."""
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, str(tmp_path), q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, str(tmp_path), q, micro)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda t: t[0])
@@ -94,7 +98,8 @@ def test_two_ranks_one_gpu_equal_single_process(tmp_path):
     # single process, whole batch (shards encoded separately like the ranks do), same fused step
     from dbmm_amd import dp
     model, clf, opt, images, y, g = _setup(str(tmp_path))
-    encode = lambda x: torch.cat([model.encode_image(x[:B // 2].contiguous()), model.encode_image(x[B // 2:].contiguous())])
+    n_chunks = world * micro                                         # the launches the ranks made, in global row order
+    encode = lambda x: torch.cat([model.encode_image(c.contiguous()) for c in x.chunk(n_chunks)])
     step = dp.EmbedAdapterStep(encode, clf, opt)
     for _ in range(STEPS):
         loss, _, _ = step.step(images, y, g)

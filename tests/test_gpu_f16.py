@@ -43,7 +43,7 @@ def test_gemm_f16(M, N, K, res, act):
 
 @pytest.mark.parametrize("M,N,K,res,act", [(16384 + 77, 512, 256, True, 2), (32768, 256, 128, False, 0), (20000, 1024, 4096, True, 0),
                                            (577 * 64, 3072, 1024, False, 2), (16384, 768, 3072, True, 0)])
-def test_gemm_f16_deep_pipelined_kernel(M, N, K, res, act, monkeypatch):
+def test_gemm_f16_deep_pipelined_kernel(M, N, K, res, act, option):
     """the 256 x 256 x 64 eight-phase kernel (N % 256 == 0, K % 128 == 0, M >= 16384) against fp64 ELEMENT-wise -- a staging
     race would show as a few wrong tiles, which a norm-wise error hides -- over repeated launches, and against the
     two-barrier kernel (DBMM_F16_8PH=0) on the same operands"""
@@ -55,9 +55,9 @@ def test_gemm_f16_deep_pipelined_kernel(M, N, K, res, act, monkeypatch):
     v = {0: v, 1: torch.relu(v), 2: v * torch.sigmoid(1.702 * v)}[act]
     if res:
         v = v + r[rows].double()
-    monkeypatch.setenv("DBMM_F16_8PH", "0")
+    option("f16_8ph", "0")
     base = ops.gemm_f16(a, w, b, residual=r, act=act)
-    monkeypatch.setenv("DBMM_F16_8PH", "1")
+    option("f16_8ph", "1")
     for _ in range(4):
         out = ops.gemm_f16(a, w, b, residual=r, act=act)
         assert torch.allclose(out[rows].double(), v, rtol=2e-3, atol=2e-3)

@@ -546,12 +546,12 @@ def test_split_planes_f16_single_only_when_exact():
     (64, 28, 128, 128, False, 1), (256, 14, 64, 256, True, 1), (256, 14, 64, 256, True, 2), (3, 12, 48, 64, False, 1),
     (9, 56, 128, 128, True, 1), (131, 14, 64, 128, True, 1), (37, 26, 64, 64, True, 1), (690, 6, 64, 128, True, 1),
     (131, 14, 96, 128, True, 1), (64, 28, 128, 512, True, 2), (7, 64, 32, 96, True, 1)])
-def test_conv_pool2_fused_equals_conv_then_avgpool(B, H, Cin, Cout, single, halo_pool, monkeypatch):
+def test_conv_pool2_fused_equals_conv_then_avgpool(B, H, Cin, Cout, single, halo_pool, option):
     """conv + ReLU + AvgPool2d(2) in one epilogue (rows walked 2x2-window-major) is bit-identical
     to the same conv followed by dbmm_avgpool2d, and agrees with an fp64 reference.  halo_pool = DBMM_IGEMM_HALO_POOL:
     1 puts the pooled conv on the window-major halo kernel where Cout % 256 != 0, 2 (default) everywhere, 0 nowhere
     (per-tap kernel).  Widths 26 / 14 / 6: the 32 windows of a tile wrap over 3 / 5 / 11+ pooled rows and over images."""
-    monkeypatch.setenv("DBMM_IGEMM_HALO_POOL", str(halo_pool))
+    option("igemm_halo_pool", str(halo_pool))
     x = rnd(1, "x", (B, Cin, H, H)); w = rnd(2, "w", (Cout, Cin, 3, 3), (Cin * 9) ** -0.5)
     if single:
         w = w.half().float()
@@ -597,7 +597,7 @@ def test_conv_pool2_unsupported_shapes_compose():
 
 
 @pytest.mark.parametrize("M,N,K,res,act", [(25637, 256, 256, True, 1), (25605, 200, 64, True, 0), (25600, 768, 768, False, 2), (128 * 300 + 5, 1024, 256, True, 1)])
-def test_direct_epilogue_equals_staged_epilogue(M, N, K, res, act, monkeypatch):
+def test_direct_epilogue_equals_staged_epilogue(M, N, K, res, act, option):
     """the fp16-pair GEMM's two epilogues -- straight from the accumulator layout (default) and staged through LDS
     (DBMM_IGEMM_EPI_DIRECT=0) -- perform the same arithmetic per element: outputs and the output maximum are bit-identical;
     ragged M (rows past M fall off the descriptor), N not a multiple of 32 (columns past N are masked lanes)"""
@@ -606,7 +606,7 @@ def test_direct_epilogue_equals_staged_epilogue(M, N, K, res, act, monkeypatch):
     ph, we, n = ops.split_planes_f16(w, allow_single=True)
     outs = []
     for knob in ("1", "0"):
-        monkeypatch.setenv("DBMM_IGEMM_EPI_DIRECT", knob)
+        option("igemm_epi_direct", knob)
         am = torch.zeros(1, device=DEV)
         y = ops.gemm(a, w, b, r, act=act, w_planes_f16=ph, w_exp=we, a_absmax=a.abs().max().reshape(1), c_absmax=am)
         assert ops._last_igemm_tag().startswith("igemm_x3_kernel<"), ops._last_igemm_tag()
@@ -627,7 +627,7 @@ def test_direct_epilogue_equals_staged_epilogue(M, N, K, res, act, monkeypatch):
         rr = rnd(9, "rr", (B, H, H, N)).to(DEV)
         ys = []
         for knob in ("1", "0"):
-            monkeypatch.setenv("DBMM_IGEMM_EPI_DIRECT", knob)
+            option("igemm_epi_direct", knob)
             am = torch.zeros(1, device=DEV)
             ys.append(ops.conv_bn_act(x, wp, b, rr, k, k, 1, k // 2, ops.ACT_RELU, wl, w_planes_f16=pk, w_exp=wek,
                                       x_absmax=x.abs().max().reshape(1), y_absmax=am, out_scale=sc))
@@ -637,7 +637,7 @@ def test_direct_epilogue_equals_staged_epilogue(M, N, K, res, act, monkeypatch):
 
 @pytest.mark.parametrize("M,N,K,res,act", [(16384 + 77, 512, 128, True, 2), (25600, 2304, 768, False, 0), (20000, 1024, 4096, True, 0), (16500, 256, 256, False, 0),
                                            (577 * 32, 3072, 1024, False, 2), (16384, 768, 3072, True, 1)])
-def test_gemm_pair_deep_pipelined_kernel(M, N, K, res, act, monkeypatch):
+def test_gemm_pair_deep_pipelined_kernel(M, N, K, res, act, option):
     """parity-mode GEMM on the 256 x 256 eight-phase kernel (gemm_pair_8ph.hip; N % 256 == 0, K % 64 == 0, M >= 16384):
     element-wise against fp64 -- a staging race would show as a few wrong tiles -- over repeated launches, against the
     two-barrier fp16-pair kernel (DBMM_GEMM_8PH=0) on the same operands, and the output-maximum scalar"""
@@ -652,11 +652,11 @@ def test_gemm_pair_deep_pipelined_kernel(M, N, K, res, act, monkeypatch):
         v = v + r[rows].double()
     v = {0: v, 1: torch.relu(v), 2: v * torch.sigmoid(1.702 * v)}[act]
     aam = a.abs().max().reshape(1)
-    monkeypatch.setenv("DBMM_GEMM_8PH", "0")
+    option("gemm_8ph", "0")
     am0 = torch.zeros(1, device=DEV)
     base = ops.gemm(a, w, b, r, act=act, w_planes_f16=ph, w_exp=we, a_absmax=aam, c_absmax=am0)
     assert ops._last_igemm_tag().startswith("igemm_x3_kernel<")
-    monkeypatch.setenv("DBMM_GEMM_8PH", "2")
+    option("gemm_8ph", "2")
     scale = max(1.0, v.abs().max().item())
     for _ in range(4):
         am = torch.zeros(1, device=DEV)
@@ -764,7 +764,7 @@ def test_conv_chunk32_major_layout(B, H, Cin, Cout, single, pool):
                                                 (9, 40, 72, 64, 192, False), (70, 19, 19, 128, 128, True),
                                                 (4, 112, 112, 32, 32, False), (16, 40, 40, 32, 64, False),
                                                 (40, 26, 26, 96, 128, True)])
-def test_conv3x3_halo_kernel(B, H, W, Cin, Cout, res, monkeypatch):
+def test_conv3x3_halo_kernel(B, H, W, Cin, Cout, res, option):
     """3x3 conv with the activation tile reused across the kw taps (LDS rows shifted, border taps
     redirected to a zero row): equal to the per-tap kernel up to summation order, and to fp64.
     Shapes cover every image-border case (7x7 ... 56x56, non-square, M not a multiple of 128,
@@ -783,12 +783,12 @@ def test_conv3x3_halo_kernel(B, H, W, Cin, Cout, res, monkeypatch):
     assert n == 1
     kw = dict(w_planes_f16=ph, w_exp=we, x_absmax=xd.abs().max().reshape(1), out_scale=sc.to(DEV))
     am = torch.zeros(1, device=DEV)
-    monkeypatch.setenv("DBMM_IGEMM_HALO", "1")
-    monkeypatch.setenv("DBMM_CONV_PATCH", "0")          # (the 32-channel stem shape would otherwise take the patch kernel)
+    option("igemm_halo", "1")
+    option("conv_patch", "0")          # (the 32-channel stem shape would otherwise take the patch kernel)
     o = ops.conv_bn_act(xd, wp, b.to(DEV), rd, 3, 3, 1, 1, ops.ACT_RELU, wl, y_absmax=am, **kw)
     tag = ops._last_igemm_tag()
     assert tag.startswith("igemm_halo_kernel<"), tag
-    monkeypatch.setenv("DBMM_IGEMM_HALO", "0")
+    option("igemm_halo", "0")
     o_tap = ops.conv_bn_act(xd, wp, b.to(DEV), rd, 3, 3, 1, 1, ops.ACT_RELU, wl, **kw)
     assert ops._last_igemm_tag().startswith("igemm_x3_kernel<")
     assert relerr(o.cpu(), o_tap.cpu()) < 2e-6
@@ -843,7 +843,7 @@ def _last_cfg():
     return list(cfg)
 
 
-def test_operands_over_2gib_stay_on_the_split_kernels(monkeypatch):
+def test_operands_over_2gib_stay_on_the_split_kernels(option):
     """RN50 layer 1 at the headline batch 1024 holds 3.3 GB activation tensors.  Buffer descriptors
     address 32 bits, so every tile rebases its descriptor on a 64-bit base (a_desc in igemm_f32.hip):
     operands past 2 GiB must still run the fp16-pair / halo / dual-source kernels (cfg[8] in 2, 4, 5 --
@@ -912,7 +912,7 @@ def test_operands_over_2gib_stay_on_the_split_kernels(monkeypatch):
         assert relerr(y[i].double().cpu(), ref.cpu()) < 5e-6, i
     # --- the same tensor pooled (window-major rows): the halo kernel's pooled variant, then the per-tap conv kernel
     for knob, kind in (("2", 4), ("0", 2)):
-        monkeypatch.setenv("DBMM_IGEMM_HALO_POOL", knob)
+        option("igemm_halo_pool", knob)
         yp = ops.conv_bn_act(x, wp, b, None, 3, 3, 1, 1, ops.ACT_RELU, wl, w_planes_f16=ph, w_exp=we,
                              x_absmax=x.abs().max().reshape(1), out_scale=sc, pool=2)
         cfg = _last_cfg()
@@ -1009,7 +1009,7 @@ def test_bottleneck_chain_dual_first_block(M, N, P):
 
 @pytest.mark.parametrize("B,H,W,Cout,pool", [(2, 112, 112, 32, 1), (2, 112, 112, 64, 2), (3, 8, 28, 64, 1), (5, 4, 56, 32, 2),
                                              (1, 12, 84, 64, 2), (300, 16, 28, 32, 1)])
-def test_conv3x3_c32_patch_kernel(B, H, W, Cout, pool, monkeypatch):
+def test_conv3x3_c32_patch_kernel(B, H, W, Cout, pool, option):
     """the stem's 32-channel 3x3 convs on the persistent patch kernel == fp64 and == the implicit-GEMM kernels
     (DBMM_CONV_PATCH=0), un-pooled and with the fused 2x2 average pool; image borders, several tiles per row, more tiles
     than resident workgroups (B = 300: 1200 tiles over 768 slots)."""
@@ -1023,7 +1023,7 @@ def test_conv3x3_c32_patch_kernel(B, H, W, Cout, pool, monkeypatch):
     xa = (x.abs().max() * 1.5).reshape(1)
     kw = dict(w_planes_f16=ph, w_exp=we, x_absmax=xa, out_scale=sc, pool=pool)
     am = torch.zeros(1, device=DEV)
-    monkeypatch.setenv("DBMM_CONV_PATCH", "1")
+    option("conv_patch", "1")
     y = ops.conv_bn_act(x, wp, b, None, 3, 3, 1, 1, ops.ACT_RELU, wl, y_absmax=am, **kw)
     ref = torch.relu(F.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), None, padding=1) * sc.double().view(1, -1, 1, 1)
                      + b.double().view(1, -1, 1, 1))
@@ -1032,7 +1032,7 @@ def test_conv3x3_c32_patch_kernel(B, H, W, Cout, pool, monkeypatch):
         ref = F.avg_pool2d(ref, 2)
     ref = ref.permute(0, 2, 3, 1)
     assert tuple(y.shape) == tuple(ref.shape) and relerr(y.double().cpu(), ref.cpu()) < 5e-6
-    monkeypatch.setenv("DBMM_CONV_PATCH", "0")
+    option("conv_patch", "0")
     y0 = ops.conv_bn_act(x, wp, b, None, 3, 3, 1, 1, ops.ACT_RELU, wl, **kw)
     assert relerr(y.cpu(), y0.cpu()) < 2e-6
 

@@ -25,7 +25,7 @@ for M, N, K, res, act in shapes:
     b = torch.randn((N,), device="cuda"); r = torch.randn((M, N), device="cuda").half() if res else None
     row = f"M={M:7d} N={N:5d} K={K:5d} res={int(res)} act={act}:"
     for v in ("0", "1"):
-        os.environ["DBMM_F16_8PH"] = v
+        ops.set_option("f16_8ph", int(v))
         ms = t(lambda: ops.gemm_f16(a, w, b, residual=r, act=act))
         row += f"   8ph={v} {ms * 1e3:8.1f} us {2.0 * M * N * K / ms / 1e9:7.1f} TF"
     print(row)

@@ -26,7 +26,7 @@ for M, N, K, res, act in shapes:
     aam = a.abs().max().reshape(1)
     row = f"M={M:7d} N={N:5d} K={K:5d} res={int(res)} act={act}:"
     for v in ("0", "1"):
-        os.environ["DBMM_GEMM_8PH"] = v
+        ops.set_option("gemm_8ph", 2 * int(v))
         am = torch.zeros(1, device="cuda")
         ms = t(lambda: ops.gemm(a, w, b, r, act=act, w_planes_f16=ph, w_exp=we, a_absmax=aam, c_absmax=am))
         row += f"   8ph={v} {ms * 1e3:8.1f} us {2.0 * M * N * K / ms / 1e9:7.1f} TF-eq"

@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
 """Developer tool: fold the rocprofv3 passes of ONE bench command into the per-kernel table bench.py reads
-(profiles/r02_pmc.json) and a kernel-stats csv.
+(profiles/r0N_pmc.json) and a kernel-stats csv.
 
     rocprofv3 --kernel-trace --stats --output-format csv -d D/stats -o s -- python3 bench.py ...
     rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d D/fetch -o f -- python3 bench.py ...
     rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d D/write -o w -- python3 bench.py ...
     rocprofv3 --kernel-trace --pmc SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_IDX_ACTIVE \
               SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU --output-format csv -d D/sq -o q -- ...
-    python tools/pmc_summary.py D RN50 1024 f32 > profiles/r02_pmc.json
+    python tools/pmc_summary.py D RN50 1024 f32 > profiles/r03_pmc.json
 
 Separate passes as MI355X_MICROARCH.md prescribes (FETCH_SIZE and WRITE_SIZE do not fit one pass; no tracing domains
 beside --pmc).  Units and gfx950 correction from the same guide: the TCC counters are KiB, FETCH_SIZE reports half of
@@ -20,6 +20,10 @@ import json
 import os
 import re
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import dbmm_amd  # noqa: E402,F401
+from dbmm_amd import _lib  # noqa: E402
 
 
 def short(name):
@@ -82,6 +86,7 @@ def main():
             if c.get("SQ_WAVE_CYCLES"):
                 e["wave_time_waiting_frac"] = c["SQ_WAIT_INST_ANY"] / c["SQ_WAVE_CYCLES"]
                 e["wave_time_issuing_frac"] = c["SQ_ACTIVE_INST_ANY"] / c["SQ_WAVE_CYCLES"]
+        e["source_hash"] = _lib.kernel_source_hash(k)      # bench.py drops these counters once the kernel's sources change
         out["kernels"][k] = e
     json.dump(out, sys.stdout, indent=1)
     print()
