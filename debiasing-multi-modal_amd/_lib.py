@@ -114,6 +114,10 @@ _SIGS = {
     "dbmm_gemm_f16": [_P, _L, _P, _L, _P, _P, _L, _P, _L, _L, _L, _L, _I, _P],
     "dbmm_mha_core_f16": [_P, _P, _L, _L, _L, _L, _I, _P],
     "dbmm_layernorm_f16": [_P, _L, _P, _P, _P, _L, _L, _L, _F, _P],
+    "dbmm_conv1x1_bn_act_f16": [_P, _P, _P, _P, _P, _P, _L, _L, _L, _I, _P],
+    "dbmm_conv3x3_bn_relu_f16": [_P, _P, _P, _P, _P, _L, _L, _L, _L, _L, _I, _P],
+    "dbmm_conv_stem_s2_f16": [_P, _I, _P, _P, _P, _L, _L, _L, _L, _P],
+    "dbmm_avgpool2_f16": [_P, _P, _L, _L, _L, _L, _P],
     "dbmm_im2col_patch_f16": [_P, _I, _P, _L, _L, _L, _L, _P],
     "dbmm_vit_tokens_f16": [_P, _P, _P, _P, _L, _L, _L, _P],
     "dbmm_embed_gather_f16": [_P, _P, _P, _P, _L, _L, _L, _L, _P],

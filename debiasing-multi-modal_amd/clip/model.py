@@ -19,9 +19,10 @@ Each tower compiles an execution plan on first use and `forward` walks that plan
     there too; in layers 1-2 conv3 + residual and the next block's conv1 are one launch.
     DBMM_CONV_SPLIT=bf16 / off select the bf16-triple / fp32-input-MFMA variants of the same arithmetic.
   * fp16 throughput mode (`convert_weights(model)` or `model.half()`, the reference's GPU path,
-    clip/model.py:375-396): the transformer towers keep fp16 activations in HBM, one fp16 MFMA per product,
-    fp32 accumulation, fp32 LayerNorm / softmax statistics (csrc/f16_ops.hip).  RN towers still compute
-    fp32-accurately in this mode and round their output to fp16.
+    clip/model.py:375-396): every tower keeps fp16 activations in HBM, one fp16 MFMA per product, fp32 accumulation,
+    fp32 LayerNorm / softmax statistics / BatchNorm arithmetic (csrc/f16_ops.hip, csrc/conv_f16.hip).  RN towers whose
+    width is not a multiple of 64 (RN50x4, RN50x16, toy towers) compute fp32-accurately in this mode and round their
+    output to fp16.
 """
 import os
 import re
@@ -190,17 +191,18 @@ class ModifiedResNet(nn.Module):
             setattr(self, f"layer{li}", nn.Sequential(*blocks))
         self.attnpool = AttentionPool2d(input_resolution // 32, width * 32, heads, output_dim)
         self._plan = None
+        self._plan16 = None
 
     def refresh_plan(self):
         """Re-fold the weights (call after loading new parameters)."""
-        self._plan = None
+        self._plan = self._plan16 = None
 
     def _apply(self, fn, *a, **k):
-        self._plan = None
+        self._plan = self._plan16 = None
         return super()._apply(fn, *a, **k)
 
     def _load_from_state_dict(self, *a, **k):        # load_state_dict(): the folded / packed plan is stale
-        self._plan = None
+        self._plan = self._plan16 = None
         return super()._load_from_state_dict(*a, **k)
 
     def _param_key(self):
@@ -244,12 +246,88 @@ class ModifiedResNet(nn.Module):
         self._plan_key = self._param_key()
         return P
 
+    def _f16_eligible(self):
+        """the fp16 kernels' shapes: every 1x1 conv reduces over a multiple of 64 channels, the stem convs over 32"""
+        return self.conv2.weight.shape[1] % 32 == 0 and self.conv3.weight.shape[0] % 64 == 0 and self.conv1.weight.shape[0] in (32, 64)
+
+    @torch.no_grad()
+    def _compile_f16(self):
+        """fp16 mode (clip/model.py:146, 375-396): conv weights as the checkpoint's fp16 values ([Cout][Cin] for 1x1,
+        [Cout][(cin/32, kh, kw, 32)] for 3x3), eval-mode BatchNorm as fp32 per-channel scale / bias for the conv epilogues;
+        the 3-channel stem conv keeps BatchNorm folded into fp32 weights (it runs on the vector ALUs)."""
+        def bn_sb(bn):
+            sc = bn.weight.detach().double() / torch.sqrt(bn.running_var.detach().double() + bn.eps)
+            return sc.float().contiguous(), (bn.bias.detach().double() - bn.running_mean.detach().double() * sc).float().contiguous()
+
+        def c1x1(conv, bn):
+            w = conv.weight.detach()
+            return (w.reshape(w.shape[0], w.shape[1]).to(torch.float16).contiguous(),) + bn_sb(bn)
+
+        def c3x3(conv, bn):
+            w, _ = ops.pack_conv_weight(conv.weight.detach().float(), chunk_major=32)
+            return (w.to(torch.float16).contiguous(),) + bn_sb(bn)
+        P = {}
+        w, b = _fold_bn(self.conv1.weight.float(), self.bn1)
+        P["stem1"] = (w.permute(2, 3, 1, 0).contiguous().float(), b.float().contiguous())
+        P["stem2"], P["stem3"] = c3x3(self.conv2, self.bn2), c3x3(self.conv3, self.bn3)
+        blocks = []
+        for li in (1, 2, 3, 4):
+            for blk in getattr(self, f"layer{li}"):
+                e = {"stride": blk.stride, "c1": c1x1(blk.conv1, blk.bn1), "c2": c3x3(blk.conv2, blk.bn2), "c3": c1x1(blk.conv3, blk.bn3)}
+                if blk.downsample is not None:
+                    e["ds"] = c1x1(getattr(blk.downsample, "0"), getattr(blk.downsample, "1"))
+                blocks.append(e)
+        P["blocks"] = blocks
+        ap = self.attnpool
+        f = lambda t: t.detach().float().contiguous()
+        P["attn"] = dict(pos=f(ap.positional_embedding), wq=f(ap.q_proj.weight), bq=f(ap.q_proj.bias),
+                         wkv=f(torch.cat([ap.k_proj.weight, ap.v_proj.weight], 0)), bkv=f(torch.cat([ap.k_proj.bias, ap.v_proj.bias], 0)),
+                         wc=f(ap.c_proj.weight), bc=f(ap.c_proj.bias))
+        self._plan16 = (self._param_key(), P)
+        return P
+
+    @torch.no_grad()
+    def forward_f16(self, x, return_stages=False):
+        """fp16 mode: fp16 NHWC activations in HBM, one fp16 MFMA per product, BatchNorm / ReLU / residual / average pool in the
+        fp32 epilogues (csrc/conv_f16.hip, csrc/f16_ops.hip).  Bottleneck.forward (clip/model.py:42-55) block by block."""
+        if getattr(self, "_plan16", None) is None or self._plan16[0] != self._param_key():
+            self._compile_f16()
+        P = self._plan16[1]
+        x = x.contiguous()
+        if x.dtype not in (torch.float16, torch.float32):
+            x = x.float()
+        x = ops.conv_stem_s2_f16(x, *P["stem1"])                       # NCHW image -> fp16 NHWC
+        x = ops.conv3x3_f16(x, *P["stem2"])
+        x = ops.conv3x3_f16(x, *P["stem3"], pool=2)                     # + the stem's AvgPool2d(2)
+        stages = {"stem": x}
+        bi = 0
+        for li in (1, 2, 3, 4):
+            for _ in getattr(self, f"layer{li}"):
+                e = P["blocks"][bi]; bi += 1
+                out = ops.conv1x1_f16(x, *e["c1"])
+                out = ops.conv3x3_f16(out, *e["c2"], pool=2 if e["stride"] == 2 else 1)     # conv2 + bn2 + relu (+ avgpool)
+                identity = x
+                if "ds" in e:
+                    if e["stride"] == 2:
+                        identity = ops.avgpool2_f16(x)
+                    identity = ops.conv1x1_f16(identity, *e["ds"], act=ops.ACT_NONE)
+                x = ops.conv1x1_f16(out, *e["c3"], residual=identity)   # bn3(conv3) + identity, ReLU
+            stages[f"layer{li}"] = x
+        a = P["attn"]
+        # attention pool: the fp32-accurate kernels on the fp16 feature map (0.2 MB per image), result rounded to fp16
+        out = ops.attnpool(x.float(), a["pos"], a["wq"], a["bq"], a["wkv"], a["bkv"], a["wc"], a["bc"], self.attnpool.num_heads)
+        out = out.to(torch.float16)
+        return (out, stages) if return_stages else out
+
     @torch.no_grad()
     def forward(self, x, return_stages=False):
-        if self.conv1.weight.dtype == torch.float16 and not return_stages:
-            # fp16 mode reaches the RN towers as fp16-stored weights only: the plan computes fp32-accurately from them
-            # (they are fp16-exact, like every checkpoint weight) and the embedding is rounded to the model dtype
-            return self.forward(x, return_stages=True)[0].to(torch.float16)
+        if self.conv1.weight.dtype == torch.float16:
+            if self._f16_eligible() and all(b.stride in (1, 2) for li in (1, 2, 3, 4) for b in getattr(self, f"layer{li}")):
+                return self.forward_f16(x, return_stages)
+            if not return_stages:
+                # widths the fp16 kernels do not serve (RN50x4: 80, RN50x16: 96, toy towers): the fp32-accurate plan on the
+                # fp16-stored weights, embedding rounded to the model dtype
+                return self.forward(x, return_stages=True)[0].to(torch.float16)
         if self._plan is not None and self._plan_key != self._param_key():
             self._plan = None
         P = self._plan or self._compile()

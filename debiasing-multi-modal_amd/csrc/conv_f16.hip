@@ -1,0 +1,457 @@
+// fp16 mode of the ModifiedResNet towers (the reference's GPU path: clip/model.py:146 casts the image to the conv weights'
+// dtype, convert_weights :375-396 leaves every conv weight in fp16, BatchNorm parameters stay fp32): activations are fp16
+// NHWC in HBM, every product is ONE fp16 MFMA (v_mfma_f32_32x32x16_f16) with fp32 accumulation; eval-mode BatchNorm
+// (per-channel scale / bias in fp32), ReLU, the residual add and the 2x2 average pools are applied to the fp32
+// accumulator and the result is rounded to fp16 ONCE when stored (the reference rounds after the conv, after the
+// BatchNorm and after the pool: this path is at least as accurate; tests pin it to the reference's own fp16 outputs).
+//
+//   conv3x3_f16_kernel<WM, WN, TN, POOL>   3x3 / stride 1 / pad 1 conv + BN + ReLU (+ AvgPool2d(2)), implicit GEMM:
+//       * a wave owns 128 pixels x 32 TN channels (4 x TN MFMA tiles: 4 + TN fragment reads per 4 TN MFMAs -- the LDS
+//         bandwidth a 64 x 64 wave tile spends per MFMA is what caps the 128 x 128 two-barrier kernels at half the peak);
+//         workgroup = 4 waves = 256 x 128 (WM, WN = 2, 2) or 512 x 64 / 512 x 32 pixels x channels (4, 1);
+//       * K order (cin / 32, kh, kw, 32).  For one (32-channel slab, kh) GROUP the three kw taps read the SAME BM + 2
+//         consecutive pixels shifted by 0 / 1 / 2 rows, so the strip goes to LDS once per group and the taps are LDS
+//         row shifts; border taps (image edges, rows past M) are masked when the fragment is read: the lane's address is
+//         redirected to a 256-B zero line at the same offset modulo 256 B (bank-neutral);
+//       * both operands reach LDS by LDS-DMA (buffer_load ... lds, 1 KB per wave instruction, the XOR swizzle that
+//         keeps ds_read_b128 conflict-free applied to the SOURCE chunk): no staging registers, no ds_write.  A strips
+//         are double-buffered per group, the per-tap W blocks (BN x 32) sit in a ring of 3-4 slots staged 2-3 taps
+//         ahead; waits are counted (s_waitcnt vmcnt(N) never drains the queue inside the loop); one barrier per tap =
+//         per 16 MFMAs of a wave; two workgroups per CU cover each other's barriers;
+//       * POOL: tile rows run 2x2-window-major (row = 4 * pooled pixel + dy * 2 + dx) so that a pooling window is the
+//         four registers r & 3 of one lane; the strip of a group becomes two strips (one per window row dy) STRIP rows
+//         apart, STRIP = 136 / 264 chosen (brute force) so that every 16-lane fragment read stays on 16 bank quads;
+//       * epilogue straight from the accumulators: the W rows of a wave's two 32-column blocks are staged interleaved
+//         (block j, column c <-> channel 2 c + j), so a lane holds two ADJACENT channels = one packed dword, 32 lanes =
+//         one 128-B row segment; rows >= M are masked by lane.
+//   stem_s2_f16_kernel      3x3 / stride 2 conv on the NCHW image (fp32 or fp16; rounded to fp16 like the reference's cast),
+//                           folded BatchNorm + ReLU, fp16 NHWC out
+//   avgpool2_f16_kernel     AvgPool2d(2) on fp16 NHWC (the downsample branches; fp32 sum in (dy, dx) order)
+//
+// Bounds: conv3x3 MFMA (2500 TFLOP/s dense fp16); stem / pool HBM.
+#include <stdlib.h>
+#include "common.h"
+
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u16;
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr unsigned OOR = 0x80000000u;
+constexpr long long EXT_LIM = 0x7FFFFFF0LL;
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t desc(const void* base, long long total, long long shift) {
+    long long ext = total - shift;
+    ext = ext < 0 ? 0 : (ext > EXT_LIM ? EXT_LIM : ext);
+    return __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)base + shift), 0, (int)ext, 0x00020000);
+}
+__device__ __forceinline__ void glds16(__amdgpu_buffer_rsrc_t r, unsigned char* lds_dst, unsigned voff, unsigned soff) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_dst, 16, voff, soff, 0, 0);
+#else
+    (void)r; (void)lds_dst; (void)voff; (void)soff;
+#endif
+}
+__device__ __forceinline__ unsigned pack2(float a, float b) {
+    const f16x2 v = {(_Float16)a, (_Float16)b};
+    return __builtin_bit_cast(unsigned, v);
+}
+
+struct ConvHP {
+    const u16* x; const u16* w; const float* scale; const float* bias; u16* y;
+    long long x_total, w_total, y_total;        // bytes
+    int B, H, W, Cin, N, M;                     // M = B * H * W conv output pixels
+    int tiles_n, n_tiles;
+};
+
+// standard-order pixel of the corner of pooled pixel mp (2x2 windows of an H x W map)
+__device__ __forceinline__ int pool_corner(const ConvHP& p, int mp) {
+    const int wp2 = p.W >> 1, hwp = (p.H >> 1) * wp2;
+    const int n = mp / hwp, rem = mp - n * hwp, hp = rem / wp2;
+    return (n * p.H + 2 * hp) * p.W + 2 * (rem - hp * wp2);
+}
+
+template <int BM> struct StripGeo { static constexpr int STRIP = BM == 256 ? 136 : 264; };
+
+template <int WM, int WN, int TN, int POOL>
+__global__ __launch_bounds__(256, 2) void conv3x3_f16_kernel(const ConvHP p) {
+    static_assert(WM * WN == 4 && (TN == 1 || TN == 2), "4 waves; a wave tile is 128 rows x 32 TN columns");
+    constexpr int TM = 4, BM = WM * 128, BN = WN * TN * 32;
+    constexpr int STRIP = StripGeo<BM>::STRIP;                   // POOL: LDS row of the dy = 1 strip
+    constexpr int NWIN = BM / 4;                                 // POOL: windows per tile; a strip holds 2 NWIN + 2 pixels
+    constexpr int NROWS = POOL ? 2 * STRIP : BM + 2;             // LDS rows (64 B: 32 channels) of an A stage
+    constexpr int NIA = (NROWS + 15) / 16, NA = (NIA + 3) / 4;   // wave-DMA instructions per A stage: all / per wave
+    constexpr int A_BYTES = NIA * 1024;
+    constexpr int NWT = BN / 16, NWI = (NWT + 3) / 4;            // wave-DMA instructions per W tap block: all / per wave
+    constexpr int W_BYTES = BN * 64;
+    constexpr int NWS = BM == 512 ? 3 : 4, D = NWS - 1;          // W ring slots, staging distance in taps
+    constexpr int ZOFF = 2 * A_BYTES, DUMP = ZOFF + 256, WOFF = DUMP + 1024;
+    constexpr int LDS_BYTES = WOFF + NWS * W_BYTES;
+    // vmcnt bookkeeping (per wave, in issue order).  Step t issues W(t + D), then -- on a group's first tap -- A(g + 1).
+    // At the top of step t everything up to W(t) (and A(g) on a group's first tap) must have landed; what may stay in flight:
+    constexpr int ALLOW0 = (D - 1) * NWI, ALLOW12 = (D - 1) * NWI + NA;
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[LDS_BYTES];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave / WN, wn = wave % WN;
+    const int fr = lane & 31, fh = lane >> 5;
+    const int tile = xcd_remap(blockIdx.x, p.n_tiles);
+    const int m0 = (tile / p.tiles_n) * BM, n0 = (tile % p.tiles_n) * BN;
+
+    // ---- descriptors rebased to the first pixel / channel the tile touches (tensors may exceed 2 GiB) --------------
+    const int pxf = POOL ? pool_corner(p, m0 >> 2) : m0;
+    const int px0 = pxf - 1 - p.W > 0 ? pxf - 1 - p.W : 0;
+    const __amdgpu_buffer_rsrc_t rsA = desc(p.x, p.x_total, (long long)px0 * p.Cin * 2);
+    const __amdgpu_buffer_rsrc_t rsW = desc(p.w, p.w_total, (long long)n0 * (9 * p.Cin) * 2);
+    const __amdgpu_buffer_rsrc_t rsA0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsW0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, 0, 0x00020000);
+
+    // ---- stager: wave-DMA instruction k of a block covers LDS rows 16 k .. 16 k + 15; lane -> (row 16 k + lane / 4, 16-B
+    //      slot lane % 4), which receives SOURCE chunk slot ^ swz(row).  Instructions k = wave + 4 i; the ones past the
+    //      block's end (every wave issues the same number: the waits are counted) fetch nothing and land in a dump KB.
+    unsigned fa_off[NA];        // byte offset of the group (slab 0, kh = 1) pixel from px0, + chunk; OOR = no such row
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int k = wave + 4 * i, row = 16 * k + (lane >> 2), c = (lane & 3) ^ ((row >> 2) & 3);
+        int pix = 0;
+        bool have = false;                                       // a row the stage uses (its pixel may still be < 0 or >= M: zeros)
+        if (k < NIA) {
+            if constexpr (POOL) {
+                const int dy = row >= STRIP, cc = row - dy * STRIP;                  // strip column: 0 / 2 NWIN + 1 = the halo pixels
+                if (cc < 2 * NWIN + 2) {
+                    const int wl = cc == 0 ? 0 : (cc == 2 * NWIN + 1 ? NWIN - 1 : (cc - 1) >> 1);
+                    const int dxo = cc == 0 ? -1 : (cc == 2 * NWIN + 1 ? 2 : (cc - 1) & 1);
+                    const int mp = (m0 >> 2) + wl;
+                    if (4 * mp < p.M) { pix = pool_corner(p, mp) + dy * p.W + dxo; have = true; }
+                }
+            } else if (row < BM + 2) {
+                pix = m0 - 1 + row; have = true;
+            }
+        }
+        // (a pixel index below px0 -- only pixel -1 of the first tile -- wraps past the extent: zeros; such a row only feeds masked taps)
+        fa_off[i] = have ? (unsigned)((pix - px0) * p.Cin) * 2u + c * 16u : OOR;
+    }
+    unsigned fw_off[NWI];
+#pragma unroll
+    for (int i = 0; i < NWI; ++i) {
+        const int k = wave + 4 * i, row = 16 * k + (lane >> 2), c = (lane & 3) ^ ((row >> 2) & 3);
+        const int wq = row / (TN * 32), within = row % (TN * 32), j = within >> 5, cc = within & 31;
+        const int nrel = wq * TN * 32 + (TN == 2 ? 2 * cc + j : cc);              // block j, column cc <-> channel 2 cc + j
+        fw_off[i] = (k < NWT && n0 + nrel < p.N) ? (unsigned)nrel * (unsigned)(9 * p.Cin * 2) + c * 16u : OOR;
+    }
+    auto issue_a = [&](int g, int stage, bool valid) {          // group g = (slab, kh): pixel shift (kh - 1) * W, channels slab * 32 ..
+        const int slab = g / 3, kh = g - slab * 3;
+        const unsigned delta = (unsigned)(((kh - 1) * p.W * p.Cin + slab * 32) * 2);
+        const __amdgpu_buffer_rsrc_t ra = valid ? rsA : rsA0;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int k = wave + 4 * i;
+            unsigned char* dst = k < NIA ? lds + stage * A_BYTES + k * 1024 : lds + DUMP;
+            glds16(ra, dst, fa_off[i] == OOR ? OOR : fa_off[i] + delta, 0u);
+        }
+    };
+    auto issue_w = [&](int t, int slot, bool valid) {           // tap step t: K columns [32 t, 32 t + 32)
+        const __amdgpu_buffer_rsrc_t rw = valid ? rsW : rsW0;
+#pragma unroll
+        for (int i = 0; i < NWI; ++i) {
+            const int k = wave + 4 * i;
+            unsigned char* dst = k < NWT ? lds + WOFF + slot * W_BYTES + k * 1024 : lds + DUMP;
+            glds16(rw, dst, fw_off[i], (unsigned)t * 64u);
+        }
+    };
+
+    // ---- fragment addresses (bytes from the stage / slot base) and the tap-validity masks of this lane's four A rows ----
+    int faddr[TM][3];           // row (lrow + kw), k-step 0; k-step 1 = ^ 32
+    unsigned fmask[TM];         // bit kh * 3 + kw
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int r = wm * 128 + i * 32 + fr, m = m0 + r;
+        unsigned msk = 0;
+        if (m < p.M) {
+            int ho, wo;
+            if constexpr (POOL) {
+                const int q = m & 3, mp = m >> 2, wp2 = p.W >> 1, hwp = (p.H >> 1) * wp2;
+                const int rem = mp % hwp, hp = rem / wp2;
+                ho = 2 * hp + (q >> 1); wo = 2 * (rem - hp * wp2) + (q & 1);
+            } else {
+                const int hw = p.H * p.W, rem = m % hw;
+                ho = rem / p.W; wo = rem - ho * p.W;
+            }
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw)
+                    if (ho + kh - 1 >= 0 && ho + kh - 1 < p.H && wo + kw - 1 >= 0 && wo + kw - 1 < p.W) msk |= 1u << (kh * 3 + kw);
+        }
+        fmask[i] = msk;
+        const int lrow = POOL ? ((r >> 1) & 1) * STRIP + (r >> 2) * 2 + (r & 1) : r;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) faddr[i][kw] = (lrow + kw) * 64 + ((fh ^ (((lrow + kw) >> 2) & 3)) << 4);
+    }
+    int waddr[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int r = wn * TN * 32 + j * 32 + fr;
+        waddr[j] = r * 64 + ((fh ^ ((r >> 2) & 3)) << 4);
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (tid < 16) *(u32x4*)(lds + ZOFF + tid * 16) = (u32x4){0u, 0u, 0u, 0u};      // the zero line (never staged over)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // ... written before this wave reaches the first barrier
+
+    const int G = (p.Cin >> 5) * 3, T = 3 * G;
+    issue_a(0, 0, true);
+#pragma unroll
+    for (int t = 0; t < D; ++t) issue_w(t, t, t < T);
+
+    int wslot = 0;                                               // slot of the current tap = t % NWS
+    for (int g = 0; g < G; ++g) {
+        const int kh = g % 3, astage = g & 1;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+            const int t = 3 * g + kw;
+            if (kw == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ALLOW0) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ALLOW12) : "memory");
+            __builtin_amdgcn_s_barrier();                        // every wave's share of W(t) / A(g) has landed; step t - 1 is read out
+            {
+                int ns = wslot + D; ns = ns >= NWS ? ns - NWS : ns;
+                issue_w(t + D, ns, t + D < T);
+            }
+            if (kw == 0) issue_a(g + 1, astage ^ 1, g + 1 < G);
+            const unsigned char* Wb = lds + WOFF + wslot * W_BYTES;
+            const int tap = kh * 3 + kw;
+            int aoff[TM];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const bool ok = (fmask[i] >> tap) & 1u;
+                aoff[i] = ok ? astage * A_BYTES + faddr[i][kw] : ZOFF + (faddr[i][kw] & 255);
+            }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                u32x4 af[TM], wf[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) af[i] = *(const u32x4*)(lds + (aoff[i] ^ (ks * 32)));
+#pragma unroll
+                for (int j = 0; j < TN; ++j) wf[j] = *(const u32x4*)(Wb + (waddr[j] ^ (ks * 32)));
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[i]), __builtin_bit_cast(f16x8, wf[j]),
+                                                                           acc[i][j], 0, 0, 0);
+            }
+            wslot = wslot + 1 == NWS ? 0 : wslot + 1;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // the (zero-extent) tail DMAs
+
+    // ---- epilogue: BatchNorm scale / bias, ReLU, (2x2 average), packed fp16 stores from the accumulator layout -----------
+    float sv[TN], bv[TN];
+    const int ncol = n0 + wn * TN * 32 + (TN == 2 ? 2 * fr : fr);        // this lane's first channel
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = ncol + j;
+        sv[j] = (p.scale && n < p.N) ? p.scale[n] : 1.f;
+        bv[j] = (p.bias && n < p.N) ? p.bias[n] : 0.f;
+    }
+    const bool col_ok = ncol < p.N;
+    if constexpr (POOL) {
+        // register group t = r >> 2 of row block i = window (wm * 32 + i * 8 + 2 t + fh) of the tile; its four rows are r & 3
+        const __amdgpu_buffer_rsrc_t rsY = desc(p.y, p.y_total, (long long)(m0 >> 2) * p.N * 2);
+        const int wins_left = (p.M >> 2) - (m0 >> 2);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int wl = wm * 32 + i * 8 + 2 * t + fh;
+                const unsigned voff = (col_ok && wl < wins_left) ? (unsigned)(wl * p.N + ncol) * 2u : OOR;
+                float s[TN];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    float v[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] = fmaxf(fmaf(acc[i][j][4 * t + q], sv[j], bv[j]), 0.f);
+                    s[j] = (((v[0] + v[1]) + v[2]) + v[3]) * 0.25f;                  // (dy, dx) order, like the pool kernel
+                }
+                if constexpr (TN == 2) __builtin_amdgcn_raw_buffer_store_b32(pack2(s[0], s[1]), rsY, voff, 0u, 0);
+                else __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, (_Float16)s[0]), rsY, voff, 0u, 0);
+            }
+    } else {
+        const __amdgpu_buffer_rsrc_t rsY = desc(p.y, p.y_total, (long long)m0 * p.N * 2);
+        const int rows_left = p.M - m0;
+        const int row_lim = (rows_left < BM ? rows_left : BM) - (wm * 128 + 4 * fh);   // row u of this lane is valid iff u < row_lim
+        const unsigned vbase = col_ok ? (unsigned)((wm * 128 + 4 * fh) * p.N + ncol) * 2u : OOR;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ru = i * 32 + (r & 3) + 8 * (r >> 2);
+                const unsigned voff = ru < row_lim ? vbase : OOR;                    // rows >= M: masked by lane
+                const float v0 = fmaxf(fmaf(acc[i][0][r], sv[0], bv[0]), 0.f);
+                if constexpr (TN == 2) {
+                    const float v1 = fmaxf(fmaf(acc[i][1][r], sv[1], bv[1]), 0.f);
+                    __builtin_amdgcn_raw_buffer_store_b32(pack2(v0, v1), rsY, voff, (unsigned)(ru * p.N * 2), 0);
+                } else {
+                    __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, (_Float16)v0), rsY, voff, (unsigned)(ru * p.N * 2), 0);
+                }
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// stem conv1: 3x3, stride 2, pad 1, Cin = 3, NCHW image -> fp16 NHWC, folded BatchNorm + ReLU.  One thread per output pixel
+// (27 taps in registers, weights broadcast from LDS, 8 output channels at a time); the workgroup's 256 pixels leave
+// through an LDS staging tile as one contiguous run of 16-B lane stores.  The image is rounded to fp16 first, as the
+// reference's `x.type(self.conv1.weight.dtype)` does (clip/model.py:146).
+// ---------------------------------------------------------------------------------------------------------------
+template <int COUT, typename TIN>
+__global__ __launch_bounds__(256) void stem_s2_f16_kernel(const TIN* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                          u16* __restrict__ y, int B, int H, int W, int Ho, int Wo) {
+    constexpr int PITCH = COUT + 8;                             // staging row pitch in halves (16-B aligned rows, shifted banks)
+    __shared__ __attribute__((aligned(16))) float sw[28 * COUT];
+    __shared__ __attribute__((aligned(16))) u16 stage[256 * PITCH];
+    for (int i = threadIdx.x; i < 27 * COUT; i += 256) sw[i] = w[i];
+    for (int i = threadIdx.x; i < COUT; i += 256) sw[27 * COUT + i] = bias ? bias[i] : 0.f;
+    __syncthreads();
+    const long long m0 = (long long)blockIdx.x * 256, m = m0 + threadIdx.x;
+    const long long M = (long long)B * Ho * Wo;
+    if (m < M) {
+        const int wo = (int)(m % Wo), ho = (int)((m / Wo) % Ho), n = (int)(m / ((long long)Wo * Ho));
+        float xin[27];
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int hi = ho * 2 - 1 + kh, wi = wo * 2 - 1 + kw;
+                const bool ok = hi >= 0 && hi < H && wi >= 0 && wi < W;
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    xin[(kh * 3 + kw) * 3 + c] = ok ? (float)(_Float16)(float)x[(((long long)n * 3 + c) * H + hi) * W + wi] : 0.f;
+            }
+        u16* so = stage + threadIdx.x * PITCH;
+        for (int c0 = 0; c0 < COUT; c0 += 8) {
+            float acc[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+#pragma unroll
+            for (int t = 0; t < 27; ++t) {
+                const f32x4 w0 = *(const f32x4*)(sw + t * COUT + c0);
+                const f32x4 w1 = *(const f32x4*)(sw + t * COUT + c0 + 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc[j] = fmaf(xin[t], w0[j], acc[j]);
+                    acc[4 + j] = fmaf(xin[t], w1[j], acc[4 + j]);
+                }
+            }
+            float o[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = fmaxf(acc[j] + sw[27 * COUT + c0 + j], 0.f);
+            *(u32x4*)(so + c0) = (u32x4){pack2(o[0], o[1]), pack2(o[2], o[3]), pack2(o[4], o[5]), pack2(o[6], o[7])};
+        }
+    }
+    __syncthreads();
+    constexpr int QPP = COUT / 8;                               // 16-B chunks per pixel
+    const long long run = (M - m0 < 256 ? M - m0 : 256) * QPP;
+    u32x4* yo = (u32x4*)(y + m0 * COUT);
+#pragma unroll 2
+    for (int q = threadIdx.x; q < 256 * QPP; q += 256)
+        if (q < run) yo[q] = *(const u32x4*)(stage + (q / QPP) * PITCH + (q % QPP) * 8);
+}
+
+// AvgPool2d(2) on fp16 NHWC: a thread owns 8 channels of one output pixel
+__global__ __launch_bounds__(256) void avgpool2_f16_kernel(const u16* __restrict__ x, u16* __restrict__ y, int H, int W, int C, long long n_out) {
+    const long long q = (long long)blockIdx.x * 256 + threadIdx.x;       // chunk index: output pixel * (C / 8) + chunk
+    if (q >= n_out) return;
+    const int cpp = C >> 3, Wo = W >> 1, Ho = H >> 1;
+    const long long op = q / cpp;
+    const int ch = (int)(q - op * cpp) * 8, wo = (int)(op % Wo), ho = (int)((op / Wo) % Ho);
+    const long long n = op / ((long long)Wo * Ho);
+    const u16* base = x + (((n * H + 2 * ho) * W + 2 * wo) * (long long)C + ch);
+    float s[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s[e] = 0.f;
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+            const f16x8 v = __builtin_bit_cast(f16x8, *(const u32x4*)(base + ((long long)dy * W + dx) * C));
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s[e] += (float)v[e];
+        }
+    *(u32x4*)(y + op * C + ch) = (u32x4){pack2(s[0] * 0.25f, s[1] * 0.25f), pack2(s[2] * 0.25f, s[3] * 0.25f),
+                                         pack2(s[4] * 0.25f, s[5] * 0.25f), pack2(s[6] * 0.25f, s[7] * 0.25f)};
+}
+
+template <int WM, int WN, int TN>
+int launch_conv(ConvHP& p, int pool, hipStream_t s) {
+    constexpr int BM = WM * 128, BN = WN * TN * 32;
+    p.tiles_n = (p.N + BN - 1) / BN;
+    p.n_tiles = ((p.M + BM - 1) / BM) * p.tiles_n;
+    if (pool) hipLaunchKernelGGL((conv3x3_f16_kernel<WM, WN, TN, 1>), dim3(p.n_tiles), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((conv3x3_f16_kernel<WM, WN, TN, 0>), dim3(p.n_tiles), dim3(256), 0, s, p);
+    DBMM_CHECK_LAUNCH();
+    return DBMM_OK;
+}
+
+}  // namespace
+
+// see include/dbmm.h
+extern "C" int dbmm_conv3x3_bn_relu_f16(const void* x, const void* w, const float* scale, const float* bias, void* y, int64_t B, int64_t H,
+                                        int64_t W, int64_t Cin, int64_t Cout, int pool, void* stream) {
+    if (!x || !w || !y) return DBMM_E_ARG;
+    if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || (pool != 0 && pool != 2)) return DBMM_E_SHAPE;
+    const long long M = (long long)B * H * W;
+    if (M > INT32_MAX - 1024) return DBMM_E_SHAPE;
+    if ((Cin % 32) || (Cout % 8)) return DBMM_E_UNSUPPORTED;
+    if (pool && ((H & 1) || (W & 1))) return DBMM_E_UNSUPPORTED;
+    if (!dbmm_aligned16(x) || !dbmm_aligned16(w) || !dbmm_aligned16(y)) return DBMM_E_ALIGN;
+    const long long wb = Cout * 9 * Cin * 2;
+    if (wb >= EXT_LIM || (long long)(1024 + 2 * W + 8) * Cin * 2 >= EXT_LIM || 1024LL * Cout * 2 >= EXT_LIM) return DBMM_E_UNSUPPORTED;
+    ConvHP p{};
+    p.x = (const u16*)x; p.w = (const u16*)w; p.scale = scale; p.bias = bias; p.y = (u16*)y;
+    p.x_total = M * Cin * 2; p.w_total = wb; p.y_total = (pool ? M / 4 : M) * Cout * 2;
+    p.B = (int)B; p.H = (int)H; p.W = (int)W; p.Cin = (int)Cin; p.N = (int)Cout; p.M = (int)M;
+    hipStream_t s = (hipStream_t)stream;
+    if (Cout <= 32) return launch_conv<4, 1, 1>(p, pool, s);
+    if (Cout <= 64) return launch_conv<4, 1, 2>(p, pool, s);
+    return launch_conv<2, 2, 2>(p, pool, s);
+}
+
+extern "C" int dbmm_conv_stem_s2_f16(const void* x_nchw, int x_is_f16, const float* w, const float* bias, void* y_nhwc, int64_t B, int64_t H,
+                                     int64_t W, int64_t Cout, void* stream) {
+    if (!x_nchw || !w || !y_nhwc) return DBMM_E_ARG;
+    if (B <= 0 || H <= 0 || W <= 0) return DBMM_E_SHAPE;
+    if (Cout != 32 && Cout != 64) return DBMM_E_UNSUPPORTED;
+    if (!dbmm_aligned16(y_nhwc) || !dbmm_aligned16(w)) return DBMM_E_ALIGN;
+    const int Ho = (int)((H - 1) / 2 + 1), Wo = (int)((W - 1) / 2 + 1);
+    const long long M = (long long)B * Ho * Wo;
+    const dim3 g((unsigned)((M + 255) / 256));
+    hipStream_t s = (hipStream_t)stream;
+#define DBMM_STEMH(C, T) hipLaunchKernelGGL((stem_s2_f16_kernel<C, T>), g, dim3(256), 0, s, (const T*)x_nchw, w, bias, (u16*)y_nhwc, (int)B, (int)H, (int)W, Ho, Wo)
+    if (Cout == 32) { if (x_is_f16) DBMM_STEMH(32, _Float16); else DBMM_STEMH(32, float); }
+    else { if (x_is_f16) DBMM_STEMH(64, _Float16); else DBMM_STEMH(64, float); }
+#undef DBMM_STEMH
+    DBMM_CHECK_LAUNCH();
+    return DBMM_OK;
+}
+
+extern "C" int dbmm_avgpool2_f16(const void* x, void* y, int64_t B, int64_t H, int64_t W, int64_t C, void* stream) {
+    if (!x || !y) return DBMM_E_ARG;
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || (H & 1) || (W & 1)) return DBMM_E_SHAPE;
+    if (C % 8) return DBMM_E_UNSUPPORTED;
+    if (!dbmm_aligned16(x) || !dbmm_aligned16(y)) return DBMM_E_ALIGN;
+    const long long n_out = B * (H / 2) * (W / 2) * (C / 8);
+    hipLaunchKernelGGL(avgpool2_f16_kernel, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const u16*)x, (u16*)y,
+                       (int)H, (int)W, (int)C, n_out);
+    DBMM_CHECK_LAUNCH();
+    return DBMM_OK;
+}

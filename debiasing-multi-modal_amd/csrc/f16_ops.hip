@@ -64,6 +64,8 @@ struct GemmHP {
     const u16* a; const u16* w; const float* bias; const u16* res; u16* c;
     long long lda, ldw, ldr, ldc, a_total, w_total;
     int M, N, K, act, tiles_n, n_tiles;
+    const float* oscale;        // optional per-output-channel scale of the accumulator (eval-mode BatchNorm of a 1x1 conv)
+    int res_first;              // 0: act(acc * s + b) + residual (transformer blocks); 1: act(acc * s + b + residual) (bottleneck conv3)
 };
 
 constexpr int GBM = 128;
@@ -205,8 +207,10 @@ __global__ __launch_bounds__(256, MINB) void gemm_f16_kernel(const GemmHP p) {
     float* Ls = (float*)lds + wave * (32 * G_LROW);
     const int ec = (lane % LPR) * 8, er = lane / LPR;
     const int n = n0 + wn0 + ec;
-    f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;
+    f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0, s0 = {1.f, 1.f, 1.f, 1.f}, s1 = s0;
     if (p.bias && n < p.N) { b0 = *(const f32x4*)(p.bias + n); b1 = *(const f32x4*)(p.bias + n + 4); }
+    if (p.oscale && n < p.N) { s0 = *(const f32x4*)(p.oscale + n); s1 = *(const f32x4*)(p.oscale + n + 4); }
+    const bool rf = p.res_first != 0;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         __syncthreads();
@@ -227,11 +231,15 @@ __global__ __launch_bounds__(256, MINB) void gemm_f16_kernel(const GemmHP p) {
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const int row = er + RPI * (t0 + t), m = m0 + wm0 + 32 * i + row;
-                const f32x4 v0 = *(const f32x4*)(Ls + row * G_LROW + ec) + b0, v1 = *(const f32x4*)(Ls + row * G_LROW + ec + 4) + b1;
+                const f32x4 v0 = *(const f32x4*)(Ls + row * G_LROW + ec) * s0 + b0, v1 = *(const f32x4*)(Ls + row * G_LROW + ec + 4) * s1 + b1;
                 const f16x8 rh = __builtin_bit_cast(f16x8, rv[t]);
                 float o[8];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) { o[q] = act_f(v0[q], p.act) + (float)rh[q]; o[4 + q] = act_f(v1[q], p.act) + (float)rh[4 + q]; }
+                for (int q = 0; q < 4; ++q) {
+                    const float r0 = (float)rh[q], r1 = (float)rh[4 + q];
+                    o[q] = act_f(v0[q] + (rf ? r0 : 0.f), p.act) + (rf ? 0.f : r0);
+                    o[4 + q] = act_f(v1[q] + (rf ? r1 : 0.f), p.act) + (rf ? 0.f : r1);
+                }
                 if (m < p.M && n < p.N)
                     *(u32x4*)(p.c + (long long)m * p.ldc + n) = (u32x4){pack2(o[0], o[1]), pack2(o[2], o[3]), pack2(o[4], o[5]), pack2(o[6], o[7])};
             }
@@ -439,8 +447,10 @@ __global__ __launch_bounds__(512, 1) void gemm_f16_8ph_kernel(const GemmHP p) {
     //  instruction -- the vector-memory path made it slower still: 848 -> 663 TF on the out-projection shape.)
     {
         const int n = en0 + wn0 + 2 * fr;
-        float bn0 = 0.f, bn1 = 0.f;
+        float bn0 = 0.f, bn1 = 0.f, sn0 = 1.f, sn1 = 1.f;
         if (p.bias) { bn0 = p.bias[n]; bn1 = p.bias[n + 1]; }
+        if (p.oscale) { sn0 = p.oscale[n]; sn1 = p.oscale[n + 1]; }
+        const bool rf = p.res_first != 0;
         // descriptors rebased to the wave's first row: the extent ends with the last valid row, so rows past M are dropped
         // by the hardware (no branches); lane offset = its column pair + its half's 4-row step, the row of a register is a
         // wave-uniform scalar offset
@@ -472,8 +482,9 @@ __global__ __launch_bounds__(512, 1) void gemm_f16_8ph_kernel(const GemmHP p) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const f16x2 rh = __builtin_bit_cast(f16x2, RES ? rvv[i][r] : 0u);
-                    float o0 = act_f(acc[i][0][r] + bn0, ACT), o1 = act_f(acc[i][1][r] + bn1, ACT);
-                    if (RES) { o0 += (float)rh[0]; o1 += (float)rh[1]; }
+                    const float r0 = RES ? (float)rh[0] : 0.f, r1 = RES ? (float)rh[1] : 0.f;
+                    float o0 = act_f(fmaf(acc[i][0][r], sn0, bn0) + (rf ? r0 : 0.f), ACT), o1 = act_f(fmaf(acc[i][1][r], sn1, bn1) + (rf ? r1 : 0.f), ACT);
+                    if (RES) { o0 += rf ? 0.f : r0; o1 += rf ? 0.f : r1; }
                     if (GF16_ABL & 2) { asm volatile("" ::"v"(acc[i][0][r]), "v"(acc[i][1][r]), "v"(rh)); continue; }
                     if (GF16_ABL & 1) { asm volatile("" ::"v"(pack2(o0, o1))); continue; }
                     const int ru = 32 * i + (r & 3) + 8 * (r >> 2);
@@ -832,17 +843,36 @@ inline unsigned grid_for(long long total) {
 
 }  // namespace
 
+namespace {
+int gemm_f16_impl(const void* a, int64_t lda, const void* w, int64_t ldw, const float* out_scale, const float* bias, const void* residual,
+                  int64_t ldr, int res_first, void* c, int64_t ldc, int64_t M, int64_t N, int64_t K, int act, void* stream);
+}
+
 extern "C" int dbmm_gemm_f16(const void* a, int64_t lda, const void* w, int64_t ldw, const float* bias, const void* residual,
                              int64_t ldr, void* c, int64_t ldc, int64_t M, int64_t N, int64_t K, int act, void* stream) {
+    return gemm_f16_impl(a, lda, w, ldw, nullptr, bias, residual, ldr, 0, c, ldc, M, N, K, act, stream);
+}
+
+// 1x1 conv + eval-mode BatchNorm (+ residual) + activation on fp16 NHWC maps = the same GEMM with a per-channel scale and the
+// residual added BEFORE the activation (Bottleneck.forward, clip/model.py:42-55); see include/dbmm.h
+extern "C" int dbmm_conv1x1_bn_act_f16(const void* x, const void* w, const float* scale, const float* bias, const void* residual, void* y,
+                                       int64_t M, int64_t Cin, int64_t Cout, int act, void* stream) {
+    return gemm_f16_impl(x, Cin, w, Cin, scale, bias, residual, Cout, 1, y, Cout, M, Cout, Cin, act, stream);
+}
+
+namespace {
+int gemm_f16_impl(const void* a, int64_t lda, const void* w, int64_t ldw, const float* out_scale, const float* bias, const void* residual,
+                  int64_t ldr, int res_first, void* c, int64_t ldc, int64_t M, int64_t N, int64_t K, int act, void* stream) {
     if (!a || !w || !c) return DBMM_E_ARG;
     if (M <= 0 || N <= 0 || K <= 0 || M > INT32_MAX || N > INT32_MAX || K > INT32_MAX) return DBMM_E_SHAPE;
     if (act < 0 || act > 2) return DBMM_E_ARG;
     if ((K % 64) || (N & 7)) return DBMM_E_UNSUPPORTED;
     if ((lda & 7) || (ldw & 7) || (ldc & 7) || (residual && (ldr & 7)) || !dbmm_aligned16(a) || !dbmm_aligned16(w) || !dbmm_aligned16(c) ||
-        (residual && !dbmm_aligned16(residual)) || (bias && !dbmm_aligned16(bias)))
+        (residual && !dbmm_aligned16(residual)) || (bias && !dbmm_aligned16(bias)) || (out_scale && !dbmm_aligned16(out_scale)))
         return DBMM_E_ALIGN;
     GemmHP p{};
     p.a = (const u16*)a; p.w = (const u16*)w; p.bias = bias; p.res = (const u16*)residual; p.c = (u16*)c;
+    p.oscale = out_scale; p.res_first = res_first;
     p.lda = lda; p.ldw = ldw; p.ldr = ldr; p.ldc = ldc;
     p.a_total = ((M - 1) * lda + K) * 2; p.w_total = ((N - 1) * ldw + K) * 2;
     p.M = (int)M; p.N = (int)N; p.K = (int)K; p.act = act;
@@ -872,6 +902,7 @@ extern "C" int dbmm_gemm_f16(const void* a, int64_t lda, const void* w, int64_t 
     DBMM_CHECK_LAUNCH();
     return DBMM_OK;
 }
+}  // namespace
 
 extern "C" int dbmm_mha_core_f16(const void* qkv, void* out, int64_t B, int64_t L, int64_t E, int64_t heads, int causal,
                                  void* stream) {

@@ -765,6 +765,73 @@ def gather_eot_f16(tokens_i32, x):
     return out
 
 
+# ---- fp16 mode of the ModifiedResNet towers (csrc/conv_f16.hip, csrc/f16_ops.hip) ------------------------------------------
+
+def conv1x1_f16(x, w, scale, bias, residual=None, act=ACT_RELU):
+    """y f16 NHWC = act(conv1x1(x) * scale + bias + residual); x f16 [..., Cin], w f16 [Cout][Cin]; None when the library has no
+    kernel for the shape (Cin % 64, Cout % 8)."""
+    require_cuda(x, w)
+    _f16c(x); _f16c(w)
+    Cout, Cin = w.shape
+    M = x.numel() // Cin
+    y = _empty(tuple(x.shape[:-1]) + (Cout,), device=x.device, dtype=torch.float16)
+    deep = Cout % 256 == 0 and Cin % 128 == 0 and M >= 16384 and get_option("f16_8ph")
+    t = _TimedTag("gemm_f16_8ph_kernel" if deep else "gemm_f16_kernel", 2.0 * M * Cout * Cin,
+                  2 * (M * Cin + Cout * Cin + M * Cout * (2 if residual is not None else 1)))
+    t.__enter__()
+    rc = _lib.lib().dbmm_conv1x1_bn_act_f16(ptr(x), ptr(w), ptr(scale), ptr(bias), ptr(residual), ptr(y), M, Cin, Cout, act, stream())
+    if rc == _lib.E_UNSUPPORTED:
+        return None
+    check(rc, "conv1x1_bn_act_f16")
+    t.__exit__(None, None, None)
+    return y
+
+
+def conv3x3_f16(x, w, scale, bias, pool=1):
+    """y f16 NHWC = [AvgPool2d(2)] relu(conv3x3(x, stride 1, pad 1) * scale + bias); x f16 [B,H,W,Cin], w f16 [Cout][(cin/32, kh, kw, 32)];
+    None when the library has no kernel for the shape."""
+    require_cuda(x, w)
+    _f16c(x); _f16c(w)
+    B, H, W, Cin = x.shape
+    Cout = w.shape[0]
+    y = _empty((B, H // pool, W // pool, Cout), device=x.device, dtype=torch.float16)
+    geo = "2, 2, 2" if Cout > 64 else ("4, 1, 2" if Cout > 32 else "4, 1, 1")
+    t = _TimedTag(f"conv3x3_f16_kernel<{geo}, {int(pool == 2)}>", 2.0 * B * H * W * Cout * 9 * Cin, 2 * (x.numel() + y.numel() + w.numel()))
+    t.__enter__()
+    rc = _lib.lib().dbmm_conv3x3_bn_relu_f16(ptr(x), ptr(w), ptr(scale), ptr(bias), ptr(y), B, H, W, Cin, Cout, 2 if pool == 2 else 0, stream())
+    if rc == _lib.E_UNSUPPORTED:
+        return None
+    check(rc, "conv3x3_bn_relu_f16")
+    t.__exit__(None, None, None)
+    return y
+
+
+def conv_stem_s2_f16(x_nchw, w, bias):
+    """stem conv1 (3x3, stride 2, folded BatchNorm, ReLU): NCHW f32 / f16 image -> f16 NHWC"""
+    require_cuda(x_nchw, w)
+    if x_nchw.dtype not in (torch.float16, torch.float32) or not x_nchw.is_contiguous():
+        raise _lib.DbmmError("conv_stem_s2_f16 needs a contiguous float16 / float32 image batch")
+    B, C, H, W = x_nchw.shape
+    if C != 3:
+        raise _lib.DbmmError("stem conv expects 3 input channels")
+    Cout = w.shape[-1]
+    y = _empty((B, (H - 1) // 2 + 1, (W - 1) // 2 + 1, Cout), device=x_nchw.device, dtype=torch.float16)
+    with _TimedTag("stem_s2_f16_kernel", 2.0 * y.numel() * 27, x_nchw.numel() * x_nchw.element_size() + 2 * y.numel()):
+        check(_lib.lib().dbmm_conv_stem_s2_f16(ptr(x_nchw), int(x_nchw.dtype == torch.float16), ptr(w), ptr(bias), ptr(y), B, H, W, Cout,
+                                               stream()), "conv_stem_s2_f16")
+    return y
+
+
+def avgpool2_f16(x):
+    require_cuda(x)
+    _f16c(x)
+    B, H, W, C = x.shape
+    y = _empty((B, H // 2, W // 2, C), device=x.device, dtype=torch.float16)
+    with _TimedTag("avgpool2_f16_kernel", 0.0, 2 * (x.numel() + y.numel())):
+        check(_lib.lib().dbmm_avgpool2_f16(ptr(x), ptr(y), B, H, W, C, stream()), "avgpool2_f16")
+    return y
+
+
 class _TimedTag:
     """profile hook for kernels outside the igemm family: fixed tag, caller-supplied FLOPs and algorithmic bytes"""
     def __init__(self, tag, flops, nbytes):

@@ -258,6 +258,23 @@ int dbmm_gemm_pair_8ph(const float* a, int64_t lda, const float* a_absmax, const
 /* c f16 [M][ldc] = act(a f16 [M][lda] @ w f16 [N][ldw]^T + bias f32 [N]) + residual f16 [M][ldr].  K % 64 == 0, N % 8 == 0. */
 int dbmm_gemm_f16(const void* a, int64_t lda, const void* w, int64_t ldw, const float* bias, const void* residual,
                   int64_t ldr, void* c, int64_t ldc, int64_t M, int64_t N, int64_t K, int act, void* stream);
+/* fp16 mode of the ModifiedResNet towers (clip/model.py:10-154 on the reference's GPU path: the image is cast to fp16, :146,
+ * conv weights are fp16, BatchNorm parameters fp32).  Activations f16 NHWC; eval-mode BatchNorm as fp32 per-channel
+ * scale / bias on the fp32 accumulator, residual add, ReLU and AvgPool2d(2) fused, ONE rounding to fp16 when stored.
+ *   conv1x1: y f16 [M][Cout] = act(x f16 [M][Cin] @ w f16 [Cout][Cin]^T * scale + bias + residual f16 [M][Cout])
+ *            (Bottleneck conv1 / conv3 / downsample conv).  Cin % 64 == 0, Cout % 8 == 0, else DBMM_E_UNSUPPORTED.
+ *   conv3x3: stride 1, pad 1, + BatchNorm + ReLU, pool = 0 | 2 (AvgPool2d(2) of the result: Bottleneck conv2 of a stride-2
+ *            block, stem conv3); w f16 [Cout][(cin / 32, kh, kw, 32)].  Cin % 32 == 0, Cout % 8 == 0; pool: H, W even.
+ *   stem:    3x3 / stride 2 / pad 1 on the NCHW image (f32, or f16 with x_is_f16; rounded to fp16 first like the
+ *            reference's cast), w f32 [kh][kw][3][Cout] with BatchNorm folded, bias f32 [Cout], ReLU, y f16 NHWC.  Cout 32 | 64.
+ *   avgpool2: AvgPool2d(2) on f16 NHWC (the downsample branch of a stride-2 block, clip/model.py:36-38). */
+int dbmm_conv1x1_bn_act_f16(const void* x, const void* w, const float* scale, const float* bias, const void* residual, void* y,
+                            int64_t M, int64_t Cin, int64_t Cout, int act, void* stream);
+int dbmm_conv3x3_bn_relu_f16(const void* x, const void* w, const float* scale, const float* bias, void* y, int64_t B, int64_t H,
+                             int64_t W, int64_t Cin, int64_t Cout, int pool, void* stream);
+int dbmm_conv_stem_s2_f16(const void* x_nchw, int x_is_f16, const float* w, const float* bias, void* y_nhwc, int64_t B, int64_t H,
+                          int64_t W, int64_t Cout, void* stream);
+int dbmm_avgpool2_f16(const void* x, void* y, int64_t B, int64_t H, int64_t W, int64_t C, void* stream);
 /* softmax(q k^T / sqrt(64)) v per (image, head), head_dim 64; qkv f16 [B*L][3E] (q | k | v), out f16 [B*L][E]. */
 int dbmm_mha_core_f16(const void* qkv, void* out, int64_t B, int64_t L, int64_t E, int64_t heads, int causal, void* stream);
 /* y f16 [rows][ldy] = LayerNorm(x f16 [rows][ldx]) with f32 gamma / beta [E], statistics in fp32.  E % 8 == 0. */

@@ -150,14 +150,121 @@ def test_fp16_mode_towers_vs_reference_fp16_path(arch, golden):
     assert model.dtype == torch.float32 and relerr(model.encode_image(img).cpu(), ref32) < 5e-5
 
 
-def test_fp16_mode_rn_tower_rounds_its_fp32_accurate_output():
-    sd = synth.clip_state_dict(3, "tiny-RN")
-    model = build_model(sd).cuda()
-    img = synth.images(103, 2, 64).cuda()
-    ref = model.encode_image(img)
-    convert_weights(model)
-    out = model.encode_image(img)
-    assert out.dtype == torch.float16 and relerr(out.float().cpu(), ref.cpu()) < 1e-3
+def test_fp16_mode_rn_towers_without_fp16_kernels_round_their_fp32_accurate_output(golden):
+    """widths the fp16 conv kernels do not serve (not a multiple of 64: RN50x4, RN50x16, the toy towers) keep the fp32-accurate
+    plan on the fp16-stored weights and round the embedding; still within the reference fp16 path's own rounding distance"""
+    for arch in ("tiny-RN", "tiny-RN-w32"):
+        h = golden(gname16(arch))
+        seed, B, res = int(h["seed"]), int(h["batch"]), int(h["res"])
+        model = build_model(synth.clip_state_dict(seed, arch)).cuda()
+        img = synth.images(seed + 100, B, res).cuda()
+        ref = model.encode_image(img)
+        convert_weights(model)
+        out = model.encode_image(img)
+        assert out.dtype == torch.float16 and relerr(out.float().cpu(), ref.cpu()) < 1e-3
+        assert relerr(out.float().cpu(), torch.from_numpy(h["embedding"])) < 3.0 * float(h["f16_vs_f32"])
+
+
+# ---- fp16 mode of the ModifiedResNet towers (csrc/conv_f16.hip) -----------------------------------------------------------
+
+def _bn(g, n):
+    return 0.5 + torch.rand((n,), device=DEV, generator=g), torch.randn((n,), device=DEV, generator=g) * 0.1
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,pool", [(3, 14, 14, 256, 256, 1), (2, 56, 56, 64, 64, 1), (5, 7, 7, 512, 512, 1), (2, 28, 28, 128, 128, 2),
+                                                 (3, 12, 20, 32, 32, 1), (2, 16, 24, 32, 64, 2), (9, 10, 6, 64, 192, 1), (4, 14, 14, 96, 136, 2),
+                                                 (1, 2, 2, 32, 8, 2), (1, 1, 1, 64, 64, 1), (40, 28, 28, 128, 128, 1), (33, 14, 14, 256, 256, 2)])
+def test_conv3x3_f16_kernel(B, H, W, Cin, Cout, pool):
+    """3x3 / stride 1 / pad 1 conv + BatchNorm + ReLU (+ AvgPool2d(2)) with fp16 operands against fp64 on the SAME fp16 values:
+    every tile geometry (256 x 128, 512 x 64, 512 x 32), image borders on 1x1 ... 56x56 maps, tiles that span several images
+    and end in a ragged tail, Cout tails, one / many channel slabs, pooled (window-major) and standard row order."""
+    g = torch.Generator(device=DEV); g.manual_seed(B * 131 + H * 7 + Cin + Cout + pool)
+    x = torch.relu(torch.randn((B, H, W, Cin), device=DEV, generator=g) * 1.5).half()
+    w = (torch.randn((Cout, Cin, 3, 3), device=DEV, generator=g) * (9 * Cin) ** -0.5).half()
+    sc, b = _bn(g, Cout)
+    wp, wl = ops.pack_conv_weight(w.float(), chunk_major=32)
+    assert wl == ops.WL_CHUNK32_MAJOR
+    y = ops.conv3x3_f16(x, wp.half().contiguous(), sc, b, pool=pool)
+    assert y is not None and y.dtype == torch.float16
+    ref = torch.relu(F.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), None, padding=1) * sc.double().view(1, -1, 1, 1) + b.double().view(1, -1, 1, 1))
+    if pool == 2:
+        ref = F.avg_pool2d(ref, 2)
+    ref = ref.permute(0, 2, 3, 1)
+    assert tuple(y.shape) == tuple(ref.shape)
+    assert relerr(y.double().cpu(), ref.cpu()) < 1.5e-3            # one fp16 rounding of the result + fp32 accumulation
+
+
+@pytest.mark.parametrize("M,Cin,Cout,res,act", [(56 * 56 * 3, 64, 256, True, 1), (28 * 28 * 5, 512, 128, False, 1), (14 * 14 * 90, 1024, 256, False, 1),
+                                                (14 * 14 * 90 + 12, 256, 1024, True, 1), (7 * 7 * 40, 2048, 512, False, 1), (300, 64, 64, False, 0),
+                                                (17000, 128, 512, True, 1)])
+def test_conv1x1_f16(M, Cin, Cout, res, act):
+    """1x1 conv + BatchNorm (+ residual added BEFORE the ReLU, clip/model.py:53-54) on both fp16 GEMM kernels vs fp64"""
+    g = torch.Generator(device=DEV); g.manual_seed(M + Cin + Cout)
+    x = torch.relu(torch.randn((M, Cin), device=DEV, generator=g)).half()
+    w = (torch.randn((Cout, Cin), device=DEV, generator=g) * Cin ** -0.5).half()
+    sc, b = _bn(g, Cout)
+    r = (torch.randn((M, Cout), device=DEV, generator=g) * 2.0).half() if res else None
+    y = ops.conv1x1_f16(x, w, sc, b, residual=r, act=act)
+    v = x.double() @ w.double().t() * sc.double() + b.double()
+    if res:
+        v = v + r.double()
+    if act == 1:
+        v = torch.relu(v)
+    assert y is not None and y.dtype == torch.float16 and relerr(y.double().cpu(), v.cpu()) < 1.5e-3
+
+
+@pytest.mark.parametrize("B,R,Cout,half_in", [(3, 64, 32, False), (2, 224, 32, True), (2, 96, 64, False), (1, 50, 32, False)])
+def test_stem_and_avgpool_f16(B, R, Cout, half_in):
+    g = torch.Generator(device=DEV); g.manual_seed(R + Cout)
+    x = torch.randn((B, 3, R, R), device=DEV, generator=g)
+    w = torch.randn((3, 3, 3, Cout), device=DEV, generator=g) * 0.2; b = torch.randn((Cout,), device=DEV, generator=g) * 0.1
+    y = ops.conv_stem_s2_f16(x.half() if half_in else x, w, b)
+    ref = torch.relu(F.conv2d(x.half().double(), w.permute(3, 2, 0, 1).double(), b.double(), stride=2, padding=1)).permute(0, 2, 3, 1)
+    assert y.dtype == torch.float16 and tuple(y.shape) == tuple(ref.shape) and relerr(y.double().cpu(), ref.cpu()) < 1e-3
+    if y.shape[1] % 2 == 0:
+        p = ops.avgpool2_f16(y)
+        assert relerr(p.double().cpu(), F.avg_pool2d(y.double().permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1).cpu()) < 1e-3
+
+
+def test_fp16_mode_rn50_vs_reference_fp16_path(golden):
+    """the whole RN50 tower in fp16 mode (fp16 NHWC activations, the fp16 conv / GEMM kernels) against the reference's OWN
+    fp16 path run on CPU: per-stage samples and the embedding within 3 x the reference's fp16-vs-fp32 distance"""
+    arch = "RN50"
+    g, h = golden(gname(arch)), golden(gname16(arch))
+    seed, B, res = int(h["seed"]), int(h["batch"]), int(h["res"])
+    model = convert_weights(build_model(synth.clip_state_dict(seed, arch)).cuda())
+    img = synth.images(seed + 100, B, res).cuda()
+    out, stages = model.visual(img.half(), return_stages=True)
+    assert out.dtype == torch.float16 and all(t.dtype == torch.float16 for t in stages.values())
+    tol = 3.0 * float(h["f16_vs_f32"])
+    from conftest import summary
+    for k, t in stages.items():
+        sums, sample = summary(t.float())
+        ref = h[f"{k}_sample"]
+        e = np.abs(sample - ref).max() / np.abs(ref).max()
+        print(f"RN50 fp16 {k}: sample error {e:.2e} of the maximum")
+        assert e < tol, (k, e)
+        assert abs(sums[1] - h[f"{k}_sums"][1]) <= 2e-3 * h[f"{k}_sums"][1], k
+    e16, e32 = relerr(out.float().cpu(), torch.from_numpy(h["embedding"])), relerr(out.float().cpu(), torch.from_numpy(g["embedding"]))
+    print(f"RN50 fp16: embedding vs reference fp16 path {e16:.2e} (tol {tol:.2e}), vs fp32 golden {e32:.2e}")
+    assert e16 < tol and e32 < tol
+    assert F.cosine_similarity(out.float().cpu(), torch.from_numpy(h["embedding"]), dim=1).min() > 0.99999
+    # encode_image with an fp32 batch takes the same path (the image is rounded to fp16 like the reference's cast)
+    assert torch.equal(model.encode_image(img), out)
+    ops.profile_begin()
+    model.encode_image(img)
+    tags = set(ops.profile_end())
+    assert any(t.startswith("conv3x3_f16_kernel<") for t in tags) and "stem_s2_f16_kernel" in tags, sorted(tags)
+
+
+def test_fp16_mode_rn50_large_batch_rows_are_independent():
+    """a batch the fixture does not cover (every conv tile geometry full): any row equals the same image in a small batch"""
+    model = convert_weights(build_model(synth.clip_state_dict(2, "RN50")).cuda())
+    img = synth.images(9, 80, 224).cuda()
+    big = model.encode_image(img)
+    small = model.encode_image(img[37:40].contiguous())
+    assert torch.isfinite(big).all() and relerr(big[37:40].float().cpu(), small.float().cpu()) < 2e-3
+    assert torch.equal(big, model.encode_image(img))
 
 
 def test_model_half_is_the_same_mode_as_convert_weights(golden):
