@@ -64,6 +64,7 @@ struct ConvHP {
     long long x_total, w_total, y_total;        // bytes
     int B, H, W, Cin, N, M;                     // M = B * H * W conv output pixels
     int tiles_n, n_tiles;
+    const u16* res; int act;                    // 1x1 kernel: residual [M][N] added before the activation; act 0 | 1 (ReLU)
 };
 
 // standard-order pixel of the corner of pooled pixel mp (2x2 windows of an H x W map)
@@ -308,6 +309,148 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16_kernel(const ConvHP p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// 1x1 conv + BatchNorm (+ residual) (+ ReLU) for the HBM-bound shapes (short K or narrow N: layers 1 - 2 of an RN50, every
+// downsample conv): the same machinery with one tap per 32-channel slab and nothing to mask.  A ring of THREE slots, each
+// a K chunk of both operands (BM x 32 of A, BN x 32 of W: 20 - 24 KB), staged two chunks ahead by LDS-DMA: two
+// workgroups per CU keep ~100 KB in flight per CU, which is what it takes to stream at the HBM rate with a ~2 us round trip
+// (the register-staged 128 x 128 GEMM holds 3.3 TB/s on these shapes).  Wave tile 32 TM x 64 (TM = 4: 256 x 128 tiles;
+// TM = 2: 256 x 64 for Cout <= 64).  Epilogue from the accumulator layout; the residual is loaded in the same shape
+// (one packed dword = two channels per lane, 128-B row segments), a row block's 16 loads in flight together.
+// ---------------------------------------------------------------------------------------------------------------
+template <int WM, int WN, int TM, int RES>
+__global__ __launch_bounds__(256, 2) void conv1x1_f16_kernel(const ConvHP p) {
+    static_assert(WM * WN == 4 && (TM == 2 || TM == 4), "4 waves; a wave tile is 32 TM rows x 64 columns");
+    constexpr int TN = 2, BM = WM * TM * 32, BN = WN * 64;
+    constexpr int NA = BM / 64;                                  // wave-DMA instructions per wave and A chunk (16 rows each)
+    constexpr int NWT = BN / 16, NWI = (NWT + 3) / 4;            // ... per W chunk: all / per wave
+    constexpr int A_BYTES = BM * 64, W_BYTES = BN * 64, SLOT = A_BYTES + W_BYTES;
+    constexpr int DUMP = 3 * SLOT, LDS_BYTES = DUMP + 1024;
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[LDS_BYTES];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave / WN, wn = wave % WN;
+    const int fr = lane & 31, fh = lane >> 5;
+    const int tile = xcd_remap(blockIdx.x, p.n_tiles);
+    const int m0 = (tile / p.tiles_n) * BM, n0 = (tile % p.tiles_n) * BN;
+    const __amdgpu_buffer_rsrc_t rsA = desc(p.x, p.x_total, (long long)m0 * p.Cin * 2);
+    const __amdgpu_buffer_rsrc_t rsW = desc(p.w, p.w_total, (long long)n0 * p.Cin * 2);
+    const __amdgpu_buffer_rsrc_t rsA0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsW0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, 0, 0x00020000);
+
+    unsigned fa_off[NA], fw_off[NWI];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int k = wave + 4 * i, row = 16 * k + (lane >> 2), c = (lane & 3) ^ ((row >> 2) & 3);
+        fa_off[i] = m0 + row < p.M ? (unsigned)row * (unsigned)(p.Cin * 2) + c * 16u : OOR;
+    }
+#pragma unroll
+    for (int i = 0; i < NWI; ++i) {
+        const int k = wave + 4 * i, row = 16 * k + (lane >> 2), c = (lane & 3) ^ ((row >> 2) & 3);
+        const int wq = row >> 6, within = row & 63, j = within >> 5, cc = within & 31;
+        const int nrel = wq * 64 + 2 * cc + j;                                       // block j, column cc <-> channel 2 cc + j
+        fw_off[i] = (k < NWT && n0 + nrel < p.N) ? (unsigned)nrel * (unsigned)(p.Cin * 2) + c * 16u : OOR;
+    }
+    auto issue = [&](int t, int slot, bool valid) {              // K chunk t = channels [32 t, 32 t + 32) of both operands
+        const __amdgpu_buffer_rsrc_t ra = valid ? rsA : rsA0, rw = valid ? rsW : rsW0;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) glds16(ra, lds + slot * SLOT + (wave + 4 * i) * 1024, fa_off[i], (unsigned)t * 64u);
+#pragma unroll
+        for (int i = 0; i < NWI; ++i) {
+            const int k = wave + 4 * i;
+            glds16(rw, k < NWT ? lds + slot * SLOT + A_BYTES + k * 1024 : lds + DUMP, fw_off[i], (unsigned)t * 64u);
+        }
+    };
+    int faddr[TM], waddr[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int r = wm * (TM * 32) + i * 32 + fr;
+        faddr[i] = r * 64 + ((fh ^ ((r >> 2) & 3)) << 4);
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int r = wn * 64 + j * 32 + fr;
+        waddr[j] = A_BYTES + r * 64 + ((fh ^ ((r >> 2) & 3)) << 4);
+    }
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int G = p.Cin >> 5;
+    issue(0, 0, true);
+    issue(1, 1, 1 < G);
+    int slot = 0;
+    for (int t = 0; t < G; ++t) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA + NWI) : "memory");       // chunk t has landed; chunk t + 1 may be in flight
+        __builtin_amdgcn_s_barrier();
+        {
+            int ns = slot + 2; ns = ns >= 3 ? ns - 3 : ns;                     // the slot chunk t - 1 was read from
+            issue(t + 2, ns, t + 2 < G);
+        }
+        const unsigned char* Sb = lds + slot * SLOT;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            u32x4 af[TM], wf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = *(const u32x4*)(Sb + (faddr[i] ^ (ks * 32)));
+#pragma unroll
+            for (int j = 0; j < TN; ++j) wf[j] = *(const u32x4*)(Sb + (waddr[j] ^ (ks * 32)));
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[i]), __builtin_bit_cast(f16x8, wf[j]),
+                                                                       acc[i][j], 0, 0, 0);
+        }
+        slot = slot + 1 == 3 ? 0 : slot + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    // ---- epilogue ----------------------------------------------------------------------------------------------------
+    const int ncol = n0 + wn * 64 + 2 * fr;
+    const bool col_ok = ncol < p.N;
+    float sv[2], bv[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        sv[j] = (p.scale && ncol + j < p.N) ? p.scale[ncol + j] : 1.f;
+        bv[j] = (p.bias && ncol + j < p.N) ? p.bias[ncol + j] : 0.f;
+    }
+    const __amdgpu_buffer_rsrc_t rsY = desc(p.y, p.y_total, (long long)m0 * p.N * 2);
+    const __amdgpu_buffer_rsrc_t rsR = RES ? desc(p.res, p.y_total, (long long)m0 * p.N * 2) : rsY;
+    const int rows_left = p.M - m0;
+    const int row_lim = (rows_left < BM ? rows_left : BM) - (wm * (TM * 32) + 4 * fh);
+    const unsigned vbase = col_ok ? (unsigned)((wm * (TM * 32) + 4 * fh) * p.N + ncol) * 2u : OOR;
+    const bool relu = p.act == DBMM_ACT_RELU;
+    unsigned rv[RES ? 2 : 1][16];
+    auto load_res = [&](int i, int set) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ru = i * 32 + (r & 3) + 8 * (r >> 2);
+            rv[set][r] = __builtin_amdgcn_raw_buffer_load_b32(rsR, ru < row_lim ? vbase : OOR, (unsigned)(ru * p.N * 2), 0);
+        }
+    };
+    if constexpr (RES) load_res(0, 0);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        if constexpr (RES) { if (i + 1 < TM) load_res(i + 1, (i + 1) & 1); }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ru = i * 32 + (r & 3) + 8 * (r >> 2);
+            float v0 = fmaf(acc[i][0][r], sv[0], bv[0]), v1 = fmaf(acc[i][1][r], sv[1], bv[1]);
+            if constexpr (RES) {
+                const f16x2 rh = __builtin_bit_cast(f16x2, rv[i & 1][r]);
+                v0 += (float)rh[0]; v1 += (float)rh[1];
+            }
+            if (relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
+            __builtin_amdgcn_raw_buffer_store_b32(pack2(v0, v1), rsY, ru < row_lim ? vbase : OOR, (unsigned)(ru * p.N * 2), 0);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // stem conv1: 3x3, stride 2, pad 1, Cin = 3, NCHW image -> fp16 NHWC, folded BatchNorm + ReLU.  One thread per output pixel
 // (27 taps in registers, weights broadcast from LDS, 8 output channels at a time); the workgroup's 256 pixels leave
 // through an LDS staging tile as one contiguous run of 16-B lane stores.  The image is rounded to fp16 first, as the
@@ -424,6 +567,33 @@ extern "C" int dbmm_conv3x3_bn_relu_f16(const void* x, const void* w, const floa
     if (Cout <= 32) return launch_conv<4, 1, 1>(p, pool, s);
     if (Cout <= 64) return launch_conv<4, 1, 2>(p, pool, s);
     return launch_conv<2, 2, 2>(p, pool, s);
+}
+
+// the streaming 1x1 kernel (see dbmm_conv1x1_bn_act_f16 in f16_ops.hip, which routes the HBM-bound shapes here)
+int dbmm_conv1x1_stream_f16(const void* x, const void* w, const float* scale, const float* bias, const void* residual, void* y, int64_t M,
+                            int64_t Cin, int64_t Cout, int act, void* stream) {
+    if (!x || !w || !y) return DBMM_E_ARG;
+    if (M <= 0 || Cin <= 0 || Cout <= 0 || M > INT32_MAX - 1024) return DBMM_E_SHAPE;
+    if (act != DBMM_ACT_NONE && act != DBMM_ACT_RELU) return DBMM_E_UNSUPPORTED;
+    if ((Cin % 32) || (Cout % 8)) return DBMM_E_UNSUPPORTED;
+    if (!dbmm_aligned16(x) || !dbmm_aligned16(w) || !dbmm_aligned16(y) || (residual && !dbmm_aligned16(residual))) return DBMM_E_ALIGN;
+    if (Cout * Cin * 2 >= EXT_LIM || 512LL * Cin * 2 >= EXT_LIM || 512LL * Cout * 2 >= EXT_LIM) return DBMM_E_UNSUPPORTED;
+    ConvHP p{};
+    p.x = (const u16*)x; p.w = (const u16*)w; p.scale = scale; p.bias = bias; p.y = (u16*)y; p.res = (const u16*)residual; p.act = act;
+    p.x_total = M * Cin * 2; p.w_total = Cout * Cin * 2; p.y_total = M * Cout * 2;
+    p.Cin = (int)Cin; p.N = (int)Cout; p.M = (int)M;
+    hipStream_t s = (hipStream_t)stream;
+    if (Cout <= 64) {
+        p.tiles_n = 1; p.n_tiles = (int)((M + 255) / 256);
+        if (residual) hipLaunchKernelGGL((conv1x1_f16_kernel<4, 1, 2, 1>), dim3(p.n_tiles), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((conv1x1_f16_kernel<4, 1, 2, 0>), dim3(p.n_tiles), dim3(256), 0, s, p);
+    } else {
+        p.tiles_n = (int)((Cout + 127) / 128); p.n_tiles = (int)((M + 255) / 256) * p.tiles_n;
+        if (residual) hipLaunchKernelGGL((conv1x1_f16_kernel<2, 2, 4, 1>), dim3(p.n_tiles), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((conv1x1_f16_kernel<2, 2, 4, 0>), dim3(p.n_tiles), dim3(256), 0, s, p);
+    }
+    DBMM_CHECK_LAUNCH();
+    return DBMM_OK;
 }
 
 extern "C" int dbmm_conv_stem_s2_f16(const void* x_nchw, int x_is_f16, const float* w, const float* bias, void* y_nhwc, int64_t B, int64_t H,

@@ -855,8 +855,19 @@ extern "C" int dbmm_gemm_f16(const void* a, int64_t lda, const void* w, int64_t 
 
 // 1x1 conv + eval-mode BatchNorm (+ residual) + activation on fp16 NHWC maps = the same GEMM with a per-channel scale and the
 // residual added BEFORE the activation (Bottleneck.forward, clip/model.py:42-55); see include/dbmm.h
+int dbmm_conv1x1_stream_f16(const void* x, const void* w, const float* scale, const float* bias, const void* residual, void* y, int64_t M,
+                            int64_t Cin, int64_t Cout, int act, void* stream);       // conv_f16.hip
+
 extern "C" int dbmm_conv1x1_bn_act_f16(const void* x, const void* w, const float* scale, const float* bias, const void* residual, void* y,
                                        int64_t M, int64_t Cin, int64_t Cout, int act, void* stream) {
+    // option conv1x1_stream: 0 = always the GEMM kernels, 1 (default) = the streaming kernel where the GEMM is HBM-bound
+    // (short K or narrow N), 2 = wherever it applies
+    const int mode = dbmm_opt(OPT_CONV1X1_STREAM);
+    const bool gemm8 = (Cout % 256) == 0 && (Cin % 128) == 0 && M >= 16384;          // what dbmm_gemm_f16 gives the 8-phase kernel
+    if ((mode == 2 || (mode == 1 && !gemm8)) && (act == DBMM_ACT_NONE || act == DBMM_ACT_RELU) && (Cin % 32) == 0) {
+        const int rc = dbmm_conv1x1_stream_f16(x, w, scale, bias, residual, y, M, Cin, Cout, act, stream);
+        if (rc != DBMM_E_UNSUPPORTED) return rc;
+    }
     return gemm_f16_impl(x, Cin, w, Cin, scale, bias, residual, Cout, 1, y, Cout, M, Cout, Cin, act, stream);
 }
 

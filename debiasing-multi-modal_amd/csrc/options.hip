@@ -34,7 +34,7 @@ const OptDef kOpts[DBMM_OPT_COUNT] = {
     {"conv_patch", 1},         // (host wrappers) 32-channel stem convs on the persistent patch kernel
     {"mha_x2", 1},             // (host wrappers) parity attention core on fp16-pair products
     {"adapter_step_fused", 1}, // adapter train step as the single cooperative launch where it applies (0: the multi-launch step)
-    {"conv_f16_halo", 1},      // fp16 mode: 3x3 convs on the strip-reuse kernel (0: per-tap)
+    {"conv1x1_stream", 1},     // fp16 mode 1x1 convs: 0 the GEMM kernels / 1 the streaming kernel for HBM-bound shapes / 2 wherever it applies
 };
 
 std::atomic<int> g_val[DBMM_OPT_COUNT];

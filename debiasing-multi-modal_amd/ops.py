@@ -775,8 +775,11 @@ def conv1x1_f16(x, w, scale, bias, residual=None, act=ACT_RELU):
     Cout, Cin = w.shape
     M = x.numel() // Cin
     y = _empty(tuple(x.shape[:-1]) + (Cout,), device=x.device, dtype=torch.float16)
-    deep = Cout % 256 == 0 and Cin % 128 == 0 and M >= 16384 and get_option("f16_8ph")
-    t = _TimedTag("gemm_f16_8ph_kernel" if deep else "gemm_f16_kernel", 2.0 * M * Cout * Cin,
+    deep = Cout % 256 == 0 and Cin % 128 == 0 and M >= 16384                            # dbmm_conv1x1_bn_act_f16's own routing rule
+    mode = get_option("conv1x1_stream")
+    stream_k = (mode == 2 or (mode == 1 and not deep)) and act in (ACT_NONE, ACT_RELU) and Cin % 32 == 0
+    tag = "conv1x1_f16_kernel" if stream_k else ("gemm_f16_8ph_kernel" if deep and get_option("f16_8ph") else "gemm_f16_kernel")
+    t = _TimedTag(tag, 2.0 * M * Cout * Cin,
                   2 * (M * Cin + Cout * Cin + M * Cout * (2 if residual is not None else 1)))
     t.__enter__()
     rc = _lib.lib().dbmm_conv1x1_bn_act_f16(ptr(x), ptr(w), ptr(scale), ptr(bias), ptr(residual), ptr(y), M, Cin, Cout, act, stream())

@@ -196,9 +196,12 @@ def test_conv3x3_f16_kernel(B, H, W, Cin, Cout, pool):
 
 @pytest.mark.parametrize("M,Cin,Cout,res,act", [(56 * 56 * 3, 64, 256, True, 1), (28 * 28 * 5, 512, 128, False, 1), (14 * 14 * 90, 1024, 256, False, 1),
                                                 (14 * 14 * 90 + 12, 256, 1024, True, 1), (7 * 7 * 40, 2048, 512, False, 1), (300, 64, 64, False, 0),
-                                                (17000, 128, 512, True, 1)])
-def test_conv1x1_f16(M, Cin, Cout, res, act):
-    """1x1 conv + BatchNorm (+ residual added BEFORE the ReLU, clip/model.py:53-54) on both fp16 GEMM kernels vs fp64"""
+                                                (17000, 128, 512, True, 1), (256 * 3 + 77, 96, 136, True, 1), (5, 32, 8, False, 1)])
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_conv1x1_f16(M, Cin, Cout, res, act, mode, option):
+    """1x1 conv + BatchNorm (+ residual added BEFORE the ReLU, clip/model.py:53-54) vs fp64: on the two fp16 GEMM kernels
+    (conv1x1_stream = 0), the streaming kernel everywhere (2) and the default routing (1)"""
+    option("conv1x1_stream", mode)
     g = torch.Generator(device=DEV); g.manual_seed(M + Cin + Cout)
     x = torch.relu(torch.randn((M, Cin), device=DEV, generator=g)).half()
     w = (torch.randn((Cout, Cin), device=DEV, generator=g) * Cin ** -0.5).half()
@@ -210,7 +213,10 @@ def test_conv1x1_f16(M, Cin, Cout, res, act):
         v = v + r.double()
     if act == 1:
         v = torch.relu(v)
-    assert y is not None and y.dtype == torch.float16 and relerr(y.double().cpu(), v.cpu()) < 1.5e-3
+    if y is None:
+        assert mode == 0 and Cin % 64                       # the GEMM kernels need K % 64 == 0
+        return
+    assert y.dtype == torch.float16 and relerr(y.double().cpu(), v.cpu()) < 1.5e-3
 
 
 @pytest.mark.parametrize("B,R,Cout,half_in", [(3, 64, 32, False), (2, 224, 32, True), (2, 96, 64, False), (1, 50, 32, False)])

@@ -264,5 +264,22 @@ def test_ragged_tiles_do_not_write_outside_their_outputs(tail, guarded):
     for pool in (1, 2):
         ops.conv_bn_act(xs, wqp, cq["b"], None, 3, 3, 1, 1, ops.ACT_RELU, wql, w_planes_f16=cq["ph"], w_exp=cq["we"],
                         x_absmax=xs.abs().max().reshape(1), y_absmax=torch.zeros(1, device=DEV), out_scale=cq["sc"], pool=pool)
+    # --- fp16-mode conv kernels (csrc/conv_f16.hip): LDS-DMA loaders, packed stores from the accumulator layout, rows masked by lane
+    xh = torch.relu(rn(1, 4, (256 * 2 + t4) // 4, 64)).half()                                   # M = 2 tiles + tail
+    for cout, pool in ((64, 1), (136, 1), (32, 1), (64, 2), (136, 2)):
+        wh = (rn(cout, 9 * 64) * 0.05).half()
+        yh = ops.conv3x3_f16(xh, wh, torch.ones(cout, device=DEV), torch.zeros(cout, device=DEV), pool=pool)
+        assert yh is not None and torch.isfinite(yh).all()
+    for cin, cout, res in ((64, 64, False), (64, 256, True), (128, 136, True)):
+        xa = rn(256 * 2 + tail, cin).half(); wa = (rn(cout, cin) * cin ** -0.5).half()
+        ra = rn(256 * 2 + tail, cout).half() if res else None
+        for mode in (0, 2):
+            ops.set_option("conv1x1_stream", mode)
+            ya = ops.conv1x1_f16(xa, wa, torch.ones(cout, device=DEV), torch.zeros(cout, device=DEV), residual=ra)
+            v = xa.double() @ wa.double().t() + (ra.double() if res else 0.0)
+            assert relerr(ya.double().cpu(), torch.relu(v).cpu()) < 1.5e-3
+        ops.set_option("conv1x1_stream", 1)
+    ys = ops.conv_stem_s2_f16(rn(3, 3, 40, 40), (rn(3, 3, 3, 32) * 0.2).contiguous(), rn(32) * 0.1)
+    ops.avgpool2_f16(ys)
     torch.cuda.synchronize()
     guarded.check()
