@@ -250,30 +250,41 @@ class CustomCLIP(nn.Module):
         if not self.training:
             raise RuntimeError("train_step needs classifier.train()")
         new_ad, old_ad = self._step_adapters()
-
-        def pack(ad):
-            l0, bn, l3 = ad.layers[0], ad.layers[1], ad.layers[3]
-            return (l0.weight, l0.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked,
-                    l3.weight, l3.bias)
-        new = pack(new_ad)
-        trainable = [new[0], new[1], new[2], new[3], new[7], new[8]]
+        w1 = new_ad.layers[0].weight
         group = optimizer.param_groups[0]
-        owned = {id(p) for g in optimizer.param_groups for p in g["params"]}
-        if len(optimizer.param_groups) != 1 or any(id(p) not in owned for p in trainable):
-            raise RuntimeError("train_step: the optimiser must hold the adapter's six tensors in one param group")
-        first = any("momentum_buffer" not in optimizer.state[p] for p in trainable)
-        bufs = []
-        for p in trainable:
-            st = optimizer.state[p]
-            if "momentum_buffer" not in st or st["momentum_buffer"] is None:
-                st["momentum_buffer"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
-            bufs.append(st["momentum_buffer"])
+        plan = getattr(self, "_step_plan", None)
+        first = False
+        # the argument block of the C call is rebuilt only when something it points at was replaced (a parameter moved or
+        # re-created, another optimiser, a momentum buffer swapped): the step is launch-bound, ~40 us of Python per call show
+        if (plan is None or plan["opt"] is not optimizer or plan["w1"] is not w1 or plan["w1_ptr"] != w1.data_ptr()
+                or plan["mb"] is not optimizer.state[w1].get("momentum_buffer") or plan["old"] is not old_ad):
+            def pack(ad):
+                l0, bn, l3 = ad.layers[0], ad.layers[1], ad.layers[3]
+                return (l0.weight, l0.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked,
+                        l3.weight, l3.bias)
+            new = pack(new_ad)
+            trainable = [new[0], new[1], new[2], new[3], new[7], new[8]]
+            owned = {id(p) for g in optimizer.param_groups for p in g["params"]}
+            if len(optimizer.param_groups) != 1 or any(id(p) not in owned for p in trainable):
+                raise RuntimeError("train_step: the optimiser must hold the adapter's six tensors in one param group")
+            first = any("momentum_buffer" not in optimizer.state[p] for p in trainable)
+            bufs = []
+            for p in trainable:
+                st = optimizer.state[p]
+                if "momentum_buffer" not in st or st["momentum_buffer"] is None:
+                    st["momentum_buffer"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                bufs.append(st["momentum_buffer"])
+            plan = dict(opt=optimizer, w1=w1, w1_ptr=w1.data_ptr(), mb=optimizer.state[w1]["momentum_buffer"], old=old_ad,
+                        args=ops.adapter_step_args([t.data for t in new], bufs,
+                                                   [t.data for t in pack(old_ad)] if old_ad is not None else None),
+                        H=new[0].shape[0], with_old=old_ad is not None)
+            self._step_plan = plan
         tn = self._text("group" if use_group else "class", features.device)
         with torch.no_grad():
             return ops.adapter_train_step(
-                features.detach().contiguous(), labels.contiguous(), [t.data for t in new], bufs,
-                [t.data for t in pack(old_ad)] if old_ad is not None else None, getattr(self, "ebd_weight", 0.5), tn,
-                self.temperature, group["lr"], group.get("momentum", 0.0), group.get("weight_decay", 0.0), first)
+                features.detach().contiguous(), labels.contiguous(), plan["args"], plan["H"], plan["with_old"],
+                getattr(self, "ebd_weight", 0.5), tn, self.temperature, group["lr"], group.get("momentum", 0.0),
+                group.get("weight_decay", 0.0), first)
 
 
 class MultipleAdapter(CustomCLIP):

@@ -6,6 +6,17 @@
 // dbmm_gemm_bias_act (fp32 MFMA).
 #include "common.h"
 
+// adapter_step.hip: the products of the step for the reference's shapes (H = 128, D % 128 == 0)
+bool dbmm_adapter_fast_shape(int64_t B, int64_t D, int64_t H);
+size_t dbmm_adapter_bwd_fast_floats(int64_t B, int64_t D);
+int dbmm_adapter_fwd_fast(const float* x, const float* w1, const float* b1, const float* gamma, const float* beta, float* running_mean,
+                          float* running_var, int64_t* nbt, const float* w2, const float* b2, float* h, float* mean, float* invstd, float* r,
+                          float* z, int64_t B, int64_t D, int train, float eps, float momentum, hipStream_t s);
+int dbmm_adapter_bwd_fast(const float* x, const float* dz, const float* h, const float* mean, const float* invstd, const float* r, const float* gamma,
+                          const float* beta, const float* w2, float* dw1, float* db1, float* dgamma, float* dbeta, float* dw2, float* db2,
+                          float* dh, float* scratch, int64_t B, int64_t D, hipStream_t s, const float** dw1part = nullptr,
+                          const float** db1part = nullptr, int* nsplit = nullptr);
+
 namespace {
 
 // ---- BatchNorm1d(H) statistics over the batch: 8 columns x 32 row-lanes per block ---------
@@ -221,8 +232,20 @@ template <int CMAX>
 __global__ __launch_bounds__(256) void l2norm_sim_ce_bwd_kernel(
     const float* __restrict__ z, const float* __restrict__ inv_norm, float w_new, const float* __restrict__ tn,
     const float* __restrict__ logits, const long long* __restrict__ labels, const float* __restrict__ dlogits,
-    float invT, float gscale, float* __restrict__ dz, int B, int D4, int C) {
+    float invT, float gscale, float* __restrict__ dz, int B, int D4, int C, const float* __restrict__ loss_rows,
+    float* __restrict__ loss_mean) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (loss_mean && blockIdx.x == gridDim.x - 1) {
+        // the fused step folds the batch mean of the per-row losses (written by the forward launch) into this launch:
+        // mean_reduce_kernel's arithmetic, statement for statement, so that both give the same bits
+        __shared__ float red[4];
+        float s = 0.f;
+        for (int i = threadIdx.x; i < B; i += 256) s += loss_rows[i];
+        s = wave_sum(s);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) *loss_mean = ((red[0] + red[1]) + (red[2] + red[3])) / (float)B;
+    }
     if (row >= B) return;
     float dl[CMAX];
     if (dlogits) {   // upstream gradient given (autograd path): dl = dlogits / T * blend weight
@@ -267,14 +290,18 @@ struct SgdArgs {
     const float* g[16];
     float* m[16];
     long long n[16];
+    int ns[16];            // > 1: g[t] holds ns[t] partial gradients n[t] apart, summed here in order (grad_reduce_kernel's order)
 };
 __global__ __launch_bounds__(256) void sgd_kernel(const SgdArgs a, float lr, float mu, float wd, int first) {
     const int t = blockIdx.y;
     float* p = a.p[t]; const float* g = a.g[t]; float* m = a.m[t];
     const long long n = a.n[t];
+    const int ns = a.ns[t];
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         const float w = p[i];
-        const float gi = fmaf(wd, w, g[i]);
+        float gv = g[i];
+        for (int sidx = 1; sidx < ns; ++sidx) gv += g[(long long)sidx * n + i];
+        const float gi = fmaf(wd, w, gv);
         const float b = first ? gi : fmaf(mu, m[i], gi);
         m[i] = b;
         p[i] = w - lr * b;
@@ -376,6 +403,11 @@ extern "C" int dbmm_adapter_fwd(const float* x, const float* w1, const float* b1
     if (!x || !w1 || !b1 || !gamma || !beta || !w2 || !b2 || !h || !r || !z) return DBMM_E_ARG;
     if (!running_mean || !running_var) return DBMM_E_ARG;
     if (train && (!mean || !invstd)) return DBMM_E_ARG;
+    if (dbmm_adapter_fast_shape(B, D, H) && (!train || B >= 2) && dbmm_aligned16(x) && dbmm_aligned16(w1) && dbmm_aligned16(w2) && dbmm_aligned16(h) &&
+        dbmm_aligned16(r) && dbmm_aligned16(z) && dbmm_aligned16(gamma) && dbmm_aligned16(beta) &&
+        dbmm_aligned16(train ? mean : running_mean) && dbmm_aligned16(train ? invstd : running_var) && dbmm_opt(OPT_ADAPTER_STEP_FUSED))
+        return dbmm_adapter_fwd_fast(x, w1, b1, gamma, beta, running_mean, running_var, nbt, w2, b2, h, mean, invstd, r, z, B, D, train, eps,
+                                     momentum, (hipStream_t)stream);
     int rc = dbmm_gemm_bias_act(x, D, 0, w1, D, 0, b1, nullptr, 0, h, H, B, H, D, 1.f, DBMM_ACT_NONE, stream);
     if (rc) return rc;
     if (train) {
@@ -389,9 +421,9 @@ extern "C" int dbmm_adapter_fwd(const float* x, const float* w1, const float* b1
     return dbmm_gemm_bias_act(r, H, 0, w2, H, 0, b2, nullptr, 0, z, D, B, D, H, 1.f, DBMM_ACT_NONE, stream);
 }
 
+// dr [B][H] | dh [B][H] | the fast path's partial sums (adapter_step.hip)
 extern "C" size_t dbmm_workspace_bytes_adapter_bwd(int64_t B, int64_t D, int64_t H) {
-    (void)D;
-    return (size_t)(2 * B * H) * sizeof(float);
+    return ((size_t)(2 * B * H) + (dbmm_adapter_fast_shape(B, D, H) ? dbmm_adapter_bwd_fast_floats(B, D) : 0)) * sizeof(float);
 }
 
 extern "C" int dbmm_adapter_bwd(const float* x, const float* dz, const float* h, const float* mean,
@@ -408,6 +440,9 @@ extern "C" int dbmm_adapter_bwd(const float* x, const float* dz, const float* h,
     hipStream_t s = (hipStream_t)stream;
     float* dr = (float*)workspace;
     float* dh = dr + B * H;
+    if (dbmm_adapter_fast_shape(B, D, H) && dbmm_aligned16(x) && dbmm_aligned16(dz) && dbmm_aligned16(r) && dbmm_aligned16(w2) && dbmm_aligned16(dw1) &&
+        dbmm_aligned16(dw2) && dbmm_aligned16(db1) && dbmm_aligned16(db2) && dbmm_opt(OPT_ADAPTER_STEP_FUSED))
+        return dbmm_adapter_bwd_fast(x, dz, h, mean, invstd, r, gamma, beta, w2, dw1, db1, dgamma, dbeta, dw2, db2, dh, dh + B * H, B, D, s);
     int rc;
     // dW2[D][H] = dz^T r   (reduction over the batch: both operands K-major)
     rc = dbmm_gemm_bias_act(dz, D, 1, r, H, 1, nullptr, nullptr, 0, dw2, H, D, H, B, 1.f, DBMM_ACT_NONE, stream);
@@ -466,10 +501,20 @@ extern "C" int dbmm_l2norm_sim_ce_fwd(const float* z, const float* z_old, float 
     return DBMM_OK;
 }
 
+static int ce_bwd_impl(const float* z, const float* inv_norm, float ebd_weight, int blended, const float* tn, const float* logits,
+                       const int64_t* labels, const float* dlogits, float temperature, float grad_scale, float* dz, int64_t B, int64_t D,
+                       int64_t C, const float* loss_rows, float* loss_mean, void* stream);
+
 extern "C" int dbmm_l2norm_sim_ce_bwd(const float* z, const float* inv_norm, float ebd_weight, int blended,
                                       const float* tn, const float* logits, const int64_t* labels,
                                       const float* dlogits, float temperature, float grad_scale, float* dz,
                                       int64_t B, int64_t D, int64_t C, void* stream) {
+    return ce_bwd_impl(z, inv_norm, ebd_weight, blended, tn, logits, labels, dlogits, temperature, grad_scale, dz, B, D, C, nullptr, nullptr, stream);
+}
+
+static int ce_bwd_impl(const float* z, const float* inv_norm, float ebd_weight, int blended, const float* tn, const float* logits,
+                       const int64_t* labels, const float* dlogits, float temperature, float grad_scale, float* dz, int64_t B, int64_t D,
+                       int64_t C, const float* loss_rows, float* loss_mean, void* stream) {
     if (!z || !inv_norm || !tn || !dz) return DBMM_E_ARG;
     if (!dlogits && (!logits || !labels)) return DBMM_E_ARG;
     if (B <= 0 || D <= 0 || (D & 3) || C <= 0 || C > 8 || B > INT32_MAX) return DBMM_E_SHAPE;
@@ -480,24 +525,32 @@ extern "C" int dbmm_l2norm_sim_ce_bwd(const float* z, const float* inv_norm, flo
     hipStream_t s = (hipStream_t)stream;
     if (C <= 4)
         hipLaunchKernelGGL(l2norm_sim_ce_bwd_kernel<4>, grid, dim3(256), 0, s, z, inv_norm, w_new, tn, logits,
-                           (const long long*)labels, dlogits, 1.f / temperature, gs, dz, (int)B, (int)(D / 4), (int)C);
+                           (const long long*)labels, dlogits, 1.f / temperature, gs, dz, (int)B, (int)(D / 4), (int)C, loss_rows, loss_mean);
     else
         hipLaunchKernelGGL(l2norm_sim_ce_bwd_kernel<8>, grid, dim3(256), 0, s, z, inv_norm, w_new, tn, logits,
-                           (const long long*)labels, dlogits, 1.f / temperature, gs, dz, (int)B, (int)(D / 4), (int)C);
+                           (const long long*)labels, dlogits, 1.f / temperature, gs, dz, (int)B, (int)(D / 4), (int)C, loss_rows, loss_mean);
     DBMM_CHECK_LAUNCH();
     return DBMM_OK;
 }
 
+static int sgd_impl(int64_t n, float* const* params, const float* const* grads, float* const* bufs, const int64_t* sizes, const int* nsplit,
+                    float lr, float momentum, float weight_decay, int first_step, void* stream);
+
 extern "C" int dbmm_sgd_momentum(int64_t n, float* const* params, const float* const* grads, float* const* bufs,
                                  const int64_t* sizes, float lr, float momentum, float weight_decay, int first_step,
                                  void* stream) {
+    return sgd_impl(n, params, grads, bufs, sizes, nullptr, lr, momentum, weight_decay, first_step, stream);
+}
+
+static int sgd_impl(int64_t n, float* const* params, const float* const* grads, float* const* bufs, const int64_t* sizes, const int* nsplit,
+                    float lr, float momentum, float weight_decay, int first_step, void* stream) {
     if (!params || !grads || !bufs || !sizes) return DBMM_E_ARG;
     if (n <= 0 || n > 16) return DBMM_E_SHAPE;
     SgdArgs a{};
     long long mx = 0;
     for (int i = 0; i < n; ++i) {
         if (!params[i] || !grads[i] || !bufs[i] || sizes[i] <= 0) return DBMM_E_ARG;
-        a.p[i] = params[i]; a.g[i] = grads[i]; a.m[i] = bufs[i]; a.n[i] = sizes[i];
+        a.p[i] = params[i]; a.g[i] = grads[i]; a.m[i] = bufs[i]; a.n[i] = sizes[i]; a.ns[i] = nsplit ? nsplit[i] : 1;
         if (sizes[i] > mx) mx = sizes[i];
     }
     long long bx = (mx + 1023) / 1024;
@@ -542,11 +595,11 @@ extern "C" int dbmm_gather_rows(const float* table, const int64_t* idx, float* o
 
 // ---- one call = one training step body (final_main.py:455-466 / :610-623) ----------------------
 // workspace layout (floats): h, r [B*H]x2 | z [B*D] | mean, invstd [H]x2 | (old: h, r, z, mean, invstd)
-// | inv_norm [B] | dz [B*D] | dw1 [H*D] db1 dgamma dbeta [H]x3 dw2 [D*H] db2 [D] | bwd scratch [2*B*H]
+// | inv_norm [B] | dz [B*D] | dw1 [H*D] db1 dgamma dbeta [H]x3 dw2 [D*H] db2 [D] | bwd scratch [2*B*H + B*D]
 static size_t train_step_floats(int64_t B, int64_t D, int64_t H, int with_old) {
     size_t n = 2 * B * H + B * D + 2 * H;
     if (with_old) n += 2 * B * H + B * D + 2 * H;
-    n += B + B * D + (H * D + 3 * H + D * H + D) + 2 * B * H;
+    n += B + B * D + (H * D + 3 * H + D * H + D) + dbmm_workspace_bytes_adapter_bwd(B, D, H) / sizeof(float);
     return (n + 3) / 4 * 4 + 64;
 }
 
@@ -603,19 +656,33 @@ extern "C" int dbmm_adapter_train_step(const float* x, const int64_t* labels, fl
                               oz, B, D, H, 1, eps, bn_momentum, stream);
         if (rc) return rc;
     }
-    rc = dbmm_l2norm_sim_ce_fwd(z, oz, ebd_weight, tn, labels, temperature, logits, loss_rows, loss_mean, nullptr,
+    // the batch mean of the losses is folded into the backward launch, the sums of the batch-split dW1 / db1 partials into
+    // the SGD launch (same arithmetic as the stand-alone launches the autograd path uses: same bits)
+    const bool fast = dbmm_adapter_fast_shape(B, D, H) && dbmm_opt(OPT_ADAPTER_STEP_FUSED) && dbmm_aligned16(x);
+    rc = dbmm_l2norm_sim_ce_fwd(z, oz, ebd_weight, tn, labels, temperature, logits, loss_rows, fast ? nullptr : loss_mean, nullptr,
                                 inv_norm, B, D, C, stream);
     if (rc) return rc;
-    rc = dbmm_l2norm_sim_ce_bwd(z, inv_norm, ebd_weight, with_old, tn, logits, labels, nullptr, temperature, 1.f, dz, B,
-                                D, C, stream);
-    if (rc) return rc;
-    rc = dbmm_adapter_bwd(x, dz, h, mean, invstd, r, gamma, beta, w2, dw1, db1, dgamma, dbeta, dw2, db2, B, D, H, bws,
-                          (size_t)(2 * B * H) * sizeof(float), stream);
+    rc = ce_bwd_impl(z, inv_norm, ebd_weight, with_old, tn, logits, labels, nullptr, temperature, 1.f, dz, B, D, C, fast ? loss_rows : nullptr,
+                     fast ? loss_mean : nullptr, stream);
     if (rc) return rc;
     float* ps[6] = {w1, b1, gamma, beta, w2, b2};
     const float* gs[6] = {dw1, db1, dgamma, dbeta, dw2, db2};
     float* ms[6] = {m_w1, m_b1, m_gamma, m_beta, m_w2, m_b2};
     const int64_t ns[6] = {H * D, H, H, H, D * H, D};
+    if (fast) {
+        float* dh = bws + B * H;
+        const float *dw1part = nullptr, *db1part = nullptr;
+        int nsplit = 1;
+        rc = dbmm_adapter_bwd_fast(x, dz, h, mean, invstd, r, gamma, beta, w2, dw1, db1, dgamma, dbeta, dw2, db2, dh, dh + B * H, B, D,
+                                   (hipStream_t)stream, &dw1part, &db1part, &nsplit);
+        if (rc) return rc;
+        gs[0] = dw1part; gs[1] = db1part;
+        const int nsp[6] = {nsplit, nsplit, 1, 1, 1, 1};
+        return sgd_impl(6, ps, gs, ms, ns, nsp, lr, momentum, weight_decay, first_step, stream);
+    }
+    rc = dbmm_adapter_bwd(x, dz, h, mean, invstd, r, gamma, beta, w2, dw1, db1, dgamma, dbeta, dw2, db2, B, D, H, bws,
+                          dbmm_workspace_bytes_adapter_bwd(B, D, H), stream);
+    if (rc) return rc;
     return dbmm_sgd_momentum(6, ps, gs, ms, ns, lr, momentum, weight_decay, first_step, stream);
 }
 

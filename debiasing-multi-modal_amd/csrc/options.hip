@@ -33,7 +33,7 @@ const OptDef kOpts[DBMM_OPT_COUNT] = {
     {"mha_valu", 0},           // 1: lane-per-query attention kernel instead of the MFMA one
     {"conv_patch", 1},         // (host wrappers) 32-channel stem convs on the persistent patch kernel
     {"mha_x2", 1},             // (host wrappers) parity attention core on fp16-pair products
-    {"adapter_step_fused", 1}, // adapter train step as the single cooperative launch where it applies (0: the multi-launch step)
+    {"adapter_step_fused", 1}, // adapter forward / backward on the purpose-built kernels of adapter_step.hip (0: the general GEMM kernel)
     {"conv1x1_stream", 1},     // fp16 mode 1x1 convs: 0 the GEMM kernels / 1 the streaming kernel for HBM-bound shapes / 2 wherever it applies
 };
 

@@ -602,7 +602,7 @@ def adapter_bwd(x, dz, h, mean, invstd, r, gamma, beta, w2):
     check(_lib.lib().dbmm_adapter_bwd(ptr(x), ptr(dz), ptr(h), ptr(mean), ptr(invstd), ptr(r), ptr(gamma), ptr(beta),
                                       ptr(w2), ptr(dw1), ptr(db1), ptr(dgamma), ptr(dbeta), ptr(dw2), ptr(db2), B, D, H,
                                       ptr(ws), nbytes, stream()), "adapter_bwd")
-    return dw1, db1, dgamma, dbeta, dw2, db2, ws[B * H:].view(B, H)   # last = dh (for an optional dx)
+    return dw1, db1, dgamma, dbeta, dw2, db2, ws[B * H:2 * B * H].view(B, H)   # last = dh (for an optional dx)
 
 
 def sgd_momentum(params, grads, bufs, lr, momentum, weight_decay, first_step):
@@ -636,33 +636,50 @@ def group_loss_sum(loss_rows, g, sums):
 _step_ws = {}
 
 
-def adapter_train_step(x, labels, new, bufs, old, ebd_weight, tn, temperature, lr, momentum, weight_decay, first_step):
-    """one fused training-step body (dbmm_adapter_train_step).  `new` / `old` are tuples
-    (w1, b1, gamma, beta, running_mean, running_var, nbt, w2, b2); `bufs` the six momentum buffers
-    in the order (w1, b1, gamma, beta, w2, b2); `old` may be None."""
-    require_cuda(x, labels, tn)
+def adapter_step_launches(B, D, H, with_old=False):
+    """kernel launches of one dbmm_adapter_train_step call on the purpose-built kernels (csrc/adapter_step.hip): forward 3
+    (K-split fc1, BatchNorm statistics, BatchNorm + ReLU + fc2; 3 more for a frozen old adapter), cosine logits + CE forward,
+    its backward (+ the loss mean), backward 3 (dW2 / dr, BatchNorm backward + dW2 sums, dW1), SGD (+ dW1 sums); None for
+    shapes that take the general GEMM kernel (H != 128 or D % 128 != 0)"""
+    if H != 128 or D % 128 or not get_option("adapter_step_fused"):
+        return None
+    return 9 + (3 if with_old else 0)
+
+
+def adapter_step_args(new, bufs, old):
+    """the 24 parameter / buffer pointers of dbmm_adapter_train_step, converted once: `new` / `old` are tuples
+    (w1, b1, gamma, beta, running_mean, running_var, nbt, w2, b2); `bufs` the six momentum buffers in the order
+    (w1, b1, gamma, beta, w2, b2); `old` may be None.  Valid while those tensors keep their storage."""
+    require_cuda(*new)
+    return tuple(ctypes.c_void_p(ptr(t)) for t in list(new) + list(bufs)) + \
+        (tuple(ctypes.c_void_p(ptr(t)) for t in old) if old is not None else (None,) * 9)
+
+
+def adapter_train_step(x, labels, args, H, with_old, ebd_weight, tn, temperature, lr, momentum, weight_decay, first_step):
+    """one fused training-step body (dbmm_adapter_train_step); `args` from adapter_step_args()."""
+    if not (x.is_cuda and labels.is_cuda and tn.is_cuda):
+        require_cuda(x, labels, tn)
     _f32c(x)
     B, D = x.shape
-    H = new[0].shape[0]
     C = tn.shape[0]
     dev = x.device
-    key = (dev.index, B, D, H, old is not None)
+    key = (dev.index, B, D, H, with_old)
     ws = _step_ws.get(key)
     if ws is None:
-        nbytes = _lib.lib().dbmm_workspace_bytes_adapter_train_step(B, D, H, int(old is not None))
+        nbytes = _lib.lib().dbmm_workspace_bytes_adapter_train_step(B, D, H, int(with_old))
         ws = _empty(nbytes // 4, device=dev, dtype=torch.float32)
         if len(_step_ws) > 8:
             _step_ws.clear()
         _step_ws[key] = ws
     logits = _empty((B, C), device=dev, dtype=torch.float32)
-    loss_rows = _empty((B,), device=dev, dtype=torch.float32)
-    loss_mean = _empty((), device=dev, dtype=torch.float32)
-    o = [ptr(t) for t in old] if old is not None else [None] * 9
-    check(_lib.lib().dbmm_adapter_train_step(
-        ptr(x), ptr(labels), *[ptr(t) for t in new], *[ptr(t) for t in bufs], *o, float(ebd_weight), ptr(tn),
-        float(temperature), float(lr), float(momentum), float(weight_decay), int(first_step), ptr(logits),
-        ptr(loss_rows), ptr(loss_mean), B, D, H, C, ptr(ws), ws.numel() * 4, stream()), "adapter_train_step")
-    return loss_mean, logits, loss_rows
+    loss = _empty((B + 1,), device=dev, dtype=torch.float32)        # per-row losses, then their mean: one allocation
+    rc = _lib.lib().dbmm_adapter_train_step(
+        x.data_ptr(), labels.data_ptr(), *args, float(ebd_weight), tn.data_ptr(), float(temperature), float(lr), float(momentum),
+        float(weight_decay), int(first_step), logits.data_ptr(), loss.data_ptr(), loss.data_ptr() + 4 * B, B, D, H, C, ws.data_ptr(),
+        ws.numel() * 4, stream())
+    if rc:
+        check(rc, "adapter_train_step")
+    return loss[B], logits, loss[:B]
 
 
 def gather_rows(table, idx):
