@@ -1725,6 +1725,9 @@ int conv_impl(const float* x, const float* w, const float* bias, const float* re
     hipStream_t s = (hipStream_t)stream;
     if (KH == 1 && KW == 1 && stride == 1 && pad == 0) {                                           // plain GEMM
         // (the 128 x 256 tile of gemm_impl was measured here too, on RN50 layers 3-4 at B = 1024: neutral, not kept)
+        // Also measured and not kept (round 3, profiles/r03_pair_stream_ab_layers.log): an LDS-DMA streaming variant (fp32 A tile by
+        // DMA into a 3-slot ring, split into (hi, lo) when the fragments are read): 7 - 34 % SLOWER on every layer-2/3/4 shape
+        // at B = 1024 -- the split then runs once per wave column and N tile instead of once per tile, on fp32 fragment reads.
         return launch_modes<0, 0>(p, s, 1, ws, wsb);
     }
     {

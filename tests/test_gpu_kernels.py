@@ -1114,3 +1114,4 @@ def test_bottleneck_block_chain_conv2_conv3_next_conv1(B, H, W, K, N, P, dual):
         y2 = ops.conv_bn_act(y1, w2p, b2, None, 3, 3, 1, 1, ops.ACT_RELU, wl, w_planes_f16=p2, w_exp=e2, x_absmax=ya, out_scale=s2)
         xu = ops.conv_bn_act(y2, w3, b3, res, 1, 1, 1, 0, ops.ACT_RELU, w_planes_f16=p3, w_exp=e3, x_absmax=y2.abs().max().reshape(1), out_scale=s3)
         assert relerr(x.cpu(), xu.cpu()) < 3e-6
+
