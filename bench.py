@@ -283,6 +283,43 @@ def extra_leg(arch, dtype, Bl, steps, warmup, dev, note):
     return leg
 
 
+def from_uint8_leg(dev, Bl=1024, steps=4, warmup=1, H=218, W=178):
+    """the headline step fed from DECODED uint8 images resident in HBM (CelebA geometry 218 x 178; clip_inference.py:203-206 feeds the
+    encoder from the reference's PIL `preprocess`): device preprocessing (Pillow-exact bicubic resize + centre crop + normalise,
+    preprocess.py) -> encode_image -> adapter step.  JPEG decode stays on the host and is not part of this figure."""
+    from dbmm_amd import preprocess as PP
+    sd, model, D, R, paths, stepper = build_step("RN50", dev, 1, 0, Bl)
+    raw = (synth.uniform(77, "u8img", (min(Bl, 64), H, W, 3)) * 255.999).to(torch.uint8)
+    raw = raw.repeat((Bl + raw.shape[0] - 1) // raw.shape[0], 1, 1, 1)[:Bl].contiguous().to(dev)
+    y, c, g = (t.to(dev) for t in synth.labels(6, Bl))
+    buf = torch.empty((Bl, 3, R, R), device=dev, dtype=torch.float32)
+
+    def one():
+        PP.preprocess_uniform(raw, R, out=buf)
+        return stepper.step(buf, y, g)
+    for _ in range(warmup):
+        one()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss, logits, emb = one()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); PP.preprocess_uniform(raw, R, out=buf); e1.record(); torch.cuda.synchronize()
+    if not torch.isfinite(loss).item():
+        raise SystemExit("non-finite loss")
+    del model, stepper, sd
+    torch.cuda.empty_cache()
+    return {"config": {"workload": f"decoded uint8 RGB {H}x{W} images in HBM -> device preprocessing (Pillow-exact) -> CLIP-RN50 224px encode_image + "
+                                   f"adapter step, {Bl} images on one GPU", "global_batch": Bl, "batch_per_gpu": Bl},
+            "dtype": "f32", "value": round(Bl * steps / dt, 2), "unit": "images/sec", "steps": steps, "ms_per_step": round(dt / steps * 1e3, 3),
+            "preprocess_ms": round(e0.elapsed_time(e1), 3),
+            "roofline": {"bound": "hbm", "kernel": "resize_h_kernel + resize_v_norm_kernel (preprocessing only)",
+                         "achieved": round((Bl * (H * W * 3 + 12 * R * R)) / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round((Bl * (H * W * 3 + 12 * R * R)) / (e0.elapsed_time(e1) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}
+
+
 def adapter_only_leg(B, D, dev, steps=200, warmup=20):
     """BASELINE configs[0]: the adapter-only train step (final_main.py:455-466) on precomputed embeddings resident in HBM:
     forward, mean CE, backward, SGD as the one-call fused step.  Launch-bound: figure of merit = us/step against
@@ -422,6 +459,7 @@ def main():
             legs["vit_b32_f16_bs512"] = extra_leg("ViT-B/32", "f16", 512, 4, 1, dev, "one GPU's share of BASELINE configs[3], fp16 mode")
             legs["vit_l14_336_f16_bs256"] = extra_leg("ViT-L/14@336px", "f16", 256, 2, 1, dev,
                                                       "BASELINE configs[4]'s tower and arithmetic, a quarter of one GPU's 1024-image share")
+            legs["rn50_from_uint8_bs1024"] = from_uint8_leg(dev)
             legs["adapter_only_bs256"] = adapter_only_leg(256, 1024, dev)
             legs["adapter_only_bs1024"] = adapter_only_leg(1024, 1024, dev)
             line["extra_legs"] = legs

@@ -154,6 +154,7 @@ _SIGS = {
     "dbmm_adapter_train_step": [_P] * 26 + [_F, _P, _F, _F, _F, _F, _I, _P, _P, _P, _L, _L, _L, _L, _P, _Z, _P],
     "dbmm_workspace_bytes_preprocess": [_L, _L],
     "dbmm_resize_crop_normalize_u8": [_P, _L, _L, _P, _P, _L, _P, _P, _L, _L, _L, _L, _P, _P, _P, _P, _P, _Z, _P],
+    "dbmm_resize_crop_normalize_u8_batch": [_P, _L, _L, _L, _P, _P, _L, _P, _P, _L, _L, _L, _L, _P, _P, _P, _P, _P, _Z, _P],
     "dbmm_gather_rows": [_P, _P, _P, _L, _L, _L, _P],
     "dbmm_group_count": [_P, _P, _P, _P, _L, _L, _L, _P],
     "dbmm_group_loss_sum": [_P, _P, _P, _L, _L, _P],

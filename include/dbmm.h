@@ -309,6 +309,13 @@ int dbmm_resize_crop_normalize_u8(const uint8_t* img_hwc, int64_t H, int64_t W, 
                                   const int32_t* v_coeffs, int64_t v_ksize, int64_t row0, int64_t nrows,
                                   int64_t R, const float* mean3, const float* std3, float* out_chw,
                                   uint8_t* out_u8_hwc, void* workspace, size_t workspace_bytes, void* stream);
+/* the same for a batch of B images of ONE geometry [B][H][W][3] (e.g. CelebA: every image 218 x 178) in two launches:
+ * out_chw = float32 [B][3][R][R], out_u8_hwc (optional) [B][R][R][3], workspace >= B * dbmm_workspace_bytes_preprocess(nrows, R). */
+int dbmm_resize_crop_normalize_u8_batch(const uint8_t* img_bhwc, int64_t B, int64_t H, int64_t W, const int32_t* h_bounds,
+                                  const int32_t* h_coeffs, int64_t h_ksize, const int32_t* v_bounds,
+                                  const int32_t* v_coeffs, int64_t v_ksize, int64_t row0, int64_t nrows,
+                                  int64_t R, const float* mean3, const float* std3, float* out_chw,
+                                  uint8_t* out_u8_hwc, void* workspace, size_t workspace_bytes, void* stream);
 
 /* profiling aid: the 11 template arguments <BM,BN,WAVES_M,WAVES_N,AMODE,WMODE,BK,MINB,FAST,SK,DMA>
  * of the calling thread's most recent igemm launch (= the kernel name rocprofv3 reports). */

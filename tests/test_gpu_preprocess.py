@@ -59,3 +59,12 @@ def test_preprocess_feeds_encode_image():
     dev = PP.preprocess_batch([torch.from_numpy(im).to(DEV) for im in imgs], R)
     assert torch.equal(dev, host)
     assert torch.equal(model.encode_image(dev), model.encode_image(host))
+
+
+def test_uniform_batch_equals_per_image_calls():
+    """a batch of one geometry (CelebA's 218 x 178) in two launches == the per-image entry, bit for bit"""
+    rng = np.random.RandomState(5)
+    imgs = torch.from_numpy(rng.randint(0, 256, (7, 218, 178, 3)).astype(np.uint8)).cuda()
+    a = PP.preprocess_uniform(imgs, 224)
+    b = PP.preprocess_batch([imgs[i] for i in range(7)], 224)
+    assert a.dtype == torch.float32 and torch.equal(a, b)
