@@ -701,6 +701,12 @@ def _f16c(t):
     return t
 
 
+def _gemm_f16_tag(M, N):
+    """instantiation dbmm_gemm_f16 picks for a shape the deep-pipelined kernel does not take (its own rule), as rocprofv3 prints it"""
+    wide = get_option("f16_bn256") and N >= 768 and N % 256 == 0 and M >= 32768
+    return "gemm_f16_kernel<32, 256, 2>" if wide else "gemm_f16_kernel<64, 128, 2>"
+
+
 def gemm_f16(a, w, bias=None, residual=None, act=ACT_NONE, M=None, lda=None):
     """c f16 = act(a @ w^T + bias) + residual; a f16 [M][K] (row pitch lda), w f16 [N][K], bias f32, residual f16."""
     require_cuda(a, w)
@@ -715,7 +721,7 @@ def gemm_f16(a, w, bias=None, residual=None, act=ACT_NONE, M=None, lda=None):
         M = a.numel() // a.shape[-1]
     c = _empty((M, N), device=a.device, dtype=torch.float16)
     deep = N % 256 == 0 and K % 128 == 0 and M >= 16384 and get_option("f16_8ph")   # dbmm_gemm_f16's own rule
-    with _TimedTag("gemm_f16_8ph_kernel" if deep else "gemm_f16_kernel", 2.0 * M * N * K,
+    with _TimedTag(f"gemm_f16_8ph_kernel<{act}, {int(residual is not None)}>" if deep else _gemm_f16_tag(M, N), 2.0 * M * N * K,
                    2 * (M * K + N * K + M * N * (2 if residual is not None else 1))):
         check(_lib.lib().dbmm_gemm_f16(ptr(a), lda, ptr(w), K, ptr(bias), ptr(residual), N if residual is not None else 0, ptr(c), N,
                                        M, N, K, act, stream()), "gemm_f16")
@@ -795,7 +801,9 @@ def conv1x1_f16(x, w, scale, bias, residual=None, act=ACT_RELU):
     deep = Cout % 256 == 0 and Cin % 128 == 0 and M >= 16384                            # dbmm_conv1x1_bn_act_f16's own routing rule
     mode = get_option("conv1x1_stream")
     stream_k = (mode == 2 or (mode == 1 and not deep)) and act in (ACT_NONE, ACT_RELU) and Cin % 32 == 0
-    tag = "conv1x1_f16_kernel" if stream_k else ("gemm_f16_8ph_kernel" if deep and get_option("f16_8ph") else "gemm_f16_kernel")
+    res = int(residual is not None)
+    tag = (f"conv1x1_f16_kernel<{'4, 1, 2' if Cout <= 64 else '2, 2, 4'}, {res}>" if stream_k
+           else (f"gemm_f16_8ph_kernel<{act}, {res}>" if deep and get_option("f16_8ph") else _gemm_f16_tag(M, Cout)))
     t = _TimedTag(tag, 2.0 * M * Cout * Cin,
                   2 * (M * Cin + Cout * Cin + M * Cout * (2 if residual is not None else 1)))
     t.__enter__()
