@@ -8,11 +8,11 @@
 // every sum in a fixed order (no atomics): results do not depend on the launch geometry's timing and the one-call step
 // equals the autograd path bit for bit (both run these kernels).
 //
-//   fc1_partial      hpart[ks][b][:] = x[b][128 ks : 128 ks + 128] . W1[:, same]^T     grid (B / 16, D / 128); the partials
+//   fc1_partial      hpart[ks][b][:] = x[b][128 ks : 128 ks + 128] . W1[:, same]^T     grid (B / 32, 2, D / 128); the partials
 //                    live in the z buffer (B x D floats = D / 128 slices of B x 128), which is written later
 //   bn_stats         h = b1 + sum_ks hpart (fixed order), column mean / biased variance over the batch (two passes),
 //                    running statistics with the unbiased variance, num_batches_tracked          grid H / 4
-//   fc2              r = relu(bn(h)) (stored for the backward), z = r . W2^T + b2                grid (B / 16, D / 128)
+//   fc2              r = relu(bn(h)) (stored for the backward), z = r . W2^T + b2                grid (B / 32, D / 64)
 //   bwd2             dW2 = dz^T r, db2 = colsum dz (blocks < D / 32) and drpart[ks] = dz[:, slice ks] . W2[slice ks]
 //                    (the other blocks) in ONE launch: both only need dz, r and W2
 //   bn_bwd           dr = sum_ks drpart, dhn = dr * (bn(h) > 0), dbeta / dgamma column sums, dh                  grid H / 4
@@ -30,18 +30,19 @@ constexpr int LP = 132;                    // LDS row pitch in floats
 constexpr int TB = 16, TI = TB / 8;        // rows of a tile product's output tile, rows per thread
 
 // acc[i][j] += sum_k a[row_i][k] * w[col_j][k] over 128 k, both operands as [rows][LP] in LDS; rows ty + 8 i, cols tx + 32 j
-__device__ __forceinline__ void tile_kk(const float* __restrict__ as, const float* __restrict__ ws, int tx, int ty, float (&acc)[TI][4]) {
+template <int RI, int CJ>
+__device__ __forceinline__ void tile_kk(const float* __restrict__ as, const float* __restrict__ ws, int tx, int ty, float (&acc)[RI][CJ]) {
 #pragma unroll 4
     for (int k4 = 0; k4 < 32; ++k4) {
-        f32x4 a[TI], w[4];
+        f32x4 a[RI], w[CJ];
 #pragma unroll
-        for (int i = 0; i < TI; ++i) a[i] = *(const f32x4*)(as + (ty + 8 * i) * LP + 4 * k4);
+        for (int i = 0; i < RI; ++i) a[i] = *(const f32x4*)(as + (ty + 8 * i) * LP + 4 * k4);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) w[j] = *(const f32x4*)(ws + (tx + 32 * j) * LP + 4 * k4);
+        for (int j = 0; j < CJ; ++j) w[j] = *(const f32x4*)(ws + (tx + 32 * j) * LP + 4 * k4);
 #pragma unroll
-        for (int i = 0; i < TI; ++i)
+        for (int i = 0; i < RI; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < CJ; ++j) {
                 acc[i][j] = fmaf(a[i][0], w[j][0], acc[i][j]);
                 acc[i][j] = fmaf(a[i][1], w[j][1], acc[i][j]);
                 acc[i][j] = fmaf(a[i][2], w[j][2], acc[i][j]);
@@ -70,6 +71,14 @@ __device__ __forceinline__ void load_tile32(const float* __restrict__ src, long 
         *(f32x4*)(dst + r * LP + 4 * c) = v;
     }
 }
+// rows [r0, r0 + 64) x columns [c0, c0 + 128) -> LDS [64][LP]
+__device__ __forceinline__ void load_tile64(const float* __restrict__ src, long long ld, int r0, int c0, float* __restrict__ dst, int tid) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int q = tid + 256 * i, r = q >> 5, c = q & 31;
+        *(f32x4*)(dst + r * LP + 4 * c) = *(const f32x4*)(src + (long long)(r0 + r) * ld + c0 + 4 * c);
+    }
+}
 // rows [r0, r0 + 128) x columns [c0, c0 + 128) -> LDS [128][LP]
 __device__ __forceinline__ void load_tile128(const float* __restrict__ src, long long ld, int r0, int c0, float* __restrict__ dst, int tid) {
 #pragma unroll
@@ -81,21 +90,22 @@ __device__ __forceinline__ void load_tile128(const float* __restrict__ src, long
 
 __global__ __launch_bounds__(256) void fc1_partial_kernel(const float* __restrict__ x, const float* __restrict__ w1, float* __restrict__ part,
                                                           int B, int D) {
-    __shared__ __attribute__((aligned(16))) float as[TB * LP];
-    __shared__ __attribute__((aligned(16))) float ws[128 * LP];
+    // tile = 32 rows x 64 hidden units over a 128-deep K slice (24 KB + 32 KB of operands per workgroup)
+    __shared__ __attribute__((aligned(16))) float as[32 * LP];
+    __shared__ __attribute__((aligned(16))) float ws[64 * LP];
     const int tid = threadIdx.x, tx = tid & 31, ty = tid >> 5;
-    const int b0 = blockIdx.x * TB, ks = blockIdx.y;
-    load_tileTB(x, D, b0, B, ks * 128, as, tid);
-    load_tile128(w1, D, 0, ks * 128, ws, tid);
+    const int b0 = blockIdx.x * 32, h0 = blockIdx.y * 64, ks = blockIdx.z;
+    load_tile32(x, D, b0, B, ks * 128, as, tid);
+    load_tile64(w1, D, h0, ks * 128, ws, tid);
     __syncthreads();
-    float acc[TI][4] = {};
-    tile_kk(as, ws, tx, ty, acc);
+    float acc[4][2] = {};
+    tile_kk<4, 2>(as, ws, tx, ty, acc);
 #pragma unroll
-    for (int i = 0; i < TI; ++i) {
+    for (int i = 0; i < 4; ++i) {
         const int b = b0 + ty + 8 * i;
         if (b < B)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) part[((long long)ks * B + b) * 128 + tx + 32 * j] = acc[i][j];
+            for (int j = 0; j < 2; ++j) part[((long long)ks * B + b) * 128 + h0 + tx + 32 * j] = acc[i][j];
     }
 }
 
@@ -185,13 +195,14 @@ __global__ __launch_bounds__(256) void fc2_kernel(const float* __restrict__ h, c
                                                   int var_mode, float eps, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                   const float* __restrict__ w2, const float* __restrict__ b2, float* __restrict__ r,
                                                   float* __restrict__ z, int B, int D) {
-    __shared__ __attribute__((aligned(16))) float as[TB * LP];
-    __shared__ __attribute__((aligned(16))) float ws[128 * LP];
+    // tile = 32 rows x 64 output columns, K = H = 128 (the whole reduction)
+    __shared__ __attribute__((aligned(16))) float as[32 * LP];
+    __shared__ __attribute__((aligned(16))) float ws[64 * LP];
     const int tid = threadIdx.x, tx = tid & 31, ty = tid >> 5;
-    const int b0 = blockIdx.x * TB, d0 = blockIdx.y * 128;
+    const int b0 = blockIdx.x * 32, d0 = blockIdx.y * 64;
     // r tile = relu(bn(h tile)): the expression of the stand-alone BatchNorm + ReLU kernel (bn1d_relu_kernel)
 #pragma unroll
-    for (int i = 0; i < TB / 8; ++i) {
+    for (int i = 0; i < 4; ++i) {
         const int q = tid + 256 * i, rr = q >> 5, c = q & 31;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (b0 + rr < B) {
@@ -207,16 +218,16 @@ __global__ __launch_bounds__(256) void fc2_kernel(const float* __restrict__ h, c
         }
         *(f32x4*)(as + rr * LP + 4 * c) = v;
     }
-    load_tile128(w2, 128, d0, 0, ws, tid);                 // W2 [D][128]: rows d0 .. d0 + 127
+    load_tile64(w2, 128, d0, 0, ws, tid);                  // W2 [D][128]: rows d0 .. d0 + 63
     __syncthreads();
-    float acc[TI][4] = {};
-    tile_kk(as, ws, tx, ty, acc);
+    float acc[4][2] = {};
+    tile_kk<4, 2>(as, ws, tx, ty, acc);
 #pragma unroll
-    for (int i = 0; i < TI; ++i) {
+    for (int i = 0; i < 4; ++i) {
         const int b = b0 + ty + 8 * i;
         if (b < B)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) z[(long long)b * D + d0 + tx + 32 * j] = acc[i][j] + b2[d0 + tx + 32 * j];
+            for (int j = 0; j < 2; ++j) z[(long long)b * D + d0 + tx + 32 * j] = acc[i][j] + b2[d0 + tx + 32 * j];
     }
 }
 
@@ -408,8 +419,8 @@ bool dbmm_adapter_fast_shape(int64_t B, int64_t D, int64_t H) { return H == 128 
 int dbmm_adapter_fwd_fast(const float* x, const float* w1, const float* b1, const float* gamma, const float* beta, float* running_mean,
                           float* running_var, int64_t* nbt, const float* w2, const float* b2, float* h, float* mean, float* invstd, float* r,
                           float* z, int64_t B, int64_t D, int train, float eps, float momentum, hipStream_t s) {
-    const int KS = (int)(D / 128), nb = (int)((B + TB - 1) / TB);
-    hipLaunchKernelGGL(fc1_partial_kernel, dim3(nb, KS), dim3(256), 0, s, x, w1, z, (int)B, (int)D);
+    const int KS = (int)(D / 128), nb = (int)((B + 31) / 32);
+    hipLaunchKernelGGL(fc1_partial_kernel, dim3(nb, 2, KS), dim3(256), 0, s, x, w1, z, (int)B, (int)D);
     DBMM_CHECK_LAUNCH();
     if (train) {
         hipLaunchKernelGGL(bn_stats_kernel, dim3(32), dim3(256), 0, s, (const float*)z, KS, b1, h, (int)B, eps, momentum, mean, invstd, running_mean,
@@ -419,7 +430,7 @@ int dbmm_adapter_fwd_fast(const float* x, const float* w1, const float* b1, cons
         hipLaunchKernelGGL(fc1_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const float*)z, KS, b1, h, total, (int)B);
     }
     DBMM_CHECK_LAUNCH();
-    hipLaunchKernelGGL(fc2_kernel, dim3(nb, KS), dim3(256), 0, s, (const float*)h, train ? (const float*)mean : (const float*)running_mean,
+    hipLaunchKernelGGL(fc2_kernel, dim3(nb, (unsigned)(D / 64)), dim3(256), 0, s, (const float*)h, train ? (const float*)mean : (const float*)running_mean,
                        train ? (const float*)invstd : (const float*)running_var, train ? 0 : 1, eps, gamma, beta, w2, b2, r, z, (int)B, (int)D);
     DBMM_CHECK_LAUNCH();
     return DBMM_OK;
