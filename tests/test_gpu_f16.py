@@ -303,3 +303,46 @@ def test_fp16_mode_large_batch_rows_are_independent():
     small = model.encode_image(img[40:43].contiguous())
     assert torch.isfinite(big).all() and relerr(big[40:43].float().cpu(), small.float().cpu()) < 2e-3
     assert torch.equal(big, model.encode_image(img))
+
+
+def test_fp16_conv_kernels_on_operands_over_2gib():
+    """fp16 NHWC maps past 2 GiB (RN50 layer 1 from B = 1338): every tile of the conv kernels rebases its buffer descriptors on a
+    64-bit base; first / straddling / last images against fp64 on the same fp16 values."""
+    g = torch.Generator(device=DEV); g.manual_seed(3)
+    H = 56
+    # --- 1x1 streaming kernel: 256 -> 64 channels (K-loop of 8 chunks) and 64 -> 256 + residual on 1400 images
+    B, Cin, Cout = 1400, 256, 64
+    x = torch.relu(torch.randn((B, H, H, Cin), device=DEV, generator=g, dtype=torch.float16))
+    assert x.numel() * 2 > 2 ** 31
+    w = (torch.randn((Cout, Cin), device=DEV, generator=g) * Cin ** -0.5).half()
+    sc, b = _bn(g, Cout)
+    y = ops.conv1x1_f16(x, w, sc, b)
+    w3 = (torch.randn((Cin, Cout), device=DEV, generator=g) * Cout ** -0.5).half()
+    s3, b3 = _bn(g, Cin)
+    x2 = ops.conv1x1_f16(y, w3, s3, b3, residual=x)
+    assert x2.numel() * 2 > 2 ** 31
+    straddle = 2 ** 31 // (H * H * Cin * 2)
+    for i in (0, straddle, straddle + 1, B - 1):
+        yr = torch.relu(x[i].view(-1, Cin).double() @ w.double().t() * sc.double() + b.double())
+        assert relerr(y[i].view(-1, Cout).double().cpu(), yr.cpu()) < 1.5e-3, i
+        xr = torch.relu(y[i].view(-1, Cout).double() @ w3.double().t() * s3.double() + b3.double() + x[i].view(-1, Cin).double())
+        assert relerr(x2[i].view(-1, Cin).double().cpu(), xr.cpu()) < 1.5e-3, i
+    del x, x2, y
+    torch.cuda.empty_cache()
+    # --- 3x3 kernel, 64 -> 64 channels on 56 x 56 maps: 5600 images = 2.25 GB input; plain and pooled
+    B, C = 5600, 64
+    x = torch.relu(torch.randn((B, H, H, C), device=DEV, generator=g, dtype=torch.float16))
+    assert x.numel() * 2 > 2 ** 31
+    w = (torch.randn((C, C, 3, 3), device=DEV, generator=g) * (9 * C) ** -0.5).half()
+    wp, _ = ops.pack_conv_weight(w.float(), chunk_major=32)
+    sc, b = _bn(g, C)
+    straddle = 2 ** 31 // (H * H * C * 2)
+    for pool in (1, 2):
+        y = ops.conv3x3_f16(x, wp.half().contiguous(), sc, b, pool=pool)
+        for i in (0, straddle, straddle + 1, B - 1):
+            ref = torch.relu(F.conv2d(x[i].permute(2, 0, 1)[None].double(), w.double(), None, padding=1) * sc.double().view(1, -1, 1, 1)
+                             + b.double().view(1, -1, 1, 1))
+            if pool == 2:
+                ref = F.avg_pool2d(ref, 2)
+            assert relerr(y[i].double().cpu(), ref[0].permute(1, 2, 0).cpu()) < 1.5e-3, (pool, i)
+        del y
