@@ -15,7 +15,7 @@ int dbmm_adapter_fwd_fast(const float* x, const float* w1, const float* b1, cons
 int dbmm_adapter_bwd_fast(const float* x, const float* dz, const float* h, const float* mean, const float* invstd, const float* r, const float* gamma,
                           const float* beta, const float* w2, float* dw1, float* db1, float* dgamma, float* dbeta, float* dw2, float* db2,
                           float* dh, float* scratch, int64_t B, int64_t D, hipStream_t s, const float** dw1part = nullptr,
-                          const float** db1part = nullptr, int* nsplit = nullptr);
+                          const float** db1part = nullptr, int* nsplit = nullptr, const float* loss_rows = nullptr, float* loss_mean = nullptr);
 
 namespace {
 
@@ -157,13 +157,12 @@ __global__ __launch_bounds__(256) void text_colnorm_kernel(const float* __restri
 }
 
 // ---- fused row L2-norm + logits + CE: one wave per row -------------------------------------
+// forward of one row by one wave (every lane ends up with the row's logits lg[] and 1 / ||z||); lane 0 writes the outputs
 template <int CMAX>
-__global__ __launch_bounds__(256) void l2norm_sim_ce_fwd_kernel(
-    const float* __restrict__ z, const float* __restrict__ z_old, float w_old, const float* __restrict__ tn,
-    const long long* __restrict__ labels, float invT, float* __restrict__ logits, float* __restrict__ loss_rows,
-    long long* __restrict__ pred, float* __restrict__ inv_norm, int B, int D4, int C) {
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (row >= B) return;
+__device__ __forceinline__ void ce_fwd_row(const float* __restrict__ z, const float* __restrict__ z_old, float w_old, const float* __restrict__ tn,
+                                           const long long* __restrict__ labels, float invT, float* __restrict__ logits,
+                                           float* __restrict__ loss_rows, long long* __restrict__ pred, float* __restrict__ inv_norm, int row,
+                                           int lane, int D4, int C, float (&lg)[CMAX], float& inv) {
     const f32x4* zr = (const f32x4*)z + (long long)row * D4;
     const f32x4* zo = z_old ? (const f32x4*)z_old + (long long)row * D4 : nullptr;
     float ss = 0.f, sso = 0.f, dot[CMAX], doto[CMAX];
@@ -184,10 +183,9 @@ __global__ __launch_bounds__(256) void l2norm_sim_ce_fwd_kernel(
         }
     }
     ss = wave_sum(ss);
-    const float inv = 1.f / sqrtf(ss);
+    inv = 1.f / sqrtf(ss);
     float invo = 0.f;
     if (zo) invo = 1.f / sqrtf(wave_sum(sso));
-    float lg[CMAX];
     float mx = -INFINITY;
     int am = 0;
 #pragma unroll
@@ -218,6 +216,17 @@ __global__ __launch_bounds__(256) void l2norm_sim_ce_fwd_kernel(
     }
 }
 
+template <int CMAX>
+__global__ __launch_bounds__(256) void l2norm_sim_ce_fwd_kernel(
+    const float* __restrict__ z, const float* __restrict__ z_old, float w_old, const float* __restrict__ tn,
+    const long long* __restrict__ labels, float invT, float* __restrict__ logits, float* __restrict__ loss_rows,
+    long long* __restrict__ pred, float* __restrict__ inv_norm, int B, int D4, int C) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= B) return;
+    float lg[CMAX], inv;
+    ce_fwd_row<CMAX>(z, z_old, w_old, tn, labels, invT, logits, loss_rows, pred, inv_norm, row, lane, D4, C, lg, inv);
+}
+
 __global__ __launch_bounds__(256) void mean_reduce_kernel(const float* __restrict__ x, int n, float* __restrict__ out) {
     __shared__ float red[4];
     float s = 0.f;
@@ -228,25 +237,11 @@ __global__ __launch_bounds__(256) void mean_reduce_kernel(const float* __restric
     if (threadIdx.x == 0) *out = ((red[0] + red[1]) + (red[2] + red[3])) / (float)n;
 }
 
+// backward of one row by one wave: dz from the row's logits `lgv` (read back or still in registers), its label and 1 / ||z||
 template <int CMAX>
-__global__ __launch_bounds__(256) void l2norm_sim_ce_bwd_kernel(
-    const float* __restrict__ z, const float* __restrict__ inv_norm, float w_new, const float* __restrict__ tn,
-    const float* __restrict__ logits, const long long* __restrict__ labels, const float* __restrict__ dlogits,
-    float invT, float gscale, float* __restrict__ dz, int B, int D4, int C, const float* __restrict__ loss_rows,
-    float* __restrict__ loss_mean) {
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (loss_mean && blockIdx.x == gridDim.x - 1) {
-        // the fused step folds the batch mean of the per-row losses (written by the forward launch) into this launch:
-        // mean_reduce_kernel's arithmetic, statement for statement, so that both give the same bits
-        __shared__ float red[4];
-        float s = 0.f;
-        for (int i = threadIdx.x; i < B; i += 256) s += loss_rows[i];
-        s = wave_sum(s);
-        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
-        __syncthreads();
-        if (threadIdx.x == 0) *loss_mean = ((red[0] + red[1]) + (red[2] + red[3])) / (float)B;
-    }
-    if (row >= B) return;
+__device__ __forceinline__ void ce_bwd_row(const float* __restrict__ z, float inv, float w_new, const float* __restrict__ tn, const float (&lgv)[CMAX],
+                                           const long long* __restrict__ labels, const float* __restrict__ dlogits, float invT, float gscale,
+                                           float* __restrict__ dz, int row, int lane, int D4, int C) {
     float dl[CMAX];
     if (dlogits) {   // upstream gradient given (autograd path): dl = dlogits / T * blend weight
 #pragma unroll
@@ -254,7 +249,7 @@ __global__ __launch_bounds__(256) void l2norm_sim_ce_bwd_kernel(
     } else {
         float mx = -INFINITY;
 #pragma unroll
-        for (int c = 0; c < CMAX; ++c) { dl[c] = (c < C) ? logits[(long long)row * C + c] : -INFINITY; mx = fmaxf(mx, dl[c]); }
+        for (int c = 0; c < CMAX; ++c) { dl[c] = (c < C) ? lgv[c] : -INFINITY; mx = fmaxf(mx, dl[c]); }
         float se = 0.f;
 #pragma unroll
         for (int c = 0; c < CMAX; ++c) { dl[c] = (c < C) ? expf(dl[c] - mx) : 0.f; se += dl[c]; }
@@ -263,7 +258,6 @@ __global__ __launch_bounds__(256) void l2norm_sim_ce_bwd_kernel(
 #pragma unroll
         for (int c = 0; c < CMAX; ++c) dl[c] = (dl[c] / se - (c == y ? 1.f : 0.f)) * k;
     }
-    const float inv = inv_norm[row];
     const f32x4* zr = (const f32x4*)z + (long long)row * D4;
     float fd = 0.f;
     for (int i = lane; i < D4; i += 64) {
@@ -282,6 +276,33 @@ __global__ __launch_bounds__(256) void l2norm_sim_ce_bwd_kernel(
         const f32x4 f = zr[i] * inv;
         dzr[i] = (df - f * fd) * inv;
     }
+}
+
+template <int CMAX>
+__global__ __launch_bounds__(256) void l2norm_sim_ce_bwd_kernel(
+    const float* __restrict__ z, const float* __restrict__ inv_norm, float w_new, const float* __restrict__ tn,
+    const float* __restrict__ logits, const long long* __restrict__ labels, const float* __restrict__ dlogits,
+    float invT, float gscale, float* __restrict__ dz, int B, int D4, int C) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= B) return;
+    float lgv[CMAX];
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c) lgv[c] = (logits && c < C) ? logits[(long long)row * C + c] : -INFINITY;
+    ce_bwd_row<CMAX>(z, inv_norm[row], w_new, tn, lgv, labels, dlogits, invT, gscale, dz, row, lane, D4, C);
+}
+
+// the one-call step: forward and backward of a row in ONE launch (both are row-local; the logits stay in registers).  Same
+// statements as the two kernels above, so the results are the same bits.
+template <int CMAX>
+__global__ __launch_bounds__(256) void l2norm_sim_ce_fwdbwd_kernel(
+    const float* __restrict__ z, const float* __restrict__ z_old, float w_old, float w_new, const float* __restrict__ tn,
+    const long long* __restrict__ labels, float invT, float gscale, float* __restrict__ logits, float* __restrict__ loss_rows,
+    float* __restrict__ dz, int B, int D4, int C) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= B) return;
+    float lg[CMAX], inv;
+    ce_fwd_row<CMAX>(z, z_old, w_old, tn, labels, invT, logits, loss_rows, nullptr, nullptr, row, lane, D4, C, lg, inv);
+    ce_bwd_row<CMAX>(z, inv, w_new, tn, lg, labels, nullptr, invT, gscale, dz, row, lane, D4, C);
 }
 
 // ---- multi-tensor SGD with momentum ---------------------------------------------------------
@@ -501,20 +522,10 @@ extern "C" int dbmm_l2norm_sim_ce_fwd(const float* z, const float* z_old, float 
     return DBMM_OK;
 }
 
-static int ce_bwd_impl(const float* z, const float* inv_norm, float ebd_weight, int blended, const float* tn, const float* logits,
-                       const int64_t* labels, const float* dlogits, float temperature, float grad_scale, float* dz, int64_t B, int64_t D,
-                       int64_t C, const float* loss_rows, float* loss_mean, void* stream);
-
 extern "C" int dbmm_l2norm_sim_ce_bwd(const float* z, const float* inv_norm, float ebd_weight, int blended,
                                       const float* tn, const float* logits, const int64_t* labels,
                                       const float* dlogits, float temperature, float grad_scale, float* dz,
                                       int64_t B, int64_t D, int64_t C, void* stream) {
-    return ce_bwd_impl(z, inv_norm, ebd_weight, blended, tn, logits, labels, dlogits, temperature, grad_scale, dz, B, D, C, nullptr, nullptr, stream);
-}
-
-static int ce_bwd_impl(const float* z, const float* inv_norm, float ebd_weight, int blended, const float* tn, const float* logits,
-                       const int64_t* labels, const float* dlogits, float temperature, float grad_scale, float* dz, int64_t B, int64_t D,
-                       int64_t C, const float* loss_rows, float* loss_mean, void* stream) {
     if (!z || !inv_norm || !tn || !dz) return DBMM_E_ARG;
     if (!dlogits && (!logits || !labels)) return DBMM_E_ARG;
     if (B <= 0 || D <= 0 || (D & 3) || C <= 0 || C > 8 || B > INT32_MAX) return DBMM_E_SHAPE;
@@ -525,10 +536,27 @@ static int ce_bwd_impl(const float* z, const float* inv_norm, float ebd_weight, 
     hipStream_t s = (hipStream_t)stream;
     if (C <= 4)
         hipLaunchKernelGGL(l2norm_sim_ce_bwd_kernel<4>, grid, dim3(256), 0, s, z, inv_norm, w_new, tn, logits,
-                           (const long long*)labels, dlogits, 1.f / temperature, gs, dz, (int)B, (int)(D / 4), (int)C, loss_rows, loss_mean);
+                           (const long long*)labels, dlogits, 1.f / temperature, gs, dz, (int)B, (int)(D / 4), (int)C);
     else
         hipLaunchKernelGGL(l2norm_sim_ce_bwd_kernel<8>, grid, dim3(256), 0, s, z, inv_norm, w_new, tn, logits,
-                           (const long long*)labels, dlogits, 1.f / temperature, gs, dz, (int)B, (int)(D / 4), (int)C, loss_rows, loss_mean);
+                           (const long long*)labels, dlogits, 1.f / temperature, gs, dz, (int)B, (int)(D / 4), (int)C);
+    DBMM_CHECK_LAUNCH();
+    return DBMM_OK;
+}
+
+// forward + backward of the cosine-logits / CE head in one launch (the one-call step): logits, per-row losses, dz
+static int ce_fwdbwd(const float* z, const float* z_old, float ebd_weight, const float* tn, const int64_t* labels, float temperature,
+                     float* logits, float* loss_rows, float* dz, int64_t B, int64_t D, int64_t C, void* stream) {
+    const float w_new = z_old ? (1.f - ebd_weight) : 1.f;
+    const float gs = 1.f / (float)B;
+    const dim3 grid((unsigned)((B + 3) / 4));
+    hipStream_t s = (hipStream_t)stream;
+    if (C <= 4)
+        hipLaunchKernelGGL(l2norm_sim_ce_fwdbwd_kernel<4>, grid, dim3(256), 0, s, z, z_old, ebd_weight, w_new, tn, (const long long*)labels,
+                           1.f / temperature, gs, logits, loss_rows, dz, (int)B, (int)(D / 4), (int)C);
+    else
+        hipLaunchKernelGGL(l2norm_sim_ce_fwdbwd_kernel<8>, grid, dim3(256), 0, s, z, z_old, ebd_weight, w_new, tn, (const long long*)labels,
+                           1.f / temperature, gs, logits, loss_rows, dz, (int)B, (int)(D / 4), (int)C);
     DBMM_CHECK_LAUNCH();
     return DBMM_OK;
 }
@@ -656,15 +684,20 @@ extern "C" int dbmm_adapter_train_step(const float* x, const int64_t* labels, fl
                               oz, B, D, H, 1, eps, bn_momentum, stream);
         if (rc) return rc;
     }
-    // the batch mean of the losses is folded into the backward launch, the sums of the batch-split dW1 / db1 partials into
-    // the SGD launch (same arithmetic as the stand-alone launches the autograd path uses: same bits)
+    // one-call step on the purpose-built kernels: cosine logits + CE forward AND backward are one launch (row-local), the batch
+    // mean of the losses rides in a spare block of the next launch, the sums of the batch-split dW1 / db1 partials in the SGD
+    // launch -- the same statements as the stand-alone launches the autograd path uses, hence the same bits
     const bool fast = dbmm_adapter_fast_shape(B, D, H) && dbmm_opt(OPT_ADAPTER_STEP_FUSED) && dbmm_aligned16(x);
-    rc = dbmm_l2norm_sim_ce_fwd(z, oz, ebd_weight, tn, labels, temperature, logits, loss_rows, fast ? nullptr : loss_mean, nullptr,
-                                inv_norm, B, D, C, stream);
-    if (rc) return rc;
-    rc = ce_bwd_impl(z, inv_norm, ebd_weight, with_old, tn, logits, labels, nullptr, temperature, 1.f, dz, B, D, C, fast ? loss_rows : nullptr,
-                     fast ? loss_mean : nullptr, stream);
-    if (rc) return rc;
+    if (fast) {
+        if ((D & 3) || C <= 0 || C > 8) return DBMM_E_SHAPE;
+        rc = ce_fwdbwd(z, oz, ebd_weight, tn, labels, temperature, logits, loss_rows, dz, B, D, C, stream);
+        if (rc) return rc;
+    } else {
+        rc = dbmm_l2norm_sim_ce_fwd(z, oz, ebd_weight, tn, labels, temperature, logits, loss_rows, loss_mean, nullptr, inv_norm, B, D, C, stream);
+        if (rc) return rc;
+        rc = dbmm_l2norm_sim_ce_bwd(z, inv_norm, ebd_weight, with_old, tn, logits, labels, nullptr, temperature, 1.f, dz, B, D, C, stream);
+        if (rc) return rc;
+    }
     float* ps[6] = {w1, b1, gamma, beta, w2, b2};
     const float* gs[6] = {dw1, db1, dgamma, dbeta, dw2, db2};
     float* ms[6] = {m_w1, m_b1, m_gamma, m_beta, m_w2, m_b2};
@@ -674,7 +707,7 @@ extern "C" int dbmm_adapter_train_step(const float* x, const int64_t* labels, fl
         const float *dw1part = nullptr, *db1part = nullptr;
         int nsplit = 1;
         rc = dbmm_adapter_bwd_fast(x, dz, h, mean, invstd, r, gamma, beta, w2, dw1, db1, dgamma, dbeta, dw2, db2, dh, dh + B * H, B, D,
-                                   (hipStream_t)stream, &dw1part, &db1part, &nsplit);
+                                   (hipStream_t)stream, &dw1part, &db1part, &nsplit, loss_rows, loss_mean);
         if (rc) return rc;
         gs[0] = dw1part; gs[1] = db1part;
         const int nsp[6] = {nsplit, nsplit, 1, 1, 1, 1};

@@ -234,13 +234,23 @@ __global__ __launch_bounds__(256) void fc2_kernel(const float* __restrict__ h, c
 // blocks [0, NS D / 32): split s = bid / (D / 32) of the batch: dw2part[s][d0 .. d0 + 31][:] = sum_{b in split} dz[b][d] r[b][:],
 //                         db2part[s][d] = sum_{b in split} dz[b][d]           (summed over s, in order, by grad_reduce blocks)
 // the other blocks:       drpart[ks][b0 .. b0 + 31][:] = dz[b][128 ks ..] . W2[128 ks ..][:]
+// one more block, when loss_mean is given: the batch mean of the per-row losses (mean_reduce_kernel's statements)
 __global__ __launch_bounds__(256) void bwd2_kernel(const float* __restrict__ dz, const float* __restrict__ r, const float* __restrict__ w2,
                                                    float* __restrict__ dw2part, float* __restrict__ db2part, float* __restrict__ drpart, int B, int D,
-                                                   int NS, int RB) {
+                                                   int NS, int RB, const float* __restrict__ loss_rows, float* __restrict__ loss_mean) {
     __shared__ __attribute__((aligned(16))) float s0[32 * LP];
     __shared__ __attribute__((aligned(16))) float s1[128 * LP];
     const int tid = threadIdx.x;
     const int nd = D / 32;
+    if (loss_mean && blockIdx.x == gridDim.x - 1) {
+        float s = 0.f;
+        for (int i = threadIdx.x; i < B; i += 256) s += loss_rows[i];
+        s = wave_sum(s);
+        if ((threadIdx.x & 63) == 0) s0[threadIdx.x >> 6] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) *loss_mean = ((s0[0] + s0[1]) + (s0[2] + s0[3])) / (float)B;
+        return;
+    }
     if ((int)blockIdx.x < nd * NS) {
         const int sp = blockIdx.x / nd, d0 = (blockIdx.x % nd) * 32, td = tid & 7, th = tid >> 3;   // register tile: d = 4 td .., h = 4 th ..
         const int bb = sp * RB, be = bb + RB < B ? bb + RB : B;
@@ -453,7 +463,7 @@ size_t dbmm_adapter_bwd_fast_floats(int64_t B, int64_t D) {
 int dbmm_adapter_bwd_fast(const float* x, const float* dz, const float* h, const float* mean, const float* invstd, const float* r, const float* gamma,
                           const float* beta, const float* w2, float* dw1, float* db1, float* dgamma, float* dbeta, float* dw2, float* db2,
                           float* dh, float* scratch, int64_t B, int64_t D, hipStream_t s, const float** dw1part_o, const float** db1part_o,
-                          int* nsplit_o) {
+                          int* nsplit_o, const float* loss_rows, float* loss_mean) {
     const int KS = (int)(D / 128), nb = (int)((B + TB - 1) / TB);
     int NS, RB; bwd_split(B, &NS, &RB);
     float* drpart = scratch;
@@ -461,7 +471,8 @@ int dbmm_adapter_bwd_fast(const float* x, const float* dz, const float* h, const
     float* db2part = dw2part + (size_t)NS * D * 128;
     float* dw1part = db2part + (size_t)NS * D;
     float* db1part = dw1part + (size_t)NS * 128 * D;
-    hipLaunchKernelGGL(bwd2_kernel, dim3((unsigned)(D / 32 * NS + nb * KS)), dim3(256), 0, s, dz, r, w2, dw2part, db2part, drpart, (int)B, (int)D, NS, RB);
+    hipLaunchKernelGGL(bwd2_kernel, dim3((unsigned)(D / 32 * NS + nb * KS + (loss_mean ? 1 : 0))), dim3(256), 0, s, dz, r, w2, dw2part, db2part, drpart,
+                       (int)B, (int)D, NS, RB, loss_rows, loss_mean);
     DBMM_CHECK_LAUNCH();
     const long long nw4 = D * 128 / 4, nb4 = D / 4;
     hipLaunchKernelGGL(bn_bwd_kernel, dim3((unsigned)(32 + (nw4 + nb4 + 255) / 256)), dim3(256), 0, s, (const float*)drpart, KS, h, mean, invstd, gamma,

@@ -638,12 +638,12 @@ _step_ws = {}
 
 def adapter_step_launches(B, D, H, with_old=False):
     """kernel launches of one dbmm_adapter_train_step call on the purpose-built kernels (csrc/adapter_step.hip): forward 3
-    (K-split fc1, BatchNorm statistics, BatchNorm + ReLU + fc2; 3 more for a frozen old adapter), cosine logits + CE forward,
-    its backward (+ the loss mean), backward 3 (dW2 / dr, BatchNorm backward + dW2 sums, dW1), SGD (+ dW1 sums); None for
+    (K-split fc1, BatchNorm statistics, BatchNorm + ReLU + fc2; 3 more for a frozen old adapter), cosine logits + CE forward
+    and backward in one, backward 3 (dW2 / dr + the loss mean, BatchNorm backward + dW2 sums, dW1), SGD (+ dW1 sums); None for
     shapes that take the general GEMM kernel (H != 128 or D % 128 != 0)"""
     if H != 128 or D % 128 or not get_option("adapter_step_fused"):
         return None
-    return 9 + (3 if with_old else 0)
+    return 8 + (3 if with_old else 0)
 
 
 def adapter_step_args(new, bufs, old):
