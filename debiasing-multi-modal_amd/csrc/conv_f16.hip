@@ -215,6 +215,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16_kernel(const ConvHP p) {
     for (int t = 0; t < D; ++t) issue_w(t, t, t < T);
 
     int wslot = 0;                                               // slot of the current tap = t % NWS
+    u32x4 afc[2][TM], afn[2][TM];                                // A fragments of the current / next tap, both k-steps
     for (int g = 0; g < G; ++g) {
         const int kh = g % 3, astage = g & 1;
 #pragma unroll
@@ -230,25 +231,39 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16_kernel(const ConvHP p) {
             if (kw == 0) issue_a(g + 1, astage ^ 1, g + 1 < G);
             const unsigned char* Wb = lds + WOFF + wslot * W_BYTES;
             const int tap = kh * 3 + kw;
-            int aoff[TM];
+            // A fragments of taps kw = 1, 2 were read during the previous tap's MFMAs (same A stage, no barrier in between);
+            // tap 0 of a group reads them now -- its strip was only guaranteed by the barrier above
+            auto read_a = [&](int kwx, u32x4 (&dst)[2][TM]) {
+                const int tp = kh * 3 + kwx;
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const bool ok = (fmask[i] >> tap) & 1u;
-                aoff[i] = ok ? astage * A_BYTES + faddr[i][kw] : ZOFF + (faddr[i][kw] & 255);
-            }
+                for (int i = 0; i < TM; ++i) {
+                    const bool ok = (fmask[i] >> tp) & 1u;
+                    const int ao = ok ? astage * A_BYTES + faddr[i][kwx] : ZOFF + (faddr[i][kwx] & 255);
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                u32x4 af[TM], wf[TN];
+                    for (int ks = 0; ks < 2; ++ks) dst[ks][i] = *(const u32x4*)(lds + (ao ^ (ks * 32)));
+                }
+            };
+            if (kw == 0) read_a(0, afc);
+            u32x4 wf[2][TN];
 #pragma unroll
-                for (int i = 0; i < TM; ++i) af[i] = *(const u32x4*)(lds + (aoff[i] ^ (ks * 32)));
+            for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) wf[j] = *(const u32x4*)(Wb + (waddr[j] ^ (ks * 32)));
+                for (int j = 0; j < TN; ++j) wf[ks][j] = *(const u32x4*)(Wb + (waddr[j] ^ (ks * 32)));
+            if (kw < 2) read_a(kw + 1, afn);
+            (void)tap;                                            // (s_setprio(1) around the MFMAs below measured 3 - 15 % slower)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[i]), __builtin_bit_cast(f16x8, wf[j]),
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, afc[ks][i]), __builtin_bit_cast(f16x8, wf[ks][j]),
                                                                            acc[i][j], 0, 0, 0);
+            if (kw < 2) {
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) afc[ks][i] = afn[ks][i];
             }
             wslot = wslot + 1 == NWS ? 0 : wslot + 1;
         }
