@@ -263,6 +263,21 @@ def test_fp16_mode_rn50_vs_reference_fp16_path(golden):
     assert any(t.startswith("conv3x3_f16_kernel<") for t in tags) and "stem_s2_f16_kernel" in tags, sorted(tags)
 
 
+@pytest.mark.parametrize("B", [1, 3])
+def test_fp16_mode_rn50_small_and_odd_batches(B, golden):
+    """B = 1 and an odd batch (every conv tile is a ragged tail; pooled 3x3 tiles hold a fraction of their windows): rows equal the
+    fixture images encoded in the fixture's own batch (bit-identical arithmetic per image up to tile order)"""
+    h = golden(gname16("RN50"))
+    seed = int(h["seed"])
+    model = convert_weights(build_model(synth.clip_state_dict(seed, "RN50")).cuda())
+    img = synth.images(seed + 100, 2, 224)
+    batch = torch.cat([img, synth.images(5, 1, 224)])[:B].cuda() if B > 1 else img[:1].cuda()
+    out = model.encode_image(batch)
+    ref = torch.from_numpy(h["embedding"])[:min(B, 2)]
+    assert out.dtype == torch.float16 and tuple(out.shape) == (B, 1024) and torch.isfinite(out).all()
+    assert relerr(out[:min(B, 2)].float().cpu(), ref) < 3.0 * float(h["f16_vs_f32"])
+
+
 def test_fp16_mode_rn50_large_batch_rows_are_independent():
     """a batch the fixture does not cover (every conv tile geometry full): any row equals the same image in a small batch"""
     model = convert_weights(build_model(synth.clip_state_dict(2, "RN50")).cuda())
