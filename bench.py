@@ -8,7 +8,8 @@
 A step = CLIP-RN50 encode_image on this rank's B_l synthetic 224x224x3 images (resident in HBM) ->
 RCCL all-gather of embeddings + labels -> replicated adapter forward + CE + backward + SGD on the
 global batch.  N = 1: B = 1024, the configuration BASELINE.json's metric is quoted on ("CLIP-RN50 224px
-bs=1024").  N >= 2: 512 images per GPU (N = 2 is BASELINE configs[2], the bs-1024 DP=2 case), weak scaling.
+bs=1024").  N >= 2: the same 1024 images per GPU (weak scaling: per-GPU work fixed; BASELINE configs[2], bs 1024 over two
+GPUs, is --batch-per-gpu 512).
 
 Arithmetic ("dtype": "f32"): activations and accumulators are fp32 in HBM / registers; each product runs
 on the 16-bit matrix cores as fp16 hi + lo pair (22-bit mantissa, exact power-of-two scale per tensor) x
@@ -387,7 +388,8 @@ def main():
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch-per-gpu", type=int, default=0,
-                    help="default: 1024 at one GPU (the metric's bs=1024), 512 per GPU otherwise (BASELINE configs[2])")
+                    help="default: 1024 images per GPU at every N (N = 1 is the metric's bs=1024; weak scaling keeps the per-GPU work fixed); "
+                         "512 = BASELINE configs[1] / configs[2]")
     ap.add_argument("--arch", default="RN50")
     ap.add_argument("--dtype", default="f32", choices=["f32", "f16"],
                     help="f32 = parity mode (the headline); f16 = the reference's GPU-path arithmetic "
@@ -417,7 +419,9 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
-    default_bl = {"RN50": 1024 if world == 1 else 512, "ViT-B/32": 512, "ViT-L/14@336px": 1024 if args.dtype == "f16" else 128}
+    # per-GPU work is the same at every N (weak scaling): RN50 runs the metric's 1024 images on every GPU, so that the driver's
+    # value(N) / (N * value(1)) compares equal launches; BASELINE configs[2] (bs = 1024 over 2 GPUs) is --batch-per-gpu 512
+    default_bl = {"RN50": 1024, "ViT-B/32": 512, "ViT-L/14@336px": 1024 if args.dtype == "f16" else 128}
     Bl = args.batch_per_gpu or default_bl.get(args.arch, 512)
     B = Bl * world
     micro = max(1, args.micro_batches)
@@ -455,6 +459,8 @@ def main():
         roof = roofline_of(prof, args.steps, step_ms, value, world, args.arch, pmc_table(args.arch, Bl, args.dtype))
         cfgs = {("RN50", 1, 1024): "the metric's configuration, CLIP-RN50 224px bs=1024 on one GPU",
                 ("RN50", 1, 512): "BASELINE configs[1]", ("RN50", 2, 512): "BASELINE configs[2]",
+                ("RN50", 2, 1024): "the metric's per-GPU batch on 2 GPUs", ("RN50", 4, 1024): "the metric's per-GPU batch on 4 GPUs",
+                ("RN50", 8, 1024): "the metric's per-GPU batch on 8 GPUs",
                 ("ViT-B/32", 8, 512): "BASELINE configs[3]", ("ViT-L/14@336px", 8, 1024): "BASELINE configs[4]",
                 ("ViT-L/14@336px", 1, 1024): "one GPU's share of BASELINE configs[4]"}
         line = {
@@ -471,16 +477,15 @@ def main():
         }
         if dist_info:
             line["dist"] = dist_info
-            line["config"]["weak_scaling_note"] = (f"{Bl} images per GPU at every N >= 2; the N = 1 line runs the metric's bs = 1024, and "
-                                                   "carries the per-GPU-batch-matched single-GPU figure as extra_legs.rn50_bs512")
+            line["config"]["weak_scaling_note"] = (f"{Bl} images per GPU at every N (the N = 1 line runs the same per-GPU batch): value(N) / (N x value(1)) "
+                                                   "compares equal per-GPU work")
         if world == 1 and not args.no_fp32_mfma_leg and args.arch.startswith("RN") and args.dtype == "f32":
             line["fp32_input_mfma"] = fp32_mfma_leg(args.arch, dev, Bl, images, y_l, g_l)
         if world == 1 and not args.no_extra_legs and args.arch == "RN50" and args.dtype == "f32" and not args.batch_per_gpu:
             del stepper, model, images
             torch.cuda.empty_cache()
             legs = {}
-            legs["rn50_bs512"] = extra_leg("RN50", "f32", 512, 4, 1, dev, "BASELINE configs[1]; the matched single-GPU baseline "
-                                           "of the N >= 2 lines, which run 512 images per GPU")
+            legs["rn50_bs512"] = extra_leg("RN50", "f32", 512, 4, 1, dev, "BASELINE configs[1] = one GPU's share of configs[2]")
             legs["rn50_f16_bs1024"] = extra_leg("RN50", "f16", 1024, 4, 1, dev, "the metric's batch in the reference's GPU-path arithmetic")
             legs["vit_b32_f32_bs512"] = extra_leg("ViT-B/32", "f32", 512, 4, 1, dev, "one GPU's share of BASELINE configs[3], parity mode")
             legs["vit_b32_f16_bs512"] = extra_leg("ViT-B/32", "f16", 512, 4, 1, dev, "one GPU's share of BASELINE configs[3], fp16 mode")
