@@ -205,9 +205,9 @@ def pmc_table(arch, Bl, dtype):
             continue
         if pmc.get("arch") != arch or pmc.get("batch_per_gpu") != Bl or pmc.get("dtype", "f32") != dtype:
             continue
-        kept = {k: v for k, v in pmc.get("kernels", {}).items()
-                if v.get("source_hash") and v["source_hash"] == _lib.kernel_source_hash(k)}
-        return {"kernels": kept, "file": os.path.relpath(path, ROOT), "dropped_stale": len(pmc.get("kernels", {})) - len(kept)}
+        ours = {k: v for k, v in pmc.get("kernels", {}).items() if v.get("source_hash")}        # (torch's own kernels carry no stamp)
+        kept = {k: v for k, v in ours.items() if v["source_hash"] == _lib.kernel_source_hash(k)}
+        return {"kernels": kept, "file": os.path.relpath(path, ROOT), "dropped_stale": len(ours) - len(kept)}
     return None
 
 
