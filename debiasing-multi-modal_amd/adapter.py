@@ -143,6 +143,31 @@ class _SimCEFn(torch.autograd.Function):
         return dz * gloss, None, None, None, None, None
 
 
+def _step_key(new_ad, old_ad, optimizer):
+    """every device address the fused step's argument block holds (15 of the trainable adapter incl. its six momentum buffers, 9 of the
+    frozen one), or None while a momentum buffer does not exist yet"""
+    key = []
+    state = optimizer.state
+    for ad, trainable in ((new_ad, True), (old_ad, False)):
+        if ad is None:
+            continue
+        mods = ad.layers._modules
+        l0, bn, l3 = mods["0"], mods["1"], mods["3"]
+        ps = (l0._parameters["weight"], l0._parameters["bias"], bn._parameters["weight"], bn._parameters["bias"],
+              l3._parameters["weight"], l3._parameters["bias"])
+        bufs = bn._buffers
+        key += [p.data_ptr() for p in ps]
+        key += [bufs["running_mean"].data_ptr(), bufs["running_var"].data_ptr(), bufs["num_batches_tracked"].data_ptr()]
+        if trainable:
+            for p in ps:
+                mb = state[p].get("momentum_buffer") if p in state else None
+                if mb is None:
+                    return None
+                key.append(mb.data_ptr())
+    key.append(id(optimizer))
+    return tuple(key)
+
+
 _text_cache = {}
 
 
@@ -202,8 +227,20 @@ class CustomCLIP(nn.Module):
         new = self.__class__.__new__(self.__class__)
         memo[id(self)] = new
         for k, v in self.__dict__.items():
+            if k == "_step_plan":                    # raw device addresses of THIS module's tensors: the copy builds its own
+                continue
             new.__dict__[k] = _TextBank() if k == "_bank" else copy.deepcopy(v, memo)
         return new
+
+    def __getstate__(self):                          # torch.save(module) / pickle: same rule as __deepcopy__
+        state = dict(self.__dict__)
+        state.pop("_step_plan", None)
+        state["_bank"] = None
+        return state
+
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        self.__dict__["_bank"] = _TextBank()
 
     def _text(self, which, device):
         if which == "group":
@@ -250,14 +287,14 @@ class CustomCLIP(nn.Module):
         if not self.training:
             raise RuntimeError("train_step needs classifier.train()")
         new_ad, old_ad = self._step_adapters()
-        w1 = new_ad.layers[0].weight
         group = optimizer.param_groups[0]
-        plan = getattr(self, "_step_plan", None)
+        plan = self.__dict__.get("_step_plan")
         first = False
-        # the argument block of the C call is rebuilt only when something it points at was replaced (a parameter moved or
-        # re-created, another optimiser, a momentum buffer swapped): the step is launch-bound, ~40 us of Python per call show
-        if (plan is None or plan["opt"] is not optimizer or plan["w1"] is not w1 or plan["w1_ptr"] != w1.data_ptr()
-                or plan["mb"] is not optimizer.state[w1].get("momentum_buffer") or plan["old"] is not old_ad):
+        # The argument block of the C call holds 24 raw pointers.  It is rebuilt whenever ANY tensor it points at was replaced or
+        # moved (a parameter / buffer / momentum buffer re-assigned, `.data` swapped, the old adapter reloaded, another optimiser):
+        # the key is the tuple of every tensor's data_ptr(), read through the modules' own dicts (~4 us; the step is launch-bound).
+        key = _step_key(new_ad, old_ad, optimizer)
+        if plan is None or plan["key"] != key or key is None:
             def pack(ad):
                 l0, bn, l3 = ad.layers[0], ad.layers[1], ad.layers[3]
                 return (l0.weight, l0.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked,
@@ -274,11 +311,13 @@ class CustomCLIP(nn.Module):
                 if "momentum_buffer" not in st or st["momentum_buffer"] is None:
                     st["momentum_buffer"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                 bufs.append(st["momentum_buffer"])
-            plan = dict(opt=optimizer, w1=w1, w1_ptr=w1.data_ptr(), mb=optimizer.state[w1]["momentum_buffer"], old=old_ad,
+            # plain integer addresses (no ctypes objects, no module / optimiser references): the plan never keeps anything alive
+            # and never travels with the module (__deepcopy__ / __getstate__ drop it)
+            plan = dict(key=_step_key(new_ad, old_ad, optimizer),
                         args=ops.adapter_step_args([t.data for t in new], bufs,
                                                    [t.data for t in pack(old_ad)] if old_ad is not None else None),
                         H=new[0].shape[0], with_old=old_ad is not None)
-            self._step_plan = plan
+            self.__dict__["_step_plan"] = plan
         tn = self._text("group" if use_group else "class", features.device)
         with torch.no_grad():
             return ops.adapter_train_step(

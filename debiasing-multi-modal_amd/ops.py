@@ -651,8 +651,7 @@ def adapter_step_args(new, bufs, old):
     (w1, b1, gamma, beta, running_mean, running_var, nbt, w2, b2); `bufs` the six momentum buffers in the order
     (w1, b1, gamma, beta, w2, b2); `old` may be None.  Valid while those tensors keep their storage."""
     require_cuda(*new)
-    return tuple(ctypes.c_void_p(ptr(t)) for t in list(new) + list(bufs)) + \
-        (tuple(ctypes.c_void_p(ptr(t)) for t in old) if old is not None else (None,) * 9)
+    return tuple(ptr(t) for t in list(new) + list(bufs)) + (tuple(ptr(t) for t in old) if old is not None else (None,) * 9)
 
 
 def adapter_train_step(x, labels, args, H, with_old, ebd_weight, tn, temperature, lr, momentum, weight_decay, first_step):

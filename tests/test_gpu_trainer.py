@@ -127,3 +127,90 @@ def test_embed_adapter_step_fused_equals_autograd(text_paths):
     assert torch.equal(la.detach(), lb.detach()) and torch.equal(ga, gb) and torch.equal(ca, cb)
     for k in sa:
         assert torch.equal(sa[k], sb[k]), k
+
+
+def test_deepcopy_and_pickle_after_fused_step(text_paths, tmp_path):
+    """final_main.py:943, 1006-1008 deep-copies the classifier every epoch and starts stage 2 from the copy; the fused step's cached
+    argument block (raw device addresses) must not travel with the module: the copy builds its own and matches the autograd path."""
+    B = 64
+    x = synth.normal(5, f"x{B}", (B, D), 0.5).cuda()
+    y, c, g = (t.cuda() for t in synth.labels(6, B))
+    ad = adapter.Adapter(D, H); ad.load_state_dict(synth.adapter_state_dict(3, D, H))
+    clf = adapter.CustomCLIP(ad, *text_paths).cuda().train()
+    opt = optim.set_optimizer(_ns(), clf)
+    for _ in range(3):
+        clf.train_step(x, y, opt)
+    best = copy.deepcopy(clf)                                        # raised ValueError (ctypes pointers) in round 3
+    assert "_step_plan" not in best.__dict__ and clf.__dict__["_step_plan"] is not None
+    for (k, va), (_, vb) in zip(clf.state_dict().items(), best.state_dict().items()):
+        assert torch.equal(va, vb) and (va.data_ptr() != vb.data_ptr() or va.numel() == 0), k
+    torch.save(best, tmp_path / "clf.pt")                            # pickles the module (same rule)
+    # stage 2 from the copy, fused vs autograd (both start from identical copies)
+    def stage2(src):
+        new = adapter.Adapter(D, H); new.load_state_dict(synth.adapter_state_dict(4, D, H))
+        ma = adapter.MultipleAdapter(copy.deepcopy(src), new, init_near_identity=False).cuda().train()
+        return ma, optim.set_optimizer_reg(_ns(), ma)
+    a, oa = stage2(best); b, ob = stage2(best)
+    for step in range(3):
+        la, logits_a, _ = a.loss(x, g, True); oa.zero_grad(); la.backward(); oa.step()
+        lb, logits_b, _ = b.train_step(x, g, ob, True)
+        assert torch.equal(logits_a, logits_b) and torch.equal(la.detach(), lb)
+    for (k, va), (_, vb) in zip(a.state_dict().items(), b.state_dict().items()):
+        assert torch.equal(va, vb), k
+    # the copy of a stepped MultipleAdapter steps on ITS tensors: the original must not move
+    before = {k: v.clone() for k, v in b.state_dict().items()}
+    b2 = copy.deepcopy(b); ob2 = optim.set_optimizer_reg(_ns(), b2)
+    b2.train_step(x, g, ob2, True)
+    for k, v in b.state_dict().items():
+        assert torch.equal(v, before[k]), k
+    assert b2.__dict__["_step_plan"]["args"] != b.__dict__["_step_plan"]["args"]
+
+
+@pytest.mark.parametrize("what", ["w2_data", "running_mean", "momentum", "old_reload"])
+def test_fused_step_follows_replaced_storage(what, text_paths):
+    """every pointer of the cached argument block is re-checked: replacing a parameter's storage, a BatchNorm buffer, a momentum
+    buffer, or reloading the frozen old adapter between steps must not leave the kernel writing through stale addresses"""
+    B = 32
+    x = synth.normal(5, f"x{B}", (B, D), 0.5).cuda()
+    y, c, g = (t.cuda() for t in synth.labels(6, B))
+
+    def make():
+        ad = adapter.Adapter(D, H); ad.load_state_dict(synth.adapter_state_dict(3, D, H))
+        old = adapter.CustomCLIP(ad, *text_paths)
+        new = adapter.Adapter(D, H); new.load_state_dict(synth.adapter_state_dict(4, D, H))
+        ma = adapter.MultipleAdapter(old, new, init_near_identity=False).cuda().train()
+        return ma, optim.set_optimizer_reg(_ns(), ma)
+
+    def disturb(m, o):
+        keep = []
+        if what == "w2_data":
+            p = m.new_adapter.layers[3].weight
+            keep.append(p.data); p.data = p.data.clone()
+        elif what == "running_mean":
+            bn = m.new_adapter.layers[1]
+            keep.append(bn.running_mean); bn.running_mean = bn.running_mean.clone()
+        elif what == "momentum":
+            for p in o.param_groups[0]["params"]:
+                keep.append(o.state[p]["momentum_buffer"]); o.state[p]["momentum_buffer"] = o.state[p]["momentum_buffer"].clone()
+        else:
+            sd = {k: v.clone() for k, v in m.old_cls.adapter.state_dict().items()}
+            keep += [p.data for p in m.old_cls.adapter.parameters()]
+            for p in m.old_cls.adapter.parameters():
+                p.data = p.data.clone()
+            m.old_cls.adapter.load_state_dict(sd)
+        return keep                                                  # old storages stay alive: a stale write would go unnoticed otherwise
+
+    a, oa = make(); b, ob = make()
+    for step in range(4):
+        if step == 2:
+            ka, kb = disturb(a, oa), disturb(b, ob)
+            stale = [t.clone() for t in kb]
+        la, logits_a, _ = a.loss(x, g, True); oa.zero_grad(); la.backward(); oa.step()
+        lb, logits_b, _ = b.train_step(x, g, ob, True)
+        assert torch.equal(logits_a, logits_b) and torch.equal(la.detach(), lb), step
+    for (k, va), (_, vb) in zip(a.state_dict().items(), b.state_dict().items()):
+        assert torch.equal(va, vb), k
+    for pa, pb in zip(oa.param_groups[0]["params"], ob.param_groups[0]["params"]):
+        assert torch.equal(oa.state[pa]["momentum_buffer"], ob.state[pb]["momentum_buffer"])
+    for t, s in zip(kb, stale):
+        assert torch.equal(t, s)                                     # nothing wrote through the replaced storages
