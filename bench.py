@@ -42,6 +42,58 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+
+def self_launch(argv):
+    """`python bench.py --gpus N` with N > 1 and no launcher environment (the driver's command shape): this process becomes a plain
+    parent that starts the N ranks as CHILD processes under torch.distributed.run (one rank per GPU, rendezvous on 127.0.0.1),
+    lets them write to its stdout / stderr (rank 0 prints the JSON line) and exits with their return code.  It runs before
+    anything of this file touches the GPU: no HIP call, no library load, no exec of a process that initialised a device
+    (torch.cuda.device_count() only counts, it does not initialise).  Returns None when there is nothing to launch."""
+    pre = argparse.ArgumentParser(add_help=False)
+    pre.add_argument("--gpus", type=int, default=1)
+    n = pre.parse_known_args(argv)[0].gpus
+    if n <= 1 or "WORLD_SIZE" in os.environ:
+        return None
+    import socket
+    import subprocess
+    backend = os.environ.get("DBMM_DIST_BACKEND", "nccl")
+    if backend == "nccl":
+        import torch
+        have = torch.cuda.device_count()
+        if have < n:
+            sys.stderr.write(f"bench.py: --gpus {n} needs {n} GPUs for RCCL (one rank per GPU), this node shows {have}; "
+                             "DBMM_DIST_BACKEND=gloo rehearses the N > 1 flow with ranks sharing a GPU\n")
+            return 2
+    with socket.socket() as sock:                                    # a free rendezvous port
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")                # dmabuf IPC: what RCCL needs on these hosts
+    env.setdefault("OMP_NUM_THREADS", str(max(1, host_cores() // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    sys.stderr.write("bench.py: launching " + " ".join(cmd) + "\n")
+    return subprocess.call(cmd, env=env)
+
+
+def host_cores():
+    """CPU threads this process may really use: affinity capped by the cgroup CPU quota (the GPU
+    boxes expose 256 logical CPUs but grant 16)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+if __name__ == "__main__":
+    _rc = self_launch(sys.argv[1:])
+    if _rc is not None:
+        sys.exit(_rc)
+
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
@@ -127,21 +179,21 @@ def write_text_jsons(D):
     return paths
 
 
-def host_cores():
-    """CPU threads this process may really use: affinity capped by the cgroup CPU quota (the GPU
-    boxes expose 256 logical CPUs but grant 16)."""
-    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+def cpu_model():
     try:
-        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
-        if quota != "max":
-            n = min(n, max(1, int(int(quota) / int(period))))
-    except (OSError, ValueError):
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
         pass
-    return n
+    return "unknown"
 
 
-def cpu_baseline(sd, D, paths_unused, bs=32, iters=3):
-    """oracle encode_image + adapter step on the host cores (kind = "port")."""
+def cpu_baseline(sd, D, paths_unused, bs=32, iters=5, warmups=2):
+    """oracle encode_image + adapter step on the host cores (kind = "port"): `warmups` untimed iterations at the SAME batch size (the
+    first call at a shape builds the oneDNN primitives), then `iters` timed ones; value = the median, min / max beside it, together
+    with the thread count torch really uses and the CPU model (the boxes share their hosts: 18 -- 146 images/s were recorded for
+    this code on different leases)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import adapter_oracle as AO
     import clip_oracle as CO
@@ -153,18 +205,24 @@ def cpu_baseline(sd, D, paths_unused, bs=32, iters=3):
     osd = {"adapter." + k: v.clone() for k, v in synth.adapter_state_dict(3, D, 128).items()}
     bufs = {}
     times = []
-    with torch.no_grad():
-        CO.rn_encode_image(sd, img[:4])                       # warm-up
-    for _ in range(iters):
+    for it in range(warmups + iters):
         t0 = time.perf_counter()
         with torch.no_grad():
             emb = CO.rn_encode_image(sd, img)
         AO.train_step(osd, bufs, emb, y, text, 0.1)
-        times.append(time.perf_counter() - t0)
+        if it >= warmups:
+            times.append(time.perf_counter() - t0)
     times.sort()
     t = times[len(times) // 2]
+    try:
+        load = os.getloadavg()[0]
+    except OSError:
+        load = None
     return {"value": round(bs / t, 2), "unit": "images/sec", "cores": cores, "kind": "port",
-            "sample": f"oracle (torch-CPU fp32) RN50 encode_image + adapter step, bs={bs}, median of {iters}"}
+            "min": round(bs / times[-1], 2), "max": round(bs / times[0], 2), "iters": iters, "warmups": warmups,
+            "torch_threads": torch.get_num_threads(), "cpu_model": cpu_model(), "host_loadavg_1m": load,
+            "sample": f"oracle (torch-CPU fp32) RN50 encode_image + adapter step, bs={bs}, {warmups} warm-ups, median of {iters} "
+                      "(min / max = slowest / fastest iteration)"}
 
 
 def build_step(arch, dev, world, rank, Bl, D_hidden=128, dtype="f32", micro_batches=1):
@@ -369,6 +427,16 @@ def adapter_only_leg(B, D, dev, steps=200, warmup=20):
     us = sorted(windows)[1]
     if not torch.isfinite(loss).item():
         raise SystemExit("non-finite adapter loss")
+    # the launch floor of THIS box: the same dependent launches on four rows (no batch-dependent work left)
+    x4, y4 = x[:4].contiguous(), y[:4].contiguous()
+    for _ in range(warmup):
+        clf.train_step(x4, y4, opt)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        clf.train_step(x4, y4, opt)
+    torch.cuda.synchronize()
+    floor_us = (time.perf_counter() - t0) / steps * 1e6
     P, C = 2 * D * 128 + 3 * 128 + D, 2
     alg_bytes = 8 * B * D + 4 * B * C + 20 * P
     launches = getattr(ops, "adapter_step_launches", lambda *a: None)(B, D, 128, False)
@@ -379,7 +447,12 @@ def adapter_only_leg(B, D, dev, steps=200, warmup=20):
             "roofline": {"bound": "hbm", "kernel": "adapter train step (all launches)", "achieved": round(alg_bytes / (us * 1e-6) / 1e9, 2),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg_bytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 5),
                          "algorithmic_bytes": alg_bytes,
-                         "launch_floor_us": None if launches is None else round(launches * 1.5, 1)}}
+                         "launch_floor_us_measured": round(floor_us, 2),
+                         "launch_floor_us_measured_how": "the same step (same dependent launches) at bs=4, same process",
+                         "launch_floor_us_survey_model": None if launches is None else round(launches * 1.5, 1),
+                         "launch_floor_us_survey_model_how": "launches x 1.5 us (SURVEY section 8d's kernel-boundary estimate; this chip "
+                                                             "measures ~5 us per DEPENDENT launch)",
+                         "frac_of_measured_floor": round(floor_us / us, 4)}}
 
 
 def main():
@@ -409,6 +482,24 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     backend = os.environ.get("DBMM_DIST_BACKEND", "nccl")     # "gloo": rehearsal of the N>1 flow on one GPU
+    if os.environ.get("DBMM_BENCH_DRYRUN") == "1":
+        # launcher / rendezvous check without a GPU (tests/test_bench_launcher.py): the ranks meet on gloo, exchange what the real
+        # run exchanges around its timed region (barrier, MAX all-reduce of the time, all_gather_object) and rank 0 prints a line
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.barrier()
+        t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+        who = [None] * world
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dist.all_gather_object(who, {"rank": rank, "local_rank": local_rank})
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "n_gpus": world, "max_over_ranks": t.item(), "ranks": who, "steps": args.steps,
+                              "warmup": args.warmup}), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
     dev_index = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
@@ -453,6 +544,24 @@ def main():
                                 if micro > 1 else "one all_gather_into_tensor of the rank's embeddings + one of its packed (y, g) per step")}
     dt = tmax.item()
 
+    # N > 1: the north_star's own shape beside the weak-scaling line -- the metric's GLOBAL batch (RN50: 1024 = BASELINE configs[2] at
+    # N = 2) split over the N ranks (strong scaling), same process group, same barriers, max over ranks
+    fixed = None
+    if world > 1 and not args.batch_per_gpu and default_bl.get(args.arch) and default_bl[args.arch] % world == 0 and micro == 1:
+        Bf = default_bl[args.arch] // world
+        img_f, y_f, g_f = synthetic_batch(R, Bf, world, rank, dev)
+        if args.dtype == "f16":
+            img_f = img_f.half()
+        dtf, _ = timed_steps(stepper, img_f, y_f, g_f, args.steps, max(1, args.warmup), barrier, False)
+        tf = torch.tensor([dtf], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
+        dist.all_reduce(tf, op=dist.ReduceOp.MAX)
+        fixed = {"config": {"workload": f"global batch {Bf * world} split over {world} GPUs ({Bf} images/GPU)"
+                                        + (" = BASELINE configs[2]" if (args.arch, world) == ("RN50", 2) else ""),
+                            "global_batch": Bf * world, "batch_per_gpu": Bf},
+                 "value": round(Bf * world * args.steps / tf.item(), 2), "unit": "images/sec", "scaling": "strong",
+                 "ms_per_step": round(tf.item() / args.steps * 1e3, 3), "steps": args.steps}
+        del img_f
+
     if rank == 0:
         value = B * args.steps / dt
         step_ms = dt / args.steps * 1e3
@@ -479,6 +588,8 @@ def main():
             line["dist"] = dist_info
             line["config"]["weak_scaling_note"] = (f"{Bl} images per GPU at every N (the N = 1 line runs the same per-GPU batch): value(N) / (N x value(1)) "
                                                    "compares equal per-GPU work")
+        if world > 1 and fixed is not None:
+            line["fixed_global_batch"] = fixed
         if world == 1 and not args.no_fp32_mfma_leg and args.arch.startswith("RN") and args.dtype == "f32":
             line["fp32_input_mfma"] = fp32_mfma_leg(args.arch, dev, Bl, images, y_l, g_l)
         if world == 1 and not args.no_extra_legs and args.arch == "RN50" and args.dtype == "f32" and not args.batch_per_gpu:

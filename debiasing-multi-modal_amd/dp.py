@@ -33,10 +33,11 @@ def shard_rows(n_rows, world, rank):
     return rank * per, (rank + 1) * per
 
 
-def all_gather_rows(t, group=None):
-    """concatenate equal-sized per-rank row blocks in rank order (one all-gather)."""
+def all_gather_rows(t, group=None, always=False):
+    """concatenate equal-sized per-rank row blocks in rank order (one all-gather).  `always`: run the collective even in a world of
+    one rank (tests/test_gpu_dist.py uses it to put RCCL itself on a one-GPU box)."""
     world, _ = _world(group)
-    if world == 1:
+    if world == 1 and not (always and dist.is_available() and dist.is_initialized()):
         return t
     t = t.contiguous()
     if t.is_cuda and dist.get_backend(group) == "gloo":
@@ -57,17 +58,18 @@ class EmbedAdapterStep:
     optimizer:   dbmm_amd.optim.SGD over the classifier's trainable parameters
     """
 
-    def __init__(self, encode_fn, classifier, optimizer, n_groups=4, group=None, fused=True, micro_batches=1):
+    def __init__(self, encode_fn, classifier, optimizer, n_groups=4, group=None, fused=True, micro_batches=1, always_collective=False):
         self.encode_fn, self.classifier, self.optimizer = encode_fn, classifier, optimizer
         self.n_groups, self.group, self.fused = n_groups, group, fused
+        self.always = bool(always_collective)          # a world of ONE rank still issues its collectives (RCCL on a one-GPU box)
         self.micro_batches = int(micro_batches)
         self.counts = None
         self._side = None
 
     def gather(self, emb_local, y_local, g_local):
         labels = torch.stack([y_local, g_local], dim=1)             # int64 [B_l, 2]: one message
-        emb = all_gather_rows(emb_local, self.group)
-        labels = all_gather_rows(labels, self.group)
+        emb = all_gather_rows(emb_local, self.group, self.always)
+        labels = all_gather_rows(labels, self.group, self.always)
         return emb, labels[:, 0].contiguous(), labels[:, 1].contiguous()
 
     def encode_gather_overlapped(self, images_local, y_local, g_local):
@@ -79,7 +81,7 @@ class EmbedAdapterStep:
             raise ValueError(f"local batch {Bl} is not divisible by micro_batches {k}")
         m = Bl // k
         chunk = lambda j: images_local[j * m:(j + 1) * m].contiguous()
-        if world == 1:
+        if world == 1 and not (self.always and dist.is_available() and dist.is_initialized()):
             return torch.cat([self.encode_fn(chunk(j)) for j in range(k)]), y_local, g_local
         labels = torch.stack([y_local, g_local], dim=1)             # int64 [B_l, 2]: one message
         rccl = images_local.is_cuda and dist.get_backend(self.group) != "gloo"
@@ -101,8 +103,8 @@ class EmbedAdapterStep:
                     works.append(dist.all_gather_into_tensor(G[j], e, group=self.group, async_op=True))
                 e.record_stream(side)
             else:                                                   # gloo rehearsal (ranks sharing one GPU / CPU tests): same data flow
-                G[j].copy_(all_gather_rows(e, self.group))
-        labels = all_gather_rows(labels, self.group)
+                G[j].copy_(all_gather_rows(e, self.group, self.always))
+        labels = all_gather_rows(labels, self.group, self.always)
         for w in works:
             w.wait()                                                # stream-level: the compute stream waits, the host does not
         if rccl:

@@ -106,3 +106,78 @@ def test_two_ranks_one_gpu_equal_single_process(tmp_path, micro):
     torch.cuda.synchronize()
     assert _state_bytes(clf, opt, step, loss) == res[0][2]
     assert int(step.counts[:, 0].sum()) == B * STEPS
+
+
+def _rccl_worker(port, tmp, q):
+    """ONE rank on the `nccl` backend (= RCCL): a one-GPU box cannot host two RCCL ranks, but a world of one still loads RCCL, builds
+    its communicator on this GPU and runs every collective as an RCCL kernel on RCCL's stream -- the calls bench.py and
+    dp.EmbedAdapterStep make at N > 1, including the side-stream / async_op / record_stream ordering of the overlap path."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        from dbmm_amd import dp
+        out = {"backend": dist.get_backend()}
+        for micro in (1, 2):
+            model, clf, opt, images, y, g = _setup(tmp)
+            step = dp.EmbedAdapterStep(model.encode_image, clf, opt, micro_batches=micro, always_collective=True)
+            for _ in range(STEPS):
+                loss, logits, emb = step.step(images, y, g)
+            dist.barrier(device_ids=[0])
+            torch.cuda.synchronize()
+            out[micro] = _state_bytes(clf, opt, step, loss)
+        t = torch.tensor([1.25], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)                    # bench.py's max-over-ranks of the timed region
+        who = [None]
+        dist.all_gather_object(who, {"rank": 0, "device": torch.cuda.current_device()})
+        # a gather much larger than a step's (64 MiB) racing a kernel that rewrites its source right after: stream ordering
+        big = torch.arange(16 << 20, device=dev, dtype=torch.float32)
+        got = dp.all_gather_rows(big.view(-1, 1024), always=True)
+        big.zero_()
+        torch.cuda.synchronize()
+        out["allreduce"], out["who"] = t.item(), who
+        out["big_ok"] = bool(torch.equal(got.flatten(), torch.arange(16 << 20, device=dev, dtype=torch.float32)))
+        q.put(out)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_runs_the_collectives_of_the_step_on_one_gpu(tmp_path):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(_free_port(), str(tmp_path), q))
+    p.start()
+    out = q.get(timeout=600)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    assert out["backend"] == "nccl" and out["allreduce"] == 1.25 and out["who"] == [{"rank": 0, "device": 0}] and out["big_ok"]
+    # the same steps without any process group, chunked like the micro-batched rank encodes
+    from dbmm_amd import dp
+    for micro in (1, 2):
+        model, clf, opt, images, y, g = _setup(str(tmp_path))
+        encode = lambda x: torch.cat([model.encode_image(c.contiguous()) for c in x.chunk(micro)])
+        step = dp.EmbedAdapterStep(encode, clf, opt)
+        for _ in range(STEPS):
+            loss, _, _ = step.step(images, y, g)
+        torch.cuda.synchronize()
+        assert _state_bytes(clf, opt, step, loss) == out[micro], micro
+
+
+def test_bench_starts_its_own_ranks(tmp_path):
+    """the driver's command shape, `python bench.py --gpus 2 ...` with no launcher environment: the parent starts two ranks (gloo
+    rehearsal: both on this GPU), rank 0's line carries the dist block and the fixed-global-batch leg, return code 0"""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(DBMM_DIST_BACKEND="gloo", DBMM_BENCH_PROFILE="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"], env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [json.loads(l) for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    line = lines[0]
+    assert line["n_gpus"] == 2 and line["dist"]["world_size"] == 2 and line["dist"]["backend"] == "gloo"
+    assert line["config"]["global_batch"] == 2048 and line["fixed_global_batch"]["config"]["global_batch"] == 1024
+    assert line["value"] > 0 and line["fixed_global_batch"]["value"] > 0
