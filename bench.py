@@ -15,7 +15,7 @@ Arithmetic ("dtype": "f32"): activations and accumulators are fp32 in HBM / regi
 on the 16-bit matrix cores as fp16 hi + lo pair (22-bit mantissa, exact power-of-two scale per tensor) x
 the checkpoint's fp16-exact weight, fp32 accumulate -- error vs fp64 equal to an fp32-input-MFMA kernel's
 (DESIGN.md section 4).  The line also carries `fp32_input_mfma`: the same step with every product on
-v_mfma_f32_32x32x2_f32 (DBMM_CONV_SPLIT=off), measured in the same process.
+v_mfma_f32_32x32x2_f32 (plan option conv_split = off), measured in the same process.
 
 Besides the contract line, rank 0 reports
   roofline      every igemm launch of the timed region is bracketed by HIP events on its stream; kernels are
@@ -620,8 +620,7 @@ def fp32_mfma_leg(arch, dev, Bl, images, y_l, g_l, steps=2):
     """the same step with every product on the fp32-input MFMA (v_mfma_f32_32x32x2_f32): what "f32" would cost
     without the fp16-pair split -- printed beside the headline so the label cannot be misread"""
     from dbmm_amd.clip import model as M
-    saved = M.CONV_SPLIT
-    M.CONV_SPLIT = "off"
+    saved = M.set_plan_option("conv_split", "off")
     try:
         _, _, _, _, _, stepper = build_step(arch, dev, 1, 0, Bl)
         stepper.step(images, y_l, g_l)
@@ -632,9 +631,9 @@ def fp32_mfma_leg(arch, dev, Bl, images, y_l, g_l, steps=2):
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
     finally:
-        M.CONV_SPLIT = saved
+        M.set_plan_option("conv_split", saved)
     return {"value": round(Bl * steps / dt, 2), "unit": "images/sec", "steps": steps,
-            "note": "DBMM_CONV_SPLIT=off: fp32-input MFMA for every product, same process, same batch"}
+            "note": "plan option conv_split = off: fp32-input MFMA for every product, same process, same batch"}
 
 
 if __name__ == "__main__":

@@ -147,6 +147,8 @@ _SIGS = {
     "dbmm_workspace_bytes_adapter_bwd": [_L, _L, _L],
     "dbmm_adapter_bwd": [_P] * 15 + [_L, _L, _L, _P, _Z, _P],
     "dbmm_text_colnorm": [_P, _P, _L, _L, _P],
+    "dbmm_l2norm_rows": [_P, _P, _L, _L, _P],
+    "dbmm_colsum": [_P, _P, _L, _L, _P],
     "dbmm_l2norm_sim_ce_fwd": [_P, _P, _F, _P, _P, _F, _P, _P, _P, _P, _P, _L, _L, _L, _P],
     "dbmm_l2norm_sim_ce_bwd": [_P, _P, _F, _I, _P, _P, _P, _P, _F, _F, _P, _L, _L, _L, _P],
     "dbmm_sgd_momentum": [_L, _P, _P, _P, _P, _F, _F, _F, _I, _P],

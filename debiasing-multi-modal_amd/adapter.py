@@ -52,7 +52,7 @@ class _LinearFn(torch.autograd.Function):
         gp = torch.zeros((g.shape[0], npad), device=g.device)
         gp[:, :n] = g
         dw = ops.gemm(gp, x, trans_a=True, trans_w=True)[:n]
-        db = g.sum(0)
+        db = ops.colsum(gp)[:n]
         dx = None
         if ctx.needs_input_grad[0]:
             wp = torch.zeros((npad, w.shape[1]), device=w.device); wp[:n] = w
@@ -268,10 +268,11 @@ class CustomCLIP(nn.Module):
         tn = self._text("spurious", features.device)
         return _SimFn.apply(z, z_old, tn, self.temperature, getattr(self, "ebd_weight", 0.5))
 
-    def loss(self, features, labels, use_group=False):
-        """fused step body: returns (mean CE, logits, per-row CE)."""
+    def loss(self, features, labels, use_group=False, spurious=False):
+        """fused step body: returns (mean CE, logits, per-row CE); `spurious`: against the spurious-attribute prompts
+        (forward_spurious + criterion, final_main.py:764-766)."""
         z, z_old = self._features(features)
-        tn = self._text("group" if use_group else "class", features.device)
+        tn = self._text("spurious" if spurious else "group" if use_group else "class", features.device)
         return _SimCEFn.apply(z, z_old, tn, self.temperature, getattr(self, "ebd_weight", 0.5), labels)
 
     def _step_adapters(self):

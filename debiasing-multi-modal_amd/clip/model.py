@@ -17,7 +17,7 @@ Each tower compiles an execution plan on first use and `forward` walks that plan
     accuracy, which the 1e-3 logit parity against the reference's CPU path needs.  Eval-mode BatchNorm is a
     per-channel scale / bias in the conv epilogue; ReLU, residual adds and the 2x2 average pools are fused
     there too; in layers 1-2 conv3 + residual and the next block's conv1 are one launch.
-    DBMM_CONV_SPLIT=bf16 / off select the bf16-triple / fp32-input-MFMA variants of the same arithmetic.
+    set_plan_option("conv_split", "bf16" / "off") selects the bf16-triple / fp32-input-MFMA variants of the same arithmetic.
   * fp16 throughput mode (`convert_weights(model)` or `model.half()`, the reference's GPU path,
     clip/model.py:375-396): every tower keeps fp16 activations in HBM, one fp16 MFMA per product, fp32 accumulation,
     fp32 LayerNorm / softmax statistics / BatchNorm arithmetic (csrc/f16_ops.hip, csrc/conv_f16.hip).  RN towers whose
@@ -127,23 +127,46 @@ def _conv_bn(conv, bn):
     return _pack_conv(w, b, raw=conv.weight.detach().float(), scale=scale)
 
 
-# how the conv weights are split for the matrix cores: "f16" = fp16 pair + per-tensor power-of-two
-# scales (three partial products), "bf16" = bf16 triple (six), "off" = fp32-input MFMA only.
-# All three are fp32-accurate; the switch exists for ablation runs.
-CONV_SPLIT = os.environ.get("DBMM_CONV_SPLIT", "f16")
+# Plan options: how a tower's execution plan is built.  ONE table, set by name (`set_plan_option`), each entry seeded once at
+# import from DBMM_<NAME> like the library's own option table (csrc/options.hip) so that developer A/B runs still work from the
+# shell; nothing below reads the environment.  All settings are fp32-accurate; they exist for ablation runs.
+#   conv_split  how operands are split for the matrix cores: "f16" = fp16 pair + per-tensor power-of-two scales (two / three
+#               partial products), "bf16" = bf16 triple (six), "off" = fp32-input MFMA only
+#   conv_k_order  K order of the packed KxK conv weights: "chunk32" = (cin/32, kh, kw, 32), the taps of a 32-channel slab are
+#               consecutive K chunks so the KH*KW re-reads of an input pixel are L2 hits (+1.4 ... +9.8 % per 3x3 layer, HBM-side
+#               fetch -75 %; pack_conv_weight falls back to tap-major when Cin % 32 != 0); "tap" = tap-major
+#   fuse_ds     conv3 + downsample branch of a stage's first block as one dual-source GEMM (0: two launches)
+#   fuse_chain  conv3 + residual chained with the next block's conv1 in one launch (0: separate launches)
+#   fuse_conv2  ... and the block's own 3x3 conv2 inside that launch too (0: conv2 as its own launch)
+_PLAN_OPTIONS = {"conv_split": ("f16", ("f16", "bf16", "off")), "conv_k_order": ("chunk32", ("chunk32", "tap")),
+                 "fuse_ds": (1, (0, 1)), "fuse_chain": (1, (0, 1)), "fuse_conv2": (1, (0, 1))}
+_opt = {}
+_opt_version = [0]
 
 
-# K order of the packed KxK conv weights in fp16 mode: (cin/32, kh, kw, 32) -- the taps of a
-# 32-channel slab are consecutive K chunks, so the KH*KW re-reads of an input pixel are L2 hits
-# instead of fabric traffic (measured +1.4 ... +9.8 % per 3x3 layer, HBM-side fetch -75 %).
-# pack_conv_weight falls back to tap-major when Cin % 32 != 0.  DBMM_CONV_K_ORDER=tap restores it.
-_K_ORDER = False if os.environ.get("DBMM_CONV_K_ORDER", "chunk32") == "tap" else 32
-# conv3 + downsample branch of a stage's first block as one dual-source GEMM (DBMM_FUSE_DS=0: two launches)
-_FUSE_DS = os.environ.get("DBMM_FUSE_DS", "1") != "0"
-# conv3 + residual chained with the next block's conv1 in one launch (layer 1; DBMM_FUSE_CHAIN=0: separate launches)
-_FUSE_CHAIN = os.environ.get("DBMM_FUSE_CHAIN", "1") != "0"
-# ... and the block's own 3x3 conv2 inside that launch too (DBMM_FUSE_CONV2=0: conv2 as its own launch)
-_FUSE_CONV2 = os.environ.get("DBMM_FUSE_CONV2", "1") != "0"
+def set_plan_option(name, value):
+    """set a plan option by name; returns the previous value.  Plans compiled under other settings are rebuilt on next use."""
+    default, allowed = _PLAN_OPTIONS[name]
+    if isinstance(default, int):
+        value = int(value)
+    if value not in allowed:
+        raise ValueError(f"plan option {name}: {value!r} not in {allowed}")
+    old = _opt.get(name, default)
+    _opt[name] = value
+    _opt_version[0] += 1
+    return old
+
+
+def plan_option(name):
+    return _opt[name]
+
+
+for _name in _PLAN_OPTIONS:
+    set_plan_option(_name, os.environ.get("DBMM_" + _name.upper(), _PLAN_OPTIONS[_name][0]))
+
+
+def _k_order():
+    return False if _opt["conv_k_order"] == "tap" else 32
 
 
 def _pack_conv(w64, bias, raw=None, scale=None):
@@ -155,20 +178,20 @@ def _pack_conv(w64, bias, raw=None, scale=None):
     of two is exact in fp16: the fp16-pair kernel then needs ONE weight plane and two partial
     products, with the BatchNorm scale applied to the accumulator in the epilogue (`sc`) instead
     of being folded into (and de-fp16-ing) the weights."""
-    if raw is not None and CONV_SPLIT == "f16" and raw.is_cuda:
-        w, wl = ops.pack_conv_weight(raw, chunk_major=_K_ORDER)
+    if raw is not None and _opt["conv_split"] == "f16" and raw.is_cuda:
+        w, wl = ops.pack_conv_weight(raw, chunk_major=_k_order())
         K, cin = w.shape[1], raw.shape[1]
         if K % 32 == 0 and (raw.shape[2] * raw.shape[3] == 1 or cin % 32 == 0):
             ph, we, n = ops.split_planes_f16(w, allow_single=True)
             if n == 1:
                 return dict(w=w, wl=wl, b=bias.float().contiguous(), p3=None, ph=ph, we=we,
                             sc=scale.float().contiguous())
-    w, wl = ops.pack_conv_weight(w64, chunk_major=_K_ORDER if CONV_SPLIT == "f16" else False)
+    w, wl = ops.pack_conv_weight(w64, chunk_major=_k_order() if _opt["conv_split"] == "f16" else False)
     c = dict(w=w, wl=wl, b=bias.float().contiguous(), p3=None, ph=None, we=0, sc=None)
-    if w.is_cuda and w.shape[1] % 16 == 0 and (w.shape[0] > 32 or CONV_SPLIT == "f16"):
-        if CONV_SPLIT == "f16":
+    if w.is_cuda and w.shape[1] % 16 == 0 and (w.shape[0] > 32 or _opt["conv_split"] == "f16"):
+        if _opt["conv_split"] == "f16":
             c["ph"], c["we"], _ = ops.split_planes_f16(w)
-        elif CONV_SPLIT == "bf16":
+        elif _opt["conv_split"] == "bf16":
             c["p3"] = ops.split_planes(w)
     return c
 
@@ -207,7 +230,7 @@ class ModifiedResNet(nn.Module):
 
     def _param_key(self):
         """changes whenever a parameter or buffer is replaced or edited in place (optimizer step, .copy_())"""
-        return tuple((t.data_ptr(), t._version) for t in list(self.parameters()) + list(self.buffers()))
+        return (_opt_version[0],) + tuple((t.data_ptr(), t._version) for t in list(self.parameters()) + list(self.buffers()))
 
     @torch.no_grad()
     def _compile(self):
@@ -247,8 +270,11 @@ class ModifiedResNet(nn.Module):
         return P
 
     def _f16_eligible(self):
-        """the fp16 kernels' shapes: every 1x1 conv reduces over a multiple of 64 channels, the stem convs over 32"""
-        return self.conv2.weight.shape[1] % 32 == 0 and self.conv3.weight.shape[0] % 64 == 0 and self.conv1.weight.shape[0] in (32, 64)
+        """the fp16 kernels' shapes: every 1x1 conv reduces over a multiple of 64 channels, the stem convs over 32, and every map
+        that is average-pooled has even sides (input resolution a multiple of 32: the pooled 3x3 kernels and avgpool2_f16 take
+        even maps only, where the reference's AvgPool2d(2) floors); other towers keep the fp32-accurate plan"""
+        return (self.conv2.weight.shape[1] % 32 == 0 and self.conv3.weight.shape[0] % 64 == 0 and self.conv1.weight.shape[0] in (32, 64)
+                and self.input_resolution % 32 == 0)
 
     @torch.no_grad()
     def _compile_f16(self):
@@ -296,6 +322,8 @@ class ModifiedResNet(nn.Module):
         x = x.contiguous()
         if x.dtype not in (torch.float16, torch.float32):
             x = x.float()
+        if x.shape[2] % 32 or x.shape[3] % 32:
+            raise ops.DbmmUnsupported(f"fp16 mode of the ModifiedResNet tower needs image sides that are multiples of 32, got {tuple(x.shape)}")
         x = ops.conv_stem_s2_f16(x, *P["stem1"])                       # NCHW image -> fp16 NHWC
         x = ops.conv3x3_f16(x, *P["stem2"])
         x = ops.conv3x3_f16(x, *P["stem3"], pool=2)                     # + the stem's AvgPool2d(2)
@@ -337,7 +365,7 @@ class ModifiedResNet(nn.Module):
         n_slots = 3 + 4 * len(P["blocks"])
         amax = torch.zeros(n_slots, device=x.device, dtype=torch.float32)
         slot = [1]
-        track = CONV_SPLIT == "f16"          # the maxima are only needed by the fp16-pair kernels
+        track = _opt["conv_split"] == "f16"          # the maxima are only needed by the fp16-pair kernels
         x = ops.conv_stem_s2(x, *P["stem1"], y_absmax=amax[0:1] if track else None)   # -> NHWC from here on
 
         def conv(t, t_am, c, res, k, pad, act, pool=1, keep_full=False):
@@ -362,9 +390,9 @@ class ModifiedResNet(nn.Module):
                 else:
                     out, oam = conv(x, am, e["c1"], None, 1, 0, ops.ACT_RELU)
                 nxt = blocks[bi] if bi < len(blocks) else None
-                if (e["stride"] == 1 and track and _FUSE_CHAIN and _FUSE_CONV2 and nxt is not None and nxt["stride"] == 1
+                if (e["stride"] == 1 and track and _opt["fuse_chain"] and _opt["fuse_conv2"] and nxt is not None and nxt["stride"] == 1
                         and all(c["sc"] is not None and c["ph"] is not None for c in (e["c2"], e["c3"], nxt["c1"]))
-                        and ("ds" not in e or ("dual" in e and _FUSE_DS))):
+                        and ("ds" not in e or ("dual" in e and _opt["fuse_ds"]))):
                     # conv2 -> conv3 + residual (or downsample branch) -> next conv1: the whole rest of the block in ONE launch
                     ndsl = 3 if "ds" in e else 2                # slots the separate launches would use after conv2's
                     x_am, y1_am = amax[slot[0] + 1:slot[0] + 2], amax[slot[0] + ndsl:slot[0] + ndsl + 1]
@@ -387,7 +415,7 @@ class ModifiedResNet(nn.Module):
                     if e["stride"] > 1:
                         identity = x_pooled if (x_pooled is not None and e["stride"] == 2) else ops.avgpool2d(x, e["stride"])
                     nxt = blocks[bi] if bi < len(blocks) else None
-                    if ("dual" in e and track and _FUSE_DS and _FUSE_CHAIN and e["stride"] == 1 and nxt is not None
+                    if ("dual" in e and track and _opt["fuse_ds"] and _opt["fuse_chain"] and e["stride"] == 1 and nxt is not None
                             and nxt["c1"]["sc"] is not None and nxt["c1"]["ph"] is not None and "ds" not in nxt):
                         # ... and the same launch continues into the next block's conv1 (layer 1's first block)
                         x_am, y1_am = amax[slot[0]:slot[0] + 1], amax[slot[0] + 2:slot[0] + 3]
@@ -397,7 +425,7 @@ class ModifiedResNet(nn.Module):
                             slot[0] += 3                  # conv3's and the branch's slots, and the next conv1's
                             x, am, x_pooled, y1_next = r[0], x_am, None, (r[1], y1_am)
                             continue
-                    if "dual" in e and track and _FUSE_DS:
+                    if "dual" in e and track and _opt["fuse_ds"]:
                         # out = relu(bn3(conv3(out)) + bn_d(conv_d(identity))) in one launch: the branch
                         # output is never materialised
                         y_am = amax[slot[0]:slot[0] + 1]
@@ -414,7 +442,7 @@ class ModifiedResNet(nn.Module):
                 nxt = blocks[bi] if bi < len(blocks) else None
                 want_pool = nxt is not None and nxt["stride"] == 2 and "ds" in nxt and x.shape[1] % 2 == 0 and x.shape[2] % 2 == 0 \
                     and identity.shape[1] % 2 == 0 and identity.shape[2] % 2 == 0
-                if (nxt is not None and track and _FUSE_CHAIN and e["c3"]["sc"] is not None and nxt["c1"]["sc"] is not None
+                if (nxt is not None and track and _opt["fuse_chain"] and e["c3"]["sc"] is not None and nxt["c1"]["sc"] is not None
                         and e["c3"]["ph"] is not None and nxt["c1"]["ph"] is not None
                         and (want_pool or not (nxt["stride"] == 2 and "ds" in nxt))):
                     # the same launch continues into the next block's conv1: x is written once, not re-read
@@ -472,20 +500,20 @@ class Transformer(nn.Module):
         return super()._apply(fn, *a, **k)
 
     def _weight_key(self):
-        return tuple((w.data_ptr(), w._version) for b in self.resblocks
-                     for w in (b.attn.in_proj_weight, b.attn.out_proj.weight, b.mlp.c_fc.weight, b.mlp.c_proj.weight))
+        return (_opt_version[0],) + tuple((w.data_ptr(), w._version) for b in self.resblocks
+                                          for w in (b.attn.in_proj_weight, b.attn.out_proj.weight, b.mlp.c_fc.weight, b.mlp.c_proj.weight))
 
     @torch.no_grad()
     def _split_planes(self):
         """pre-split planes of the four projection weights of every block for the split-precision
         GEMMs: fp16 (one plane when the weight is exact in fp16, as after build_model; else hi + lo)
-        or, with DBMM_CONV_SPLIT=bf16, the bf16 triple; "off" = fp32-input MFMA."""
+        or, with conv_split = "bf16", the bf16 triple; "off" = fp32-input MFMA."""
         def one(w):
             w = w.detach().contiguous()
-            if CONV_SPLIT == "f16" and w.shape[1] % 16 == 0:
+            if _opt["conv_split"] == "f16" and w.shape[1] % 16 == 0:
                 ph, we, _ = ops.split_planes_f16(w, allow_single=True)
                 return dict(w_planes_f16=ph, w_exp=we)
-            if CONV_SPLIT == "bf16":
+            if _opt["conv_split"] == "bf16":
                 return dict(w_planes=ops.split_planes(w))
             return {}
         self._planes = [tuple(one(w) for w in (b.attn.in_proj_weight, b.attn.out_proj.weight, b.mlp.c_fc.weight,
@@ -538,7 +566,7 @@ class Transformer(nn.Module):
         if planes is None or self._planes_key != self._weight_key():     # load_state_dict / in-place edits
             planes = self._split_planes()
         amax = torch.zeros(4 * len(self.resblocks), device=x.device, dtype=torch.float32)
-        f16 = CONV_SPLIT == "f16"
+        f16 = _opt["conv_split"] == "f16"
         for i, (blk, (p_in, p_out, p_fc, p_proj)) in enumerate(zip(self.resblocks, planes)):
             a = [amax[4 * i + j:4 * i + j + 1] if f16 else None for j in range(4)]
             sc = (lambda am: dict(a_absmax=am)) if f16 else (lambda am: {})
@@ -605,8 +633,8 @@ class VisionTransformer(nn.Module):
         w1 = self.conv1.weight.reshape(W, -1)
         kw = {}
         x_am = None
-        if CONV_SPLIT == "f16" and w1.shape[1] % 16 == 0:                 # fp16-pair GEMM: planes cached per weight
-            key = (w1.data_ptr(), w1._version)
+        if _opt["conv_split"] == "f16" and w1.shape[1] % 16 == 0:                 # fp16-pair GEMM: planes cached per weight
+            key = (w1.data_ptr(), w1._version, _opt_version[0])
             if getattr(self, "_conv1_planes", (None,))[0] != key:
                 ph, we, _ = ops.split_planes_f16(w1.detach().contiguous(), allow_single=True)
                 self._conv1_planes = (key, ph, we)
@@ -670,10 +698,12 @@ class CLIP(nn.Module):
     def forward(self, image, text):
         image_features = self.encode_image(image)
         text_features = self.encode_text(text)
-        image_features = image_features / image_features.norm(dim=1, keepdim=True)
-        text_features = text_features / text_features.norm(dim=1, keepdim=True)
-        logit_scale = self.logit_scale.exp()
-        logits_per_image = logit_scale * image_features @ text_features.t()
+        # clip/model.py:362-370: cosine similarity as logits -- row normalisation and the [B, n] product on the kernels
+        # (fp16 mode: on the .float() embeddings, result cast back)
+        out_dtype = image_features.dtype
+        image_features = ops.l2norm_rows(image_features.float().contiguous())
+        text_features = ops.l2norm_rows(text_features.float().contiguous())
+        logits_per_image = ops.gemm(image_features, text_features, alpha=float(self.logit_scale.exp())).to(out_dtype)
         return logits_per_image, logits_per_image.t()
 
 

@@ -142,6 +142,18 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
     if (rl == 0 && j < N) *(f32x4*)(out + j) = red[0][cg];
 }
 
+// y[r][:] = x[r][:] / ||x[r][:]||: one wave per row, the row read twice (the second pass hits L2), no epsilon (clip/model.py:362-363)
+__global__ __launch_bounds__(256) void l2norm_rows_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int D4) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= B) return;
+    const f32x4* xr = (const f32x4*)x + (long long)row * D4;
+    f32x4* yr = (f32x4*)y + (long long)row * D4;
+    float s = 0.f;
+    for (int i = lane; i < D4; i += 64) { const f32x4 v = xr[i]; s = fmaf(v.x, v.x, s); s = fmaf(v.y, v.y, s); s = fmaf(v.z, v.z, s); s = fmaf(v.w, v.w, s); }
+    const float inv = 1.f / sqrtf(wave_sum(s));
+    for (int i = lane; i < D4; i += 64) yr[i] = xr[i] * inv;
+}
+
 // tn[c][:] = text[:, c] / ||text[:, c]||
 __global__ __launch_bounds__(256) void text_colnorm_kernel(const float* __restrict__ text, float* __restrict__ tn,
                                                            int D, int C) {
@@ -484,6 +496,24 @@ extern "C" int dbmm_adapter_bwd(const float* x, const float* dz, const float* h,
     rc = dbmm_gemm_bias_act(dh, H, 1, x, D, 1, nullptr, nullptr, 0, dw1, D, H, D, B, 1.f, DBMM_ACT_NONE, stream);
     if (rc) return rc;
     hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((H + 15) / 16)), dim3(256), 0, s, dh, (int)B, (int)H, db1);
+    DBMM_CHECK_LAUNCH();
+    return DBMM_OK;
+}
+
+extern "C" int dbmm_l2norm_rows(const float* x, float* y, int64_t B, int64_t D, void* stream) {
+    if (!x || !y) return DBMM_E_ARG;
+    if (B <= 0 || D <= 0 || (D & 3) || B > INT32_MAX) return DBMM_E_SHAPE;
+    if (!dbmm_aligned16(x) || !dbmm_aligned16(y)) return DBMM_E_ALIGN;
+    hipLaunchKernelGGL(l2norm_rows_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, y, (int)B, (int)(D / 4));
+    DBMM_CHECK_LAUNCH();
+    return DBMM_OK;
+}
+
+extern "C" int dbmm_colsum(const float* x, float* out, int64_t B, int64_t N, void* stream) {
+    if (!x || !out) return DBMM_E_ARG;
+    if (B <= 0 || N <= 0 || (N & 3) || B > INT32_MAX) return DBMM_E_SHAPE;
+    if (!dbmm_aligned16(x) || !dbmm_aligned16(out)) return DBMM_E_ALIGN;
+    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((N + 15) / 16)), dim3(256), 0, (hipStream_t)stream, x, (int)B, (int)N, out);
     DBMM_CHECK_LAUNCH();
     return DBMM_OK;
 }

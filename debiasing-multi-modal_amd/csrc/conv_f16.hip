@@ -106,8 +106,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16_kernel(const ConvHP p) {
     const int px0 = pxf - 1 - p.W > 0 ? pxf - 1 - p.W : 0;
     const __amdgpu_buffer_rsrc_t rsA = desc(p.x, p.x_total, (long long)px0 * p.Cin * 2);
     const __amdgpu_buffer_rsrc_t rsW = desc(p.w, p.w_total, (long long)n0 * (9 * p.Cin) * 2);
-    const __amdgpu_buffer_rsrc_t rsA0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, 0, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsW0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, 0, 0x00020000);
+    // (stages past the end of K are issued too -- every wave issues the same number of DMA instructions, the waits are counted --
+    //  and fetch nothing: out of range BY LANE, voffset = OOR with a zero scalar offset on the real descriptor.  A zero-extent
+    //  descriptor with a non-zero scalar offset is not relied on: the range check is offset >= num_records - soffset.)
 
     // ---- stager: wave-DMA instruction k of a block covers LDS rows 16 k .. 16 k + 15; lane -> (row 16 k + lane / 4, 16-B
     //      slot lane % 4), which receives SOURCE chunk slot ^ swz(row).  Instructions k = wave + 4 i; the ones past the
@@ -145,21 +146,19 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16_kernel(const ConvHP p) {
     auto issue_a = [&](int g, int stage, bool valid) {          // group g = (slab, kh): pixel shift (kh - 1) * W, channels slab * 32 ..
         const int slab = g / 3, kh = g - slab * 3;
         const unsigned delta = (unsigned)(((kh - 1) * p.W * p.Cin + slab * 32) * 2);
-        const __amdgpu_buffer_rsrc_t ra = valid ? rsA : rsA0;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const int k = wave + 4 * i;
             unsigned char* dst = k < NIA ? lds + stage * A_BYTES + k * 1024 : lds + DUMP;
-            glds16(ra, dst, fa_off[i] == OOR ? OOR : fa_off[i] + delta, 0u);
+            glds16(rsA, dst, (!valid || fa_off[i] == OOR) ? OOR : fa_off[i] + delta, 0u);
         }
     };
     auto issue_w = [&](int t, int slot, bool valid) {           // tap step t: K columns [32 t, 32 t + 32)
-        const __amdgpu_buffer_rsrc_t rw = valid ? rsW : rsW0;
 #pragma unroll
         for (int i = 0; i < NWI; ++i) {
             const int k = wave + 4 * i;
             unsigned char* dst = k < NWT ? lds + WOFF + slot * W_BYTES + k * 1024 : lds + DUMP;
-            glds16(rw, dst, fw_off[i], (unsigned)t * 64u);
+            glds16(rsW, dst, valid ? fw_off[i] : OOR, valid ? (unsigned)t * 64u : 0u);
         }
     };
 
@@ -349,8 +348,6 @@ __global__ __launch_bounds__(256, 2) void conv1x1_f16_kernel(const ConvHP p) {
     const int m0 = (tile / p.tiles_n) * BM, n0 = (tile % p.tiles_n) * BN;
     const __amdgpu_buffer_rsrc_t rsA = desc(p.x, p.x_total, (long long)m0 * p.Cin * 2);
     const __amdgpu_buffer_rsrc_t rsW = desc(p.w, p.w_total, (long long)n0 * p.Cin * 2);
-    const __amdgpu_buffer_rsrc_t rsA0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, 0, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsW0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, 0, 0x00020000);
 
     unsigned fa_off[NA], fw_off[NWI];
 #pragma unroll
@@ -366,13 +363,13 @@ __global__ __launch_bounds__(256, 2) void conv1x1_f16_kernel(const ConvHP p) {
         fw_off[i] = (k < NWT && n0 + nrel < p.N) ? (unsigned)nrel * (unsigned)(p.Cin * 2) + c * 16u : OOR;
     }
     auto issue = [&](int t, int slot, bool valid) {              // K chunk t = channels [32 t, 32 t + 32) of both operands
-        const __amdgpu_buffer_rsrc_t ra = valid ? rsA : rsA0, rw = valid ? rsW : rsW0;
+        const unsigned so = valid ? (unsigned)t * 64u : 0u;      // a chunk past K: out of range by lane (voffset = OOR), zero scalar offset
 #pragma unroll
-        for (int i = 0; i < NA; ++i) glds16(ra, lds + slot * SLOT + (wave + 4 * i) * 1024, fa_off[i], (unsigned)t * 64u);
+        for (int i = 0; i < NA; ++i) glds16(rsA, lds + slot * SLOT + (wave + 4 * i) * 1024, valid ? fa_off[i] : OOR, so);
 #pragma unroll
         for (int i = 0; i < NWI; ++i) {
             const int k = wave + 4 * i;
-            glds16(rw, k < NWT ? lds + slot * SLOT + A_BYTES + k * 1024 : lds + DUMP, fw_off[i], (unsigned)t * 64u);
+            glds16(rsW, k < NWT ? lds + slot * SLOT + A_BYTES + k * 1024 : lds + DUMP, valid ? fw_off[i] : OOR, so);
         }
     };
     int faddr[TM], waddr[TN];

@@ -14,6 +14,10 @@ from ._lib import check, ptr, require_cuda, stream
 ACT_NONE, ACT_RELU, ACT_QUICKGELU = 0, 1, 2
 
 
+class DbmmUnsupported(_lib.DbmmError):
+    """a wrapper's C entry answered DBMM_E_UNSUPPORTED (no kernel for this valid request)"""
+
+
 def set_option(name, value):
     """library option by name (include/dbmm.h dbmm_set_option; names in csrc/options.hip); returns the previous value"""
     old = get_option(name)
@@ -541,6 +545,24 @@ def text_colnorm(text):
     return tn
 
 
+def l2norm_rows(x):
+    """x / x.norm(dim=1, keepdim=True) for fp32 [B, D] (CLIP.forward, clip/model.py:362-363)"""
+    require_cuda(x)
+    _f32c(x)
+    y = _empty(tuple(x.shape), device=x.device, dtype=torch.float32)
+    check(_lib.lib().dbmm_l2norm_rows(ptr(x), ptr(y), x.shape[0], x.shape[1], stream()), "l2norm_rows")
+    return y
+
+
+def colsum(x):
+    """x.sum(0) of fp32 [B, N] (N % 4 == 0) in a fixed order"""
+    require_cuda(x)
+    _f32c(x)
+    out = _empty((x.shape[1],), device=x.device, dtype=torch.float32)
+    check(_lib.lib().dbmm_colsum(ptr(x), ptr(out), x.shape[0], x.shape[1], stream()), "colsum")
+    return out
+
+
 def l2norm_sim_ce_fwd(z, tn, temperature, labels=None, z_old=None, ebd_weight=0.5, want_loss=True, want_pred=False):
     require_cuda(z, tn)
     _f32c(z)
@@ -807,10 +829,10 @@ def conv1x1_f16(x, w, scale, bias, residual=None, act=ACT_RELU):
                   2 * (M * Cin + Cout * Cin + M * Cout * (2 if residual is not None else 1)))
     t.__enter__()
     rc = _lib.lib().dbmm_conv1x1_bn_act_f16(ptr(x), ptr(w), ptr(scale), ptr(bias), ptr(residual), ptr(y), M, Cin, Cout, act, stream())
+    t.__exit__(None if rc == 0 else DbmmUnsupported, None, None)      # nothing is recorded for a launch that did not happen
     if rc == _lib.E_UNSUPPORTED:
         return None
     check(rc, "conv1x1_bn_act_f16")
-    t.__exit__(None, None, None)
     return y
 
 
@@ -826,10 +848,10 @@ def conv3x3_f16(x, w, scale, bias, pool=1):
     t = _TimedTag(f"conv3x3_f16_kernel<{geo}, {int(pool == 2)}>", 2.0 * B * H * W * Cout * 9 * Cin, 2 * (x.numel() + y.numel() + w.numel()))
     t.__enter__()
     rc = _lib.lib().dbmm_conv3x3_bn_relu_f16(ptr(x), ptr(w), ptr(scale), ptr(bias), ptr(y), B, H, W, Cin, Cout, 2 if pool == 2 else 0, stream())
+    t.__exit__(None if rc == 0 else DbmmUnsupported, None, None)
     if rc == _lib.E_UNSUPPORTED:
         return None
     check(rc, "conv3x3_bn_relu_f16")
-    t.__exit__(None, None, None)
     return y
 
 

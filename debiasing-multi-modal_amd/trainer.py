@@ -123,12 +123,8 @@ def validate(table, classifier, batch_size, train_group_ratio, target="class", i
     for idx in _epoch_batches(n, batch_size, False, indices):
         idx = idx.to(dev, non_blocking=True)
         emb, labels, groups = table.batch(idx, target)
-        if spurious:
-            logits = classifier.forward_spurious(emb)
-            loss_sum += torch.nn.functional.cross_entropy(logits, labels, reduction="sum").double()
-        else:
-            _, logits, rows = classifier.loss(emb, labels)           # fused normalise + logits + CE kernel
-            loss_sum += rows.double().sum()
+        _, logits, rows = classifier.loss(emb, labels, spurious=spurious)   # fused normalise + logits + CE kernel
+        loss_sum += rows.double().sum()
         adapter.group_counts(logits, labels, groups, table.n_groups, counts)
     c = counts.cpu().numpy()
     res = _results(c, table.n_places)

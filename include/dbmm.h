@@ -428,6 +428,12 @@ int dbmm_adapter_bwd(const float* x, const float* dz, const float* h, const floa
                      float* dw2, float* db2, int64_t B, int64_t D, int64_t H, void* workspace,
                      size_t workspace_bytes, void* stream);
 
+/* y[B][D] = x / ||x||_row, no epsilon (CLIP.forward, clip/model.py:362-363).  D % 4 == 0. */
+int dbmm_l2norm_rows(const float* x, float* y, int64_t B, int64_t D, void* stream);
+
+/* out[N] = sum over the B rows of x[B][N] in a fixed order (bias gradient of LinearClassifier, final_main.py:43-49).  N % 4 == 0. */
+int dbmm_colsum(const float* x, float* out, int64_t B, int64_t N, void* stream);
+
 /* tn[C][D] = (text[D][C] / ||text[:,c]||)^T  (final_main.py:77, column normalisation) */
 int dbmm_text_colnorm(const float* text, float* tn, int64_t D, int64_t C, void* stream);
 
