@@ -230,3 +230,27 @@ def labels(seed, batch):
 def text_matrix(seed, dim, n_cls, name="text"):
     """[D, C] text feature matrix (column = prompt), un-normalised like the JSON files."""
     return normal(seed, name, (dim, n_cls))
+
+
+def embedding_dataset(seed, split, n, dim=1024, p_y=0.25, p_agree=0.85, noise=0.5, s_class=0.025, s_spur=0.045):
+    """(embeddings [n, dim] fp32, y [n], confounder [n]) of one split of a synthetic Waterbirds / CelebA-like embedding set: a class
+    direction and a STRONGER spurious direction (shared by all splits of a seed) under isotropic noise, y ~ Bernoulli(p_y), the
+    confounder agrees with y w.p. p_agree -- so that ERM leans on the spurious direction and the minority groups are the hard ones."""
+    u_y, u_c = normal(seed, "dir_class", (dim,)), normal(seed, "dir_spur", (dim,))
+    y = (uniform(seed, split + "/y", (n,)) < p_y).long()
+    c = (y ^ (uniform(seed, split + "/flip", (n,)) < 1.0 - p_agree).long()).long()
+    x = noise * normal(seed, split + "/noise", (n, dim)) + 0.1 * normal(seed, "common", (1, dim))
+    x = x + s_class * (2 * y.float().unsqueeze(1) - 1) * u_y + s_spur * (2 * c.float().unsqueeze(1) - 1) * u_c
+    return x.contiguous(), y, c
+
+
+def embedding_text(seed, dim=1024, spread=0.6):
+    """prompt matrices for embedding_dataset: (class [dim, 2], spurious [dim, 2], group [dim, 4]); a column = common part + its
+    attribute's direction(s) + its own noise"""
+    u_y, u_c = normal(seed, "dir_class", (dim,)), normal(seed, "dir_spur", (dim,))
+    base = normal(seed, "text_common", (dim,))
+    col = lambda nm, sy, sc: base + spread * (sy * u_y + sc * u_c) + 0.3 * normal(seed, "text/" + nm, (dim,))
+    tcls = torch.stack([col("c0", -1, 0), col("c1", 1, 0)], dim=1)
+    tspu = torch.stack([col("s0", 0, -1), col("s1", 0, 1)], dim=1)
+    tgrp = torch.stack([col(f"g{g}", 2 * (g // 2) - 1, 2 * (g % 2) - 1) for g in range(4)], dim=1)
+    return tcls.contiguous(), tspu.contiguous(), tgrp.contiguous()

@@ -501,9 +501,202 @@ def gen_fp16_keys(M):
         json.dump(out, f, indent=0, sort_keys=True)
 
 
+
+# ---------------------------------------------------------------------------------------
+# two-stage training schedule: the reference's OWN driver, train_all_epochs (final_main.py:805-1128)
+# ---------------------------------------------------------------------------------------
+
+TWO_STAGE = dict(seed=21, n_train=2048, n_val=1600, n_test=1024, dim=1024,
+                 argv=["--dataset", "celeba", "--tl_method", "adapter_reg_seq_alter", "--add_adapter", "--balance_val", "--continue_from_best",
+                       "--warm_reg", "--epochs", "8", "--epochs_feature_learning", "3", "--batch_size", "256", "--batch_size_reg", "16",
+                       "--learning_rate", "0.1", "--learning_rate_reg", "0.05", "--lr_decay_epochs", "6,7", "--lr_decay_rate", "0.5",
+                       "--random_seed", "42"])
+
+
+def _synthetic_embedding_module(FM, cfg, scale=1.0, log=None):
+    """A stand-in for data/celeba_embeddings{,_reg}.py (which read the absent CSV / JSON files): the same dataset protocol
+    (data/celeba_embeddings_reg.py:40-84: attributes and the __getitem__ tuple) over synth.embedding_dataset, and the same four loaders
+    as load_celeba_embeddings (:109-131; num_workers = 0) built with the REFERENCE's stratified_split_dataset."""
+    from torch.utils.data import DataLoader, Dataset
+    real = _load_by_path("ref_celeba_embeddings_reg", os.path.join(REF, "data", "celeba_embeddings_reg.py"))
+    sizes = {"train": cfg["n_train"], "val": cfg["n_val"], "test": cfg["n_test"]}
+
+    class CelebaEmbeddings(Dataset):
+        def __init__(self, data_dir=None, split="train", embedding_dir=None, transform=None):
+            x, y, c = synth.embedding_dataset(cfg["seed"], split, sizes[split], cfg["dim"])
+            self.split, self.x = split, x * scale
+            self.y_array, self.confounder_array = y.numpy().copy(), c.numpy().copy()
+            self.group_array = (self.y_array * 2 + self.confounder_array).astype("int")
+            self.filename_array = np.array([f"{split}_{i:06d}.jpg" for i in range(len(y))])
+            self.targets, self.targets_group = torch.tensor(self.y_array), torch.tensor(self.group_array)
+            self.targets_spurious = torch.tensor(self.confounder_array)
+            self.n_classes, self.n_groups, self.n_places = 2, 4, 2
+            self.group_counts = (torch.arange(self.n_groups).unsqueeze(1) == torch.from_numpy(self.group_array)).sum(1).float()
+            self.group_ratio = self.group_counts / len(self)
+
+        def __len__(self):
+            return len(self.filename_array)
+
+        def __getitem__(self, idx):
+            if log is not None:
+                log.append((self.split, int(idx)))
+            return self.x[idx], {"class": self.targets[idx], "group": self.targets_group[idx], "spurious": self.targets_spurious[idx],
+                                 "ebd_y_pred": 0}, self.filename_array[idx]
+
+    def load_celeba_embeddings(data_dir, embedding_dir, bs_train=512, bs_val=512, num_workers=0, transform=None):
+        train_loader = DataLoader(CelebaEmbeddings(split="train"), batch_size=bs_train, shuffle=True)
+        reg_set, val_set = real.stratified_split_dataset(CelebaEmbeddings(split="val"), test_size=0.5)
+        return (train_loader, DataLoader(reg_set, batch_size=bs_val, shuffle=True), DataLoader(val_set, batch_size=bs_val, shuffle=False),
+                DataLoader(CelebaEmbeddings(split="test"), batch_size=bs_val, shuffle=False))
+
+    def load_celeba_embeddings_plain(data_dir, embedding_dir, bs_train=512, bs_val=512, num_workers=0, transform=None):
+        """data/celeba_embeddings.py's loader (three loaders, no reg split): train_all_epochs builds these first and then replaces
+        them (final_main.py:843-848)"""
+        return (DataLoader(CelebaEmbeddings(split="train"), batch_size=bs_train, shuffle=True),
+                DataLoader(CelebaEmbeddings(split="val"), batch_size=bs_val, shuffle=False),
+                DataLoader(CelebaEmbeddings(split="test"), batch_size=bs_val, shuffle=False))
+
+    mod, plain = types.ModuleType("synthetic_celeba_embeddings_reg"), types.ModuleType("synthetic_celeba_embeddings")
+    mod.CelebaEmbeddings, mod.load_celeba_embeddings = CelebaEmbeddings, load_celeba_embeddings
+    plain.CelebaEmbeddings, plain.load_celeba_embeddings = CelebaEmbeddings, load_celeba_embeddings_plain
+    return mod, plain
+
+
+def run_reference_two_stage(FM, cfg, paths, scale=1.0):
+    """parse_option() + train_all_epochs() of the reference, unmodified, on the synthetic embedding set; its loop functions are wrapped
+    (not replaced) to record what every epoch saw and produced"""
+    log = []
+    mod, plain = _synthetic_embedding_module(FM, cfg, scale, log)
+    saved_mods = {k: sys.modules.get(k) for k in ("data.celeba_embeddings", "data.celeba_embeddings_reg")}
+    sys.modules["data.celeba_embeddings"], sys.modules["data.celeba_embeddings_reg"] = plain, mod
+    import data as _data_pkg                                                       # `from data.x import ...` resolves through sys.modules
+    argv = sys.argv
+    sys.argv = ["final_main.py"] + cfg["argv"] + ["--text_embedding_dir", paths[0], "--text_spurious_embedding_dir", paths[1],
+                                                 "--text_group_embedding_dir", paths[2], "--image_embedding_dir", "/nonexistent/e.json",
+                                                 "--data_dir", "/nonexistent"]
+    rec = {"epochs": [], "inits": [], "lr": []}
+    cur = {}
+    names = ("train_one_epoch", "train_reg_seq_one_epoch", "validate", "validate_zs", "update_dict", "set_model", "set_model_multiple_adapter",
+             "warmup_learning_rate", "warmup_learning_rate_reg", "balance_val")
+    orig = {n: getattr(FM, n) for n in names}
+
+    def phase(kind, fn):
+        def wrapped(*a, **k):
+            cur.clear(); cur.update(kind=kind, counts=np.zeros((4, 2), dtype=np.int64), start=len(log), lr=[])
+            out = fn(*a, **k)
+            loss, acc, gacc = out
+            rec["epochs"].append(dict(kind=kind, label=k.get("print_label", ""), use_group=bool(k.get("use_group", False)),
+                                      target=k.get("target"), loss=float(loss), acc=float(acc), counts=cur["counts"].copy(),
+                                      group_acc={kk: float(v) for kk, v in gacc.items()}, idx=[i for _, i in log[cur["start"]:]],
+                                      split=log[cur["start"]][0] if len(log) > cur["start"] else "", lr=list(cur["lr"])))
+            return out
+        return wrapped
+
+    def update_dict(acc_groups, y, g, logits):
+        cur["counts"] += AO.group_counts(logits.detach(), y, g)
+        return orig["update_dict"](acc_groups, y, g, logits)
+
+    def warm(fn):
+        def wrapped(args, epoch, batch_id, total, optimizer):
+            fn(args, epoch, batch_id, total, optimizer)
+            cur["lr"].append(float(optimizer.param_groups[0]["lr"]))
+        return wrapped
+
+    def model_maker(fn, which):
+        def wrapped(*a, **k):
+            out = fn(*a, **k)
+            m = out[0]
+            ad = m.new_adapter if which == "stage2" else m.adapter
+            rec["inits"].append({kk: v.detach().clone().numpy() for kk, v in ad.state_dict().items()})
+            return out
+        return wrapped
+
+    def balance(fn):
+        def wrapped(loader, opt, print_procedure=False):
+            out = fn(loader, opt, print_procedure)
+            rec.setdefault("balanced", []).append((np.asarray(out.dataset.indices).copy(), int(out.batch_size)))
+            return out
+        return wrapped
+    FM.train_one_epoch = phase("train1", orig["train_one_epoch"])
+    FM.train_reg_seq_one_epoch = phase("train2", orig["train_reg_seq_one_epoch"])
+    FM.validate = phase("validate", orig["validate"])
+    FM.validate_zs = phase("validate_zs", orig["validate_zs"])
+    FM.update_dict = update_dict
+    FM.warmup_learning_rate, FM.warmup_learning_rate_reg = warm(orig["warmup_learning_rate"]), warm(orig["warmup_learning_rate_reg"])
+    FM.set_model, FM.set_model_multiple_adapter = model_maker(orig["set_model"], "stage1"), model_maker(orig["set_model_multiple_adapter"], "stage2")
+    FM.balance_val = balance(orig["balance_val"])
+    try:
+        opt = FM.parse_option()                                                   # set_seed(opt.random_seed) runs in here
+        rec["opt"] = {k: v for k, v in vars(opt).items() if isinstance(v, (int, float, str, bool, list))}
+        import contextlib, io
+        # set_model_multiple_adapter only binds its return value under `if torch.cuda.is_available()` (final_main.py:338-343: the
+        # reference is GPU-only); .cuda() is the identity here (ref_final_main), so answering True keeps everything on the CPU
+        cuda_avail, torch.cuda.is_available = torch.cuda.is_available, (lambda: True)
+        try:
+            with contextlib.redirect_stdout(io.StringIO()):
+                rec["final"] = FM.train_all_epochs(opt)
+        finally:
+            torch.cuda.is_available = cuda_avail
+    finally:
+        sys.argv = argv
+        for n, f in orig.items():
+            setattr(FM, n, f)
+        for k, v in saved_mods.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+    return rec
+
+
+def gen_two_stage(FM):
+    """tests/golden/two_stage.npz: per-epoch (n, correct) counters, losses, accuracies, learning rates, batch index streams, the two
+    adapter initialisations and the final / zero-shot results of the reference's train_all_epochs on the synthetic embedding set, and
+    the same run on embeddings scaled by (1 + 2^-23) -- the reference's own sensitivity to one ulp of its input."""
+    cfg = TWO_STAGE
+    tmp = tempfile.mkdtemp()
+    tcls, tspu, tgrp = synth.embedding_text(cfg["seed"], cfg["dim"])
+    paths = [os.path.join(tmp, n) for n in ("clip_class.json", "clip_spurious.json", "clip_group.json")]
+    _write_text_json(paths[0], tcls, ["c0", "c1"]); _write_text_json(paths[1], tspu, ["s0", "s1"])
+    _write_text_json(paths[2], tgrp, ["g0", "g1", "g2", "g3"])
+    rec = run_reference_two_stage(FM, cfg, paths)
+    pert = run_reference_two_stage(FM, cfg, paths, scale=1.0 + 2.0 ** -23)
+    pert8 = run_reference_two_stage(FM, cfg, paths, scale=1.0 + 2.0 ** -20)       # 8 ulp: the size of an fp32 kernel's rounding differences
+    keys = ["weighted_mean_acc", "worst_acc", "acc_0_0", "acc_0_1", "acc_1_0", "acc_1_1", "mean_acc"]
+    out = {"config": np.array(json.dumps({k: v for k, v in cfg.items()})), "opt": np.array(json.dumps(rec["opt"])),
+           "n_phases": np.int64(len(rec["epochs"])), "acc_keys": np.array(keys)}
+    for i, (e, pe) in enumerate(zip(rec["epochs"], pert["epochs"])):
+        assert e["kind"] == pe["kind"] and e["idx"] == pe["idx"]
+        out[f"p{i}/kind"] = np.array(e["kind"]); out[f"p{i}/label"] = np.array(e["label"]); out[f"p{i}/split"] = np.array(e["split"])
+        out[f"p{i}/use_group"] = np.bool_(e["use_group"]); out[f"p{i}/target"] = np.array(str(e["target"]))
+        out[f"p{i}/loss"] = np.float64(e["loss"]); out[f"p{i}/acc"] = np.float64(e["acc"])
+        out[f"p{i}/counts"] = e["counts"]; out[f"p{i}/counts_1ulp"] = pe["counts"]; out[f"p{i}/loss_1ulp"] = np.float64(pe["loss"])
+        out[f"p{i}/counts_8ulp"] = pert8["epochs"][i]["counts"]; out[f"p{i}/loss_8ulp"] = np.float64(pert8["epochs"][i]["loss"])
+        out[f"p{i}/group_acc"] = np.array([e["group_acc"].get(k, np.nan) for k in keys], dtype=np.float64)
+        out[f"p{i}/group_acc_1ulp"] = np.array([pe["group_acc"].get(k, np.nan) for k in keys], dtype=np.float64)
+        out[f"p{i}/idx"] = np.asarray(e["idx"], dtype=np.int64); out[f"p{i}/lr"] = np.asarray(e["lr"], dtype=np.float64)
+    for i, (bi, bs) in enumerate(rec["balanced"]):
+        out[f"balanced{i}/indices"], out[f"balanced{i}/batch_size"] = bi.astype(np.int64), np.int64(bs)
+    for i, sd in enumerate(rec["inits"]):                                          # both sides draw them from the seeded global RNG:
+        for k, v in sd.items():                                                    # checksums + 256 strided samples pin them
+            out[f"init{i}/{k}_sums"], out[f"init{i}/{k}_sample"] = summary(torch.from_numpy(np.asarray(v)))
+    (btr, bva, bte), (zs, zss) = rec["final"]
+    out["final/best_test"] = np.array([bte[k] for k in keys]); out["final/best_val"] = np.array([bva[k] for k in keys])
+    out["final/zs_class"] = np.array([zs[k] for k in keys]); out["final/zs_spurious"] = np.array([zss[k] for k in keys])
+    (_, _, pte), _ = pert["final"]
+    out["final/best_test_1ulp"] = np.array([pte[k] for k in keys])
+    kinds = [e["kind"] for e in rec["epochs"]]
+    print("[two_stage] phases:", " ".join(k[0] + k[-1] for k in kinds))
+    for i, e in enumerate(rec["epochs"]):
+        d = (np.abs(e["counts"] - pert["epochs"][i]["counts"]).max(), np.abs(e["counts"] - pert8["epochs"][i]["counts"]).max())
+        print(f"[two_stage] p{i:02d} {e['kind']:11s} n={e['counts'][:, 0].sum():5d} loss {e['loss']:.4f} acc {e['acc']:.4f} worst "
+              f"{e['group_acc'].get('worst_acc', float('nan')):.4f}  group correct {e['counts'][:, 1].tolist()}  |1 / 8 ulp count diff| {d}")
+    np.savez_compressed(os.path.join(GOLD, "two_stage.npz"), **out)
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
-    which_all = ["clip", "clip_vitl", "clip_f16", "tokens", "adapter", "adapter_vit", "indices", "ckpt", "fp16keys", "split", "lr"]
+    which_all = ["clip", "clip_vitl", "clip_f16", "tokens", "adapter", "adapter_vit", "indices", "ckpt", "fp16keys", "split", "lr", "two_stage"]
     which = [a for a in sys.argv[1:] if a in which_all] or ["clip", "clip_f16", "tokens", "adapter", "adapter_vit", "indices", "ckpt",
                                                               "fp16keys", "split", "lr"]
     if "fp16keys" in which:
@@ -520,8 +713,10 @@ if __name__ == "__main__":
         gen_lr()
     if "tokens" in which:
         gen_tokens()
-    if "adapter" in which or "indices" in which or "adapter_vit" in which:
+    if "adapter" in which or "indices" in which or "adapter_vit" in which or "two_stage" in which:
         FM = ref_final_main()
+        if "two_stage" in which:                  # the reference's own train_all_epochs on a synthetic embedding set
+            gen_two_stage(FM)
         if "adapter" in which:
             gen_adapter(FM)
         if "adapter_vit" in which:                # BASELINE configs[3] / [4] adapter widths and global batches
