@@ -600,8 +600,8 @@ def main():
             legs["rn50_f16_bs1024"] = extra_leg("RN50", "f16", 1024, 4, 1, dev, "the metric's batch in the reference's GPU-path arithmetic")
             legs["vit_b32_f32_bs512"] = extra_leg("ViT-B/32", "f32", 512, 4, 1, dev, "one GPU's share of BASELINE configs[3], parity mode")
             legs["vit_b32_f16_bs512"] = extra_leg("ViT-B/32", "f16", 512, 4, 1, dev, "one GPU's share of BASELINE configs[3], fp16 mode")
-            legs["vit_l14_336_f16_bs256"] = extra_leg("ViT-L/14@336px", "f16", 256, 2, 1, dev,
-                                                      "BASELINE configs[4]'s tower and arithmetic, a quarter of one GPU's 1024-image share")
+            legs["vit_l14_336_f16_bs1024"] = extra_leg("ViT-L/14@336px", "f16", 1024, 2, 1, dev,
+                                                       "one GPU's share of BASELINE configs[4] (tests/test_gpu_config_sizes.py runs this size)")
             legs["rn50_from_uint8_bs1024"] = from_uint8_leg(dev)
             legs["tail_bs8192_d768"] = tail_leg(8192, 768, dev)
             legs["adapter_only_bs8192_d768"] = adapter_only_leg(8192, 768, dev, steps=50, warmup=5)
