@@ -65,6 +65,62 @@ def save(path, embeddings, y, confounder, group, split, y_pred, filenames, datas
     return path
 
 
+class Writer:
+    """Incremental writer of a store file of KNOWN length (extract.Extractor: rows arrive batch by batch in file order).  The numeric
+    arrays are memory-mapped at their final offsets and filled in place; the file names (unknown total size) go behind them at
+    close(), then the header is written and the file is renamed into place.  Same format as save()."""
+
+    def __init__(self, path, n, dim, dataset="celeba"):
+        self.path, self.tmp, self.n, self.dim, self.dataset = path, path + ".tmp", int(n), int(dim), dataset
+        self.header = {"version": 1, "dataset": dataset, "n": self.n, "dim": self.dim, "arrays": {}}
+        off = 0
+        spec = [("embedding", "float32", (self.n, self.dim))] + [(k, "int64", (self.n,)) for k in _INT_FIELDS] + \
+            [("name_offsets", "int64", (self.n + 1,))]
+        for k, dt, shape in spec:
+            off = _align(off, 64)
+            self.header["arrays"][k] = {"dtype": dt, "shape": list(shape), "offset": off}
+            off += int(np.prod(shape)) * np.dtype(dt).itemsize
+        self._blob_off = _align(off, 64)
+        self._data_start = 4096                                # the header of a store is a few hundred bytes whatever n is
+        with open(self.tmp, "wb") as f:
+            f.truncate(self._data_start + self._blob_off)
+        self._arr = {k: np.memmap(self.tmp, dtype=dt, mode="r+", offset=self._data_start + self.header["arrays"][k]["offset"], shape=shape)
+                     for k, dt, shape in spec if int(np.prod(shape)) > 0}
+        self._names, self._row = [], 0
+
+    def append(self, embeddings, y, confounder, group, split, y_pred, filenames):
+        b = len(filenames)
+        if self._row + b > self.n:
+            raise ValueError(f"store.Writer: {self._row + b} rows for a store of {self.n}")
+        r = slice(self._row, self._row + b)
+        self._arr["embedding"][r] = np.asarray(embeddings, dtype=np.float32).reshape(b, self.dim)
+        for k, v in (("y", y), ("confounder", confounder), ("group", group), ("split", split), ("y_pred", y_pred)):
+            self._arr[k][r] = np.asarray(v, dtype=np.int64).reshape(b)
+        self._names += list(filenames)
+        self._row += b
+
+    def close(self):
+        if self._row != self.n:
+            raise ValueError(f"store.Writer: closed after {self._row} of {self.n} rows")
+        blobs = [f.encode("utf-8") for f in self._names]
+        if self.n:
+            self._arr["name_offsets"][:] = np.cumsum([0] + [len(b) for b in blobs])
+        for a in self._arr.values():
+            a.flush()
+        self._arr = {}
+        blob = b"".join(blobs)
+        self.header["arrays"]["name_blob"] = {"dtype": "uint8", "shape": [len(blob)], "offset": self._blob_off}
+        hj = json.dumps(self.header).encode("utf-8")
+        if len(MAGIC) + 8 + len(hj) > self._data_start:
+            raise ValueError("store header too large")
+        with open(self.tmp, "r+b") as f:
+            f.write(MAGIC); f.write(np.uint64(len(hj)).tobytes()); f.write(hj)
+            f.seek(self._data_start + self._blob_off)
+            f.write(blob)
+        os.replace(self.tmp, self.path)
+        return self.path
+
+
 class Store:
     """memory-mapped view of a store file"""
 

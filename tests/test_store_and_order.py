@@ -76,3 +76,42 @@ def test_dataloader_shuffle_order_matches_torch():
     e1 = [int(i) for b in dl for i in b]; e2 = [int(i) for b in dl for i in b]
     torch.manual_seed(7)
     assert trainer.dataloader_shuffle_order(50).tolist() == e1 and trainer.dataloader_shuffle_order(50).tolist() == e2
+
+
+def test_incremental_writer_equals_save(tmp_path):
+    """store.Writer (rows appended batch by batch by extract.Extractor) produces the file store.save writes, and the same JSON text"""
+    n, D = 53, 32
+    emb = synth.normal(3, "e", (n, D))
+    y, c, g = synth.labels(4, n)
+    split, pred = torch.arange(n) % 3, (y + 1) % 2
+    names = [f"img_{i:05d}.jpg" for i in range(n)]
+    a = store.save(str(tmp_path / "a.emb"), emb.numpy(), y.numpy(), c.numpy(), g.numpy(), split.numpy(), pred.numpy(), names, "celeba")
+    w = store.Writer(str(tmp_path / "b.emb"), n, D, "celeba")
+    for lo in range(0, n, 16):
+        hi = min(n, lo + 16)
+        w.append(emb[lo:hi].numpy(), y[lo:hi], c[lo:hi], g[lo:hi], split[lo:hi], pred[lo:hi], names[lo:hi])
+    w.close()
+    A, B = store.load(a), store.load(str(tmp_path / "b.emb"))
+    assert np.array_equal(A.embedding, B.embedding) and A.filenames == B.filenames and len(B) == n
+    for f in ("y", "confounder", "group", "split", "y_pred"):
+        assert np.array_equal(getattr(A, f), getattr(B, f))
+    store.export_json(A, str(tmp_path / "a.json")); store.export_json(B, str(tmp_path / "b.json"))
+    assert open(tmp_path / "a.json").read() == open(tmp_path / "b.json").read()
+    w = store.Writer(str(tmp_path / "c.emb"), 4, D)
+    w.append(emb[:2].numpy(), y[:2], c[:2], g[:2], split[:2], pred[:2], names[:2])
+    try:
+        w.close()
+        raise AssertionError("expected ValueError")
+    except ValueError:
+        pass
+    assert not os.path.exists(tmp_path / "c.emb")              # a short store is never renamed into place
+
+
+def test_prompt_templates_are_the_references():
+    """templates.py holds the reference's eight prompts per dataset (fixture: tests/golden/tokens_prompts.json, written from the
+    reference's template modules by oracle/make_golden.py)"""
+    from dbmm_amd import templates
+    from conftest import GOLDEN
+    ref = json.load(open(os.path.join(GOLDEN, "tokens_prompts.json")))
+    ours = [p for ds in ("celeba", "waterbirds") for which in ("class", "spurious", "group") for p in templates.prompts(ds, which)]
+    assert ours == ref[:16]
