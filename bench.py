@@ -122,7 +122,7 @@ def kernel_products(tag):
         return 3                                                  # activation pair x activation pair
     if tag.startswith("mha_mfma_kernel"):
         return 1
-    if tag.startswith(("igemm_halo_kernel<", "bottleneck_chain_kernel<", "conv3x3_c32_kernel<")):
+    if tag.startswith(("igemm_halo_kernel<", "bottleneck_chain_kernel<", "bottleneck_chain8_kernel", "conv3x3_c32_kernel<")):
         return 2                                                  # fp16 pair x one exact weight plane
     if tag.startswith("igemm_x3_kernel<"):
         a = [v.strip() for v in tag[tag.index("<") + 1:tag.rindex(">")].split(",")]
@@ -279,7 +279,7 @@ def roofline_of(prof, steps, step_ms, value, world, arch, pmc):
                                     "frac_of_mfma_roof", "frac_of_hbm_roof", "traffic_over_algorithmic", "mfma_busy",
                                     "hbm_tbps")}
     roof["how"] = ("kernel = largest measured time share among the timed launches (HIP events on the launch stream inside "
-                   "the timed region); achieved = algorithmic bytes (operands read once, outputs written once) or "
+                   f"the timed region, every launch of every {PROFILE_EVERY}th step); achieved = algorithmic bytes (operands read once, outputs written once) or "
                    "2*M*N*K FLOPs / measured time; bound = the larger of bytes/8 TB/s and FLOPs/(2500 TF / partial "
                    "products per fp32 product); traffic / mfma_busy / hbm_tbps from the committed rocprofv3 --pmc passes "
                    + (f"({pmc['file']}, {pmc['dropped_stale']} kernels dropped: sources changed since)" if pmc else "(none match)"))
@@ -303,21 +303,30 @@ DTYPE_DETAIL = {
 }
 
 
+PROFILE_EVERY = 4        # the launches of every 4th timed step are bracketed by HIP events (at least two steps of any run)
+
+
 def timed_steps(stepper, images, y_l, g_l, steps, warmup, barrier, profiling):
+    """-> (seconds for `steps` steps, launch profile, number of steps whose launches were timed)"""
     for _ in range(warmup):
         stepper.step(images, y_l, g_l)
     barrier()
+    stride = max(1, min(PROFILE_EVERY, steps // 2))
+    sampled = 0
     if profiling:
         ops.profile_begin(conv_only=False)
     t0 = time.perf_counter()
-    for _ in range(steps):
+    for i in range(steps):
+        if profiling:
+            ops.profile_sample(i % stride == 0)
+            sampled += i % stride == 0
         loss, logits, emb = stepper.step(images, y_l, g_l)
     barrier()
     dt = time.perf_counter() - t0
     prof = ops.profile_end() if profiling else {}
     if not torch.isfinite(loss).item():
         raise SystemExit("non-finite loss in the timed region")
-    return dt, prof
+    return dt, prof, max(sampled, 1)
 
 
 def extra_leg(arch, dtype, Bl, steps, warmup, dev, note):
@@ -328,9 +337,9 @@ def extra_leg(arch, dtype, Bl, steps, warmup, dev, note):
     if dtype == "f16":
         images = images.half()
     sync = torch.cuda.synchronize
-    dt, prof = timed_steps(stepper, images, y_l, g_l, steps, warmup, sync, True)
+    dt, prof, nprof = timed_steps(stepper, images, y_l, g_l, steps, warmup, sync, True)
     value, step_ms = Bl * steps / dt, dt / steps * 1e3
-    roof = roofline_of(prof, steps, step_ms, value, 1, arch, pmc_table(arch, Bl, dtype))
+    roof = roofline_of(prof, nprof, step_ms, value, 1, arch, pmc_table(arch, Bl, dtype))
     keep = ("kernel", "bound", "achieved", "peak", "unit", "frac", "share_of_step", "launches_per_step", "avg_launch_ms",
             "frac_of_mfma_roof", "frac_of_hbm_roof", "end_to_end_algorithmic_tflops")
     leg = {"config": {"workload": f"CLIP-{arch} {R}px encode_image + adapter({D}-128-{D}) CE/SGD step, {Bl} images on one GPU ({note})",
@@ -380,7 +389,7 @@ def from_uint8_leg(dev, Bl=1024, steps=4, warmup=1, H=218, W=178):
                          "frac": round((Bl * (H * W * 3 + 12 * R * R)) / (e0.elapsed_time(e1) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}
 
 
-def from_host_leg(dev, Bl=1024, n_batches=6, H=218, W=178):
+def from_host_leg(dev, Bl=1024, n_batches=12, H=218, W=178):
     """The stage-1 extraction loop (clip_inference.py:188-271) as the device pipeline of extract.Extractor, fed from HOST memory:
     decoded uint8 218 x 178 images in pinned memory -> side-stream H2D (double buffered) -> device preprocessing -> encode_image ->
     fused zero-shot tail -> minority flags -> one D2H per batch -> rows appended to the binary store.  Reported: images/s of the whole
@@ -402,10 +411,15 @@ def from_host_leg(dev, Bl=1024, n_batches=6, H=218, W=178):
     ex = extract.Extractor(model, Wz, "celeba", max_batch=Bl)
     ex.run(batches(2), os.path.join(d, "warm.emb"), 2 * Bl)
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    ex.run(batches(n_batches), os.path.join(d, "clip.emb"), n_batches * Bl)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+
+    def timed(n):
+        t0 = time.perf_counter()
+        ex.run(batches(n), os.path.join(d, "clip.emb"), n * Bl)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+    n_short = max(2, n_batches // 3)
+    dt_short, dt = timed(n_short), timed(n_batches)
+    steady = (dt - dt_short) / (n_batches - n_short)                  # per batch once the pipeline is full (fill, file creation and close cancel)
     # the same device work on a batch that is already resident (no H2D, no D2H, no store)
     dev_raw = host.to(dev)
     for _ in range(2):
@@ -425,7 +439,10 @@ def from_host_leg(dev, Bl=1024, n_batches=6, H=218, W=178):
                                    f"store, {n_batches} batches of {Bl}", "global_batch": Bl, "batch_per_gpu": Bl},
             "dtype": "f32", "value": round(n_batches * Bl / dt, 2), "unit": "images/sec", "steps": n_batches, "ms_per_step": round(dt / n_batches * 1e3, 3),
             "device_resident_ms_per_step": round(dres / n_batches * 1e3, 3), "device_resident_images_per_sec": round(n_batches * Bl / dres, 2),
-            "exposed_copy_and_store_ms_per_step": round((dt - dres) / n_batches * 1e3, 3),
+            "steady_state_ms_per_step": round(steady * 1e3, 3), "steady_state_images_per_sec": round(Bl / steady, 2),
+            "steady_state_over_device_resident": round(steady / (dres / n_batches), 4),
+            "exposed_copy_and_store_ms_per_step": round((steady - dres / n_batches) * 1e3, 3),
+            "pipeline_fill_and_file_ms": round((dt - steady * n_batches) * 1e3, 3),
             "h2d_bytes_per_step": Bl * H * W * 3, "d2h_bytes_per_step": Bl * (4 * D + 24), "d2h_copies_per_step": 1,
             "store_bytes": size,
             "roofline": {"bound": "mfma", "kernel": "the RN50 tower (see the headline's roofline); the copies ride a side stream",
@@ -583,7 +600,7 @@ def main():
     # every igemm launch of the timed region is bracketed by HIP events (an event pair is ~4 us of stream time:
     # ~60 launches per RN50 step = 0.25 ms of a ~30 ms step); DBMM_BENCH_PROFILE=0 times none
     profiling = os.environ.get("DBMM_BENCH_PROFILE", "1") != "0"
-    dt, prof = timed_steps(stepper, images, y_l, g_l, args.steps, args.warmup, barrier, profiling)
+    dt, prof, nprof = timed_steps(stepper, images, y_l, g_l, args.steps, args.warmup, barrier, profiling)
 
     tmax = torch.tensor([dt], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
     dist_info = None
@@ -605,7 +622,7 @@ def main():
         img_f, y_f, g_f = synthetic_batch(R, Bf, world, rank, dev)
         if args.dtype == "f16":
             img_f = img_f.half()
-        dtf, _ = timed_steps(stepper, img_f, y_f, g_f, args.steps, max(1, args.warmup), barrier, False)
+        dtf, _, _ = timed_steps(stepper, img_f, y_f, g_f, args.steps, max(1, args.warmup), barrier, False)
         tf = torch.tensor([dtf], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tf, op=dist.ReduceOp.MAX)
         fixed = {"config": {"workload": f"global batch {Bf * world} split over {world} GPUs ({Bf} images/GPU)"
@@ -618,7 +635,8 @@ def main():
     if rank == 0:
         value = B * args.steps / dt
         step_ms = dt / args.steps * 1e3
-        roof = roofline_of(prof, args.steps, step_ms, value, world, args.arch, pmc_table(args.arch, Bl, args.dtype))
+        roof = roofline_of(prof, nprof, step_ms, value, world, args.arch, pmc_table(args.arch, Bl, args.dtype))
+        roof["timed_steps"] = nprof
         cfgs = {("RN50", 1, 1024): "the metric's configuration, CLIP-RN50 224px bs=1024 on one GPU",
                 ("RN50", 1, 512): "BASELINE configs[1]", ("RN50", 2, 512): "BASELINE configs[2]",
                 ("RN50", 2, 1024): "the metric's per-GPU batch on 2 GPUs", ("RN50", 4, 1024): "the metric's per-GPU batch on 4 GPUs",

@@ -27,6 +27,7 @@ def sources():
 KERNEL_SOURCES = (
     ("igemm_", ("igemm_f32.hip", "igemm_epilogue.inc", "common.h")),
     ("bottleneck_chain_kernel", ("bottleneck_chain.hip", "common.h")),
+    ("bottleneck_chain8_kernel", ("bottleneck_chain8.hip", "common.h")),
     ("conv3x3_c32_kernel", ("conv_patch.hip", "common.h")),
     ("gemm_pair_8ph_kernel", ("gemm_pair_8ph.hip", "common.h")),
     ("mha_pair_kernel", ("mha_pair.hip", "common.h")),

@@ -603,6 +603,11 @@ __global__ __launch_bounds__(256, 2) void bottleneck_chain_kernel(const ChainP p
 
 }  // namespace
 
+// bottleneck_chain8.hip: the layer-3 geometry (K = P = 256) on eight waves
+int dbmm_chain8_launch(const float* y2, const float* y2_absmax, const void* w3_plane_f16, int w3_exp, const float* scale3,
+                       const float* bias3, const float* residual, float* x_out, float* x_absmax, const void* w1_plane_f16, int w1_exp,
+                       const float* scale1, const float* bias1, float* y1_out, float* y1_absmax, int64_t M, int64_t N, void* stream);
+
 // see include/dbmm.h
 extern "C" int dbmm_bottleneck_block_chain_x2(const float* y1, const float* y1_absmax, const void* w2_plane_f16, int w2_exp,
                                               const float* scale2, const float* bias2, const void* w3_plane_f16, int w3_exp,
@@ -687,6 +692,14 @@ extern "C" int dbmm_bottleneck_chain_x2(const float* y2, const float* y2_absmax,
     const int64_t M = B * Ho * Wo;
     if (M > (INT32_MAX >> 1)) return DBMM_E_SHAPE;
     if (M & 3) return DBMM_E_UNSUPPORTED;               // the kernel validates rows in groups of 4
+    if (K == 256 && P == 256 && !x_pooled && dbmm_opt(OPT_CHAIN8)) {
+        if (w3_exp < -40 || w3_exp > 40 || w1_exp < -40 || w1_exp > 40) return DBMM_E_UNSUPPORTED;
+        if (!dbmm_aligned16(y2) || !dbmm_aligned16(w3_plane_f16) || !dbmm_aligned16(w1_plane_f16) || !dbmm_aligned16(residual) ||
+            !dbmm_aligned16(x_out) || !dbmm_aligned16(y1_out))
+            return DBMM_E_ALIGN;
+        return dbmm_chain8_launch(y2, y2_absmax, w3_plane_f16, w3_exp, scale3, bias3, residual, x_out, x_absmax, w1_plane_f16, w1_exp,
+                                  scale1, bias1, y1_out, y1_absmax, M, N, stream);
+    }
     if ((K != 64 && K != 128) || (N % 64) != 0 || (P != 64 && P != 128)) return DBMM_E_UNSUPPORTED;
     if (w3_exp < -40 || w3_exp > 40 || w1_exp < -40 || w1_exp > 40) return DBMM_E_UNSUPPORTED;
     if (x_pooled && ((Ho & 1) || (Wo & 1))) return DBMM_E_UNSUPPORTED;

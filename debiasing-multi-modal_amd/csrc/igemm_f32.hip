@@ -1728,6 +1728,27 @@ int conv_impl(const float* x, const float* w, const float* bias, const float* re
         // Also measured and not kept (round 3, profiles/r03_pair_stream_ab_layers.log): an LDS-DMA streaming variant (fp32 A tile by
         // DMA into a 3-slot ring, split into (hi, lo) when the fragments are read): 7 - 34 % SLOWER on every layer-2/3/4 shape
         // at B = 1024 -- the split then runs once per wave column and N tile instead of once per tile, on fp32 fragment reads.
+        {
+            // The deep-pipelined 256 x 256 kernel (gemm_pair_8ph.hip) where it measured ahead of the 128 x 128 tile on the RN50 shapes at
+            // B = 1024 (same box, profiles/r04_ab_1x1_8ph.log): long K into <= 512 channels -- layer 3's first conv1 (M 802,816, K 512,
+            // N 256) 0.635 -> 0.530 ms, layer 4's conv1s (K 1024 / 2048, N 512) 0.535 -> 0.467 and 0.262 -> 0.239 ms.  It loses on the
+            // K <= 256 conv3 shapes (8 K tiles: the tile is prologue and epilogue; 0.399 -> 0.428 ms) and where 256-row tiles quantise
+            // badly over the 256 CUs (layer 3's conv1: 784 tiles = 3.06 per CU, 0.287 -> 0.306 ms).
+            // conv1x1_8ph = 0 never, 1 (default) by that rule, 2 wherever the kernel applies.
+            const int m8 = dbmm_opt(OPT_CONV1X1_8PH);
+            const long long t8 = ((M + 255) / 256) * (Cout / 256);
+            const bool pays = m8 == 2 || (m8 == 1 && Cin >= 512 && Cout <= 512 && (Cout == 512 || t8 >= 8 * NUM_CUS));
+            if (pays && p.wh && p.nw == 1 && p.a_absmax && !p.pool2 && (Cout % 256) == 0 && (Cin % 64) == 0 && M >= 16384 && p.wh_bytes &&
+                dbmm_aligned16(y) && (!residual || dbmm_aligned16(residual)) && 256 * (Cin > Cout ? Cin : Cout) * 4 < 0x7FFFFFF0LL) {
+                const int rc = dbmm_gemm_pair_8ph(x, Cin, sx.a_absmax, p.wh, p.w_exp, K, sx.oscale, bias, residual, Cout, y, Cout, sx.absmax_out,
+                                                  M, Cout, K, 1.f, act, stream);
+                if (rc == DBMM_OK) {
+                    const int cfg[11] = {256, 256, 2, 4, 0, 0, 32, 1, 6, 0, 1};      // [8] = 6: gemm_pair_8ph_kernel
+                    for (int i = 0; i < 11; ++i) g_last_cfg[i] = cfg[i];
+                }
+                if (rc != DBMM_E_UNSUPPORTED) return rc;
+            }
+        }
         return launch_modes<0, 0>(p, s, 1, ws, wsb);
     }
     {

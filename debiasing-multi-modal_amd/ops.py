@@ -38,14 +38,22 @@ _empty = torch.empty
 # ---- optional per-launch timing of the MFMA kernel family (bench.py roofline leg) ----------
 _prof = None
 _prof_conv_only = False
+_prof_paused = False
 
 
 def profile_begin(conv_only=False):
     """start collecting (kernel tag, flops, start event, end event) for every igemm launch --
     with conv_only, just the KxK convolutions (the event pairs are stream work themselves, ~4 us
     per launch, so a bench that only needs the dominant kernel should not pay for all)."""
-    global _prof, _prof_conv_only
-    _prof, _prof_conv_only = [], bool(conv_only)
+    global _prof, _prof_conv_only, _prof_paused
+    _prof, _prof_conv_only, _prof_paused = [], bool(conv_only), False
+
+
+def profile_sample(on):
+    """inside a profile_begin() ... profile_end() window: switch the per-launch events off / on again (bench.py times the launches of
+    every k-th step only: an event pair is ~4 us of stream time, ~60 launches per RN50 step)"""
+    global _prof_paused
+    _prof_paused = not on
 
 
 def profile_end():
@@ -84,7 +92,7 @@ class _Timed:
         self.nbytes = float(nbytes)
 
     def __enter__(self):
-        self.on = _prof is not None and (self.args[3] == 1 or not _prof_conv_only)
+        self.on = _prof is not None and not _prof_paused and (self.args[3] == 1 or not _prof_conv_only)
         if self.on:
             self.e0 = torch.cuda.Event(enable_timing=True)
             self.e0.record()
@@ -338,7 +346,10 @@ def bottleneck_chain(y2, y2_absmax, c3, residual, c1, x_absmax=None, y1_absmax=N
     N, P = c3["ph"].shape[1], c1["ph"].shape[1]
     if c3["ph"].shape[0] != 1 or c1["ph"].shape[0] != 1 or tuple(residual.shape) != (B, H, W, N):
         return None
-    if K not in (64, 128) or N % 64 or P not in (64, 128) or (pooled and (H % 2 or W % 2)):     # shapes the library serves
+    chain8 = K == 256 and P == 256 and not pooled and get_option("chain8")       # the layer-3 geometry: eight-wave kernel
+    if not chain8 and (K not in (64, 128) or P not in (64, 128)):                 # shapes the library serves
+        return None
+    if N % 64 or (pooled and (H % 2 or W % 2)):
         return None
     dev = y2.device
     x = _empty((B, H, W, N), device=dev, dtype=torch.float32)
@@ -347,7 +358,7 @@ def bottleneck_chain(y2, y2_absmax, c3, residual, c1, x_absmax=None, y1_absmax=N
     M = B * H * W
     # tagged like an igemm launch for bench.py's per-kernel table: FLOPs of both GEMMs, algorithmic bytes
     global _chain_tag
-    _chain_tag = f"bottleneck_chain_kernel<{K}, {P}, {int(pooled)}, 0>"
+    _chain_tag = "bottleneck_chain8_kernel" if chain8 else f"bottleneck_chain_kernel<{K}, {P}, {int(pooled)}, 0>"
     t = _Timed(M, N, K + P, -1, 0, 4 * (M * K + 2 * M * N + M * P + (M // 4 * N if pooled else 0)) + 2 * (N * K + P * N))
     t.__enter__()
     rc = _lib.lib().dbmm_bottleneck_chain_x2(ptr(y2), ptr(y2_absmax), ptr(c3["ph"]), int(c3["we"]), ptr(c3["sc"]), ptr(c3["b"]),
@@ -887,7 +898,7 @@ class _TimedTag:
         self.tag, self.flops, self.nbytes = tag, float(flops), float(nbytes)
 
     def __enter__(self):
-        self.on = _prof is not None and not _prof_conv_only
+        self.on = _prof is not None and not _prof_paused and not _prof_conv_only
         if self.on:
             self.e0 = torch.cuda.Event(enable_timing=True)
             self.e0.record()

@@ -59,6 +59,30 @@ def test_rn50_bs1024_one_call_rows_vs_golden_and_small_batch(golden):
     assert not any(t.startswith("igemm_f32_kernel<") and prof[t][1] > 1e12 for t in tags), sorted(tags)    # no fp32 fallback on a conv
 
 
+def test_chain8_on_operands_over_2gib(option):
+    """layer-3 geometry: x / x' are [B,14,14,1024] fp32 = 802,816 B per image, > 2 GiB from B = 2675; the eight-wave chain at B = 2800:
+    first image, the images around the 2 GiB line and the last one against fp64"""
+    option("chain8", 1)
+    B, H, K, N, P = 2800, 14, 256, 1024, 256
+    HW = H * H
+    g = torch.Generator(device=DEV); g.manual_seed(13)
+    rn = lambda *sh: torch.randn(sh, device=DEV, generator=g)
+    c3 = _entry((rn(N, K) * K ** -0.5).half().float(), g); c1 = _entry((rn(P, N) * N ** -0.5).half().float(), g)
+    y2 = torch.relu(rn(B, H, H, K)); res = torch.relu(rn(B, H, H, N) * 2.0)
+    assert res.numel() * 4 > 2 ** 31
+    xam, yam = torch.zeros(1, device=DEV), torch.zeros(1, device=DEV)
+    r = ops.bottleneck_chain(y2, (y2.abs().max() * 1.1).reshape(1), c3, res, c1, xam, yam)
+    assert r is not None and ops._chain_tag == "bottleneck_chain8_kernel"
+    x, y1 = r
+    s = 2 ** 31 // (HW * N * 4)
+    for i in (0, s - 1, s, s + 1, B - 1):
+        xr = torch.relu(y2[i].view(HW, K).double() @ c3["w"].double().t() * c3["sc"].double() + c3["b"].double() + res[i].view(HW, N).double())
+        yr = torch.relu(xr @ c1["w"].double().t() * c1["sc"].double() + c1["b"].double())
+        assert relerr(x[i].view(HW, N).double().cpu(), xr.cpu()) < 5e-6, i
+        assert relerr(y1[i].view(HW, P).double().cpu(), yr.cpu()) < 5e-6, i
+    assert xam.item() == x.abs().max().item() and yam.item() == y1.abs().max().item()
+
+
 def _entry(w, g, bias_std=0.1):
     n = w.shape[0]
     ph, we, k = ops.split_planes_f16(w, allow_single=True)
@@ -193,7 +217,7 @@ def guarded(monkeypatch):
 
 
 @pytest.mark.parametrize("tail", [5, 77])
-def test_ragged_tiles_do_not_write_outside_their_outputs(tail, guarded):
+def test_ragged_tiles_do_not_write_outside_their_outputs(tail, guarded, option):
     g = torch.Generator(device=DEV); g.manual_seed(tail)
     rn = lambda *sh: torch.randn(sh, device=DEV, generator=g)
     # --- fp16-pair igemm, direct epilogue (ViT shapes: ragged M on every launch), with and without a residual
@@ -252,6 +276,14 @@ def test_ragged_tiles_do_not_write_outside_their_outputs(tail, guarded):
     r_ = ops.bottleneck_block_chain(y2, y2.abs().max().reshape(1), c2, c3, c1, residual=res, x_absmax=torch.zeros(1, device=DEV),
                                     y1n_absmax=torch.zeros(1, device=DEV))
     assert r_ is not None
+    # ... and the eight-wave chain of the layer-3 geometry (K = P = 256)
+    option("chain8", 1)
+    y2b = torch.relu(rn(1, Hh, Ww, 256)); resb = torch.relu(rn(1, Hh, Ww, 128))
+    c3b, c1b = _entry((rn(128, 256) * 0.0625).half().float(), g), _entry((rn(256, 128) * 128 ** -0.5).half().float(), g)
+    r_ = ops.bottleneck_chain(y2b, y2b.abs().max().reshape(1), c3b, resb, c1b, torch.zeros(1, device=DEV), torch.zeros(1, device=DEV))
+    assert r_ is not None and ops._chain_tag == "bottleneck_chain8_kernel"
+    xr = torch.relu(y2b.view(Mc, 256).double() @ c3b["w"].double().t() * c3b["sc"].double() + c3b["b"].double() + resb.view(Mc, 128).double())
+    assert relerr(r_[0].view(Mc, 128).double().cpu(), xr.cpu()) < 5e-6
     # --- stem convs: stride-2 MFMA gather kernel and the 32-channel patch kernels
     x = rn(3, 3, 64, 64)
     wst = (rn(3, 3, 3, 32) * 0.2)

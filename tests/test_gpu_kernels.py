@@ -926,12 +926,18 @@ def test_operands_over_2gib_stay_on_the_split_kernels(option):
                                                 (5, 6, 10, 64, 192, 128, True), (1, 2, 2, 64, 64, 64, True), (40, 56, 56, 64, 256, 64, True),
                                                 (3, 10, 14, 64, 128, 128, False), (16, 28, 28, 128, 512, 128, False),
                                                 (9, 28, 28, 128, 512, 128, True), (3, 10, 14, 128, 256, 64, False),
-                                                (2, 6, 6, 128, 64, 64, True)])
-def test_bottleneck_chain_conv3_residual_then_next_conv1(B, H, W, K, N, P, pooled):
+                                                (2, 6, 6, 128, 64, 64, True),
+                                                # layer-3 geometry (K = P = 256): the eight-wave kernel of bottleneck_chain8.hip
+                                                (64, 14, 14, 256, 1024, 256, False), (3, 10, 14, 256, 128, 256, False),
+                                                (1, 2, 2, 256, 64, 256, False), (5, 6, 10, 256, 192, 256, False),
+                                                (300, 14, 14, 256, 1024, 256, False)])
+def test_bottleneck_chain_conv3_residual_then_next_conv1(B, H, W, K, N, P, pooled, option):
     """relu(bn3(conv3(y2)) + x) and the NEXT block's relu(bn1(conv1(.))) as one launch (clip/model.py:42-55 twice) ==
     fp64, and == the two separate fp32-accurate launches; optional 2x2-pooled copy == avg-pool of the written x';
-    maxima == the written tensors' maxima.  Shapes: layer-1 and layer-2 geometry (K = 64 / 128), ragged M (not a
-    multiple of 128), one window."""
+    maxima == the written tensors' maxima.  Shapes: layer-1 / layer-2 / layer-3 geometry (K = 64 / 128 / 256), ragged M (not a
+    multiple of 128), one window, more tiles than workgroup slots (B = 300 at K = 256: 460 tiles over 256 CUs)."""
+    if K == 256:
+        option("chain8", 1)                                           # (off by default: measured no faster than the two launches)
     g = torch.Generator(device=DEV); g.manual_seed(B * 1000 + N + P)
     y2 = torch.relu(torch.randn((B, H, W, K), device=DEV, generator=g))
     res = torch.relu(torch.randn((B, H, W, N), device=DEV, generator=g) * 3.0)
@@ -971,7 +977,9 @@ def test_bottleneck_chain_reports_unsupported_shapes():
         ph, we, _ = ops.split_planes_f16(w, allow_single=True)
         return dict(w=w, ph=ph, we=we, sc=torch.ones(w.shape[0], device=DEV), b=torch.zeros(w.shape[0], device=DEV))
     y = torch.rand((2, 4, 4, 256), device=DEV); res = torch.rand((2, 4, 4, 1024), device=DEV)
-    assert ops.bottleneck_chain(y, y.max().reshape(1), entry(mk(1024, 256)), res, entry(mk(128, 1024))) is None    # K = 256
+    assert ops.bottleneck_chain(y, y.max().reshape(1), entry(mk(1024, 256)), res, entry(mk(128, 1024))) is None    # K = 256, P = 128
+    y = torch.rand((2, 4, 4, 512), device=DEV); res = torch.rand((2, 4, 4, 2048), device=DEV)
+    assert ops.bottleneck_chain(y, y.max().reshape(1), entry(mk(2048, 512)), res, entry(mk(512, 2048))) is None    # K = 512 (layer 4)
     y = torch.rand((2, 4, 4, 64), device=DEV); res = torch.rand((2, 4, 4, 256), device=DEV)
     assert ops.bottleneck_chain(y, y.max().reshape(1), entry(mk(256, 64)), res, entry(mk(256, 256))) is None        # P = 256
     y = torch.rand((1, 3, 3, 64), device=DEV); res = torch.rand((1, 3, 3, 256), device=DEV)

@@ -37,12 +37,17 @@ def main():
     ap.add_argument("--iters", type=int, default=8)
     ap.add_argument("--filter", default="")
     ap.add_argument("--unique", action="store_true", help="time each distinct shape once")
+    ap.add_argument("--opt", action="append", default=[], help="library option name=value (dbmm_set_option), repeatable")
+    ap.add_argument("--k", type=int, default=0, help="only convs with this kernel size (1 | 3)")
     a = ap.parse_args()
+    for o in a.opt:
+        n, v = o.split("=")
+        ops.set_option(n, int(v))
     dev = "cuda"
     seen, rows = {}, []
     tot_ms = tot_fl = 0.0
     for name, H, Cin, Cout, k, res in rn50_layers(a.batch):
-        if a.filter and a.filter not in name:
+        if (a.filter and a.filter not in name) or (a.k and k != a.k):
             continue
         key = (H, Cin, Cout, k, res)
         if key in seen:
