@@ -769,23 +769,31 @@ __global__ __launch_bounds__(256) void layernorm_f16_kernel(const u16* __restric
 // ---------------------------------------------------------------------------------------------------------------
 // layout kernels
 // ---------------------------------------------------------------------------------------------------------------
-// patch im2col: NCHW image (fp32 or fp16) -> [B * g * g][Kp] fp16, K = 3 * P * P zero-padded to Kp (a multiple of 64)
-template <typename TI>
+// patch im2col: NCHW image (fp32 or fp16) -> [B * g * g][Kp] fp16, K = 3 * P * P zero-padded to Kp (a multiple of 64).
+// Walks the IMAGE (round 4; the first version walked the output element by element with a div / mod chain and read 4-byte pieces:
+// 0.87 TB/s): a thread takes VEC consecutive pixels of one image row -- consecutive threads read consecutive vectors of that row,
+// P % VEC == 0 keeps a vector inside one patch row -- and writes them as one VEC-half store at (patch, channel, kh, kw).
+template <typename TI, int VEC>
 __global__ __launch_bounds__(256) void im2col_patch_f16_kernel(const TI* __restrict__ x, u16* __restrict__ out, int R, int P, int g,
-                                                               int Kp, long long total) {
-    const int K = 3 * P * P;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int k = (int)(i % Kp);
-        const long long m = i / Kp;
-        _Float16 v = (_Float16)0.f;
-        if (k < K) {
-            const int gx = (int)(m % g), gy = (int)((m / g) % g);
-            const long long b = m / ((long long)g * g);
-            const int kw = k % P, kh = (k / P) % P, c = k / (P * P);
-            v = (_Float16)(float)x[((b * 3 + c) * R + (long long)gy * P + kh) * R + (long long)gx * P + kw];
-        }
-        ((_Float16*)out)[i] = v;
+                                                               int Kp, long long n_vec, long long n_pad) {
+    const int K = 3 * P * P, RV = R / VEC;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_vec; i += (long long)gridDim.x * blockDim.x) {
+        const int xv = (int)(i % RV);
+        const long long row = i / RV;                                     // (b * 3 + c) * R + y
+        const int y = (int)(row % R), c = (int)((row / R) % 3);
+        const long long b = row / (3LL * R);
+        const int x0 = xv * VEC, gx = x0 / P, kw = x0 - gx * P, gy = y / P, kh = y - gy * P;
+        typedef TI vin_t __attribute__((ext_vector_type(VEC)));           // both sides are VEC-element aligned: R, P, Kp are multiples of VEC
+        typedef _Float16 vout_t __attribute__((ext_vector_type(VEC)));
+        const vin_t vi = *(const vin_t*)(x + row * R + x0);
+        vout_t vo;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) vo[j] = (_Float16)(float)vi[j];
+        *(vout_t*)((_Float16*)out + ((b * g + gy) * g + gx) * (long long)Kp + (c * P + kh) * P + kw) = vo;
     }
+    const int pad = Kp - K;                                               // zero columns K .. Kp - 1 (ViT-L/14: 588 -> 640)
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_pad; i += (long long)gridDim.x * blockDim.x)
+        ((_Float16*)out)[(i / pad) * Kp + K + (i % pad)] = (_Float16)0.f;
 }
 
 // class token + patches + positional embedding -> tokens [B][L][W] fp16 (sum in fp32, one rounding)
@@ -948,13 +956,15 @@ extern "C" int dbmm_im2col_patch_f16(const void* x_nchw, int x_is_f16, void* out
     if (!x_nchw || !out) return DBMM_E_ARG;
     if (B <= 0 || R <= 0 || P <= 0 || R % P || Kp < 3 * P * P) return DBMM_E_SHAPE;
     const int g = (int)(R / P);
-    const long long total = (long long)B * g * g * Kp;
-    if (x_is_f16)
-        hipLaunchKernelGGL((im2col_patch_f16_kernel<_Float16>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
-                           (const _Float16*)x_nchw, (u16*)out, (int)R, (int)P, g, (int)Kp, total);
-    else
-        hipLaunchKernelGGL((im2col_patch_f16_kernel<float>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
-                           (const float*)x_nchw, (u16*)out, (int)R, (int)P, g, (int)Kp, total);
+    const int vec = (P % 4 == 0) ? 4 : ((P % 2 == 0) ? 2 : 1);
+    const long long n_vec = (long long)B * 3 * R * (R / vec), n_pad = (long long)B * g * g * (Kp - 3 * P * P);
+    const dim3 grid(grid_for(n_vec));
+    hipStream_t s = (hipStream_t)stream;
+#define DBMM_IM2COL(T, V) hipLaunchKernelGGL((im2col_patch_f16_kernel<T, V>), grid, dim3(256), 0, s, (const T*)x_nchw, (u16*)out, (int)R, \
+                                             (int)P, g, (int)Kp, n_vec, n_pad)
+    if (x_is_f16) { if (vec == 4) DBMM_IM2COL(_Float16, 4); else if (vec == 2) DBMM_IM2COL(_Float16, 2); else DBMM_IM2COL(_Float16, 1); }
+    else { if (vec == 4) DBMM_IM2COL(float, 4); else if (vec == 2) DBMM_IM2COL(float, 2); else DBMM_IM2COL(float, 1); }
+#undef DBMM_IM2COL
     DBMM_CHECK_LAUNCH();
     return DBMM_OK;
 }

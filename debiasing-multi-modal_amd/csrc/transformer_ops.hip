@@ -387,21 +387,26 @@ __global__ __launch_bounds__(256) void embed_gather_kernel(const int32_t* __rest
     }
 }
 
+// walks the IMAGE: a thread takes VEC consecutive pixels of one image row (consecutive threads = consecutive vectors of that row;
+// P % VEC == 0 keeps a vector inside one patch row) and writes them at (patch, channel, kh, kw) -- coalesced reads, VEC-float stores
+template <int VEC>
 __global__ __launch_bounds__(256) void im2col_patch_kernel(const float* __restrict__ x, float* __restrict__ out,
-                                                           int R, int P, int g, long long total,
+                                                           int R, int P, int g, long long n_vec,
                                                            float* __restrict__ out_absmax) {
-    const int K = 3 * P * P;
+    const int K = 3 * P * P, RV = R / VEC;
     float amax = 0.f;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_vec;
          i += (long long)gridDim.x * blockDim.x) {
-        const int k = (int)(i % K);
-        const long long m = i / K;
-        const int gx = (int)(m % g), gy = (int)((m / g) % g);
-        const long long b = m / ((long long)g * g);
-        const int kw = k % P, kh = (k / P) % P, c = k / (P * P);
-        const float v = x[((b * 3 + c) * R + (long long)gy * P + kh) * R + (long long)gx * P + kw];
-        out[i] = v;
-        amax = fmaxf(amax, fabsf(v));
+        const int xv = (int)(i % RV);
+        const long long row = i / RV;                                     // (b * 3 + c) * R + y
+        const int y = (int)(row % R), c = (int)((row / R) % 3);
+        const long long b = row / (3LL * R);
+        const int x0 = xv * VEC, gx = x0 / P, kw = x0 - gx * P, gy = y / P, kh = y - gy * P;
+        typedef float vec_t __attribute__((ext_vector_type(VEC)));        // both sides are VEC-element aligned: R, P and K are multiples of VEC
+        const vec_t v = *(const vec_t*)(x + row * R + x0);
+        *(vec_t*)(out + ((b * g + gy) * g + gx) * (long long)K + (c * P + kh) * P + kw) = v;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) amax = fmaxf(amax, fabsf(v[j]));
     }
     if (out_absmax) {          // scale source of the fp16-pair patch GEMM: one filtered atomic per workgroup
         __shared__ float wmax[4];
@@ -517,9 +522,17 @@ extern "C" int dbmm_im2col_patch(const float* x_nchw, float* out, float* out_abs
     if (!x_nchw || !out) return DBMM_E_ARG;
     if (B <= 0 || R <= 0 || P <= 0 || R % P) return DBMM_E_SHAPE;
     const int64_t g = R / P;
-    const long long total = (long long)B * g * g * 3 * P * P;
-    hipLaunchKernelGGL(im2col_patch_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x_nchw, out,
-                       (int)R, (int)P, (int)g, total, out_absmax);
+    const int vec = (P % 4 == 0) ? 4 : ((P % 2 == 0) ? 2 : 1);
+    const long long n_vec = (long long)B * 3 * R * (R / vec);
+    if (vec == 4)
+        hipLaunchKernelGGL(im2col_patch_kernel<4>, dim3(grid_for(n_vec)), dim3(256), 0, (hipStream_t)stream, x_nchw, out, (int)R, (int)P,
+                           (int)g, n_vec, out_absmax);
+    else if (vec == 2)
+        hipLaunchKernelGGL(im2col_patch_kernel<2>, dim3(grid_for(n_vec)), dim3(256), 0, (hipStream_t)stream, x_nchw, out, (int)R, (int)P,
+                           (int)g, n_vec, out_absmax);
+    else
+        hipLaunchKernelGGL(im2col_patch_kernel<1>, dim3(grid_for(n_vec)), dim3(256), 0, (hipStream_t)stream, x_nchw, out, (int)R, (int)P,
+                           (int)g, n_vec, out_absmax);
     DBMM_CHECK_LAUNCH();
     return DBMM_OK;
 }
