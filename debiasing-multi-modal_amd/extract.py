@@ -16,6 +16,7 @@ target_split), file_name)` with `image` either the float32 [b, 3, R, R] tensor o
 uint8 [b, H, W, 3] of one geometry (CelebA: 218 x 178), which is preprocessed on the device (Pillow-exact, preprocess.py).
 """
 import os
+import time
 
 import numpy as np
 import torch
@@ -60,7 +61,9 @@ class _Slot:
         self.copied = torch.cuda.Event()       # H2D of this slot's input finished (side stream)
         self.consumed = torch.cuda.Event()     # the compute stream no longer reads d_in / d_lab
         self.done = torch.cuda.Event()         # D2H of this slot's results finished (compute stream)
-        self.meta = None
+        self.meta = None                       # (rows, labels, keys) of the batch whose results are in flight
+        self.staged = None                     # the same for the batch staged into h_in / d_in
+        self.early = False
 
 
 class Extractor:
@@ -78,19 +81,27 @@ class Extractor:
         self.max_batch = int(max_batch)
         self.side = torch.cuda.Stream(device=self.dev)
         self._slots = None
-        self.stats = {"batches": 0, "images": 0, "d2h_copies": 0, "h2d_copies": 0}
+        # host seconds spent: staging into pinned memory, waiting for a batch's H2D copy (pinned sources only), enqueuing the device work,
+        # waiting for the previous batch's results, writing rows into the store
+        self.stats = {"batches": 0, "images": 0, "d2h_copies": 0, "h2d_copies": 0, "t_stage": 0.0, "t_h2d_wait": 0.0, "t_enqueue": 0.0,
+                      "t_result_wait": 0.0, "t_store": 0.0}
 
     # ---- device work of one batch (compute stream) --------------------------------------------------------------------
     def _compute(self, slot, b):
         x = slot.d_in[:b]
+        lab = slot.d_lab[:b].clone()                                              # (16 KB) so that the slot's inputs are dead early
         if x.dtype == torch.uint8:
             x = preprocess.preprocess_uniform(x, self.R)                          # Resize(BICUBIC) + CenterCrop + ToTensor + Normalize
+            slot.consumed.record()                                                # the staged batch has been read: the slot may be refilled
+            slot.early = True                                                     # while the encoder runs (H2D two batches ahead)
+        else:
+            slot.early = False
         f = self.model.encode_image(x)                                            # :206
         f32 = f.float().contiguous()
         logits, pred = adapter.zeroshot_tail(f32, self.W, self.temperature)       # :207-216 (argmax of softmax = argmax of logits)
         if self.normalized:                                                       # --normalized: the saved embedding is the unit vector
             f32 = f32 / f32.norm(dim=-1, keepdim=True) if f.dtype == torch.float32 else (f / f.norm(dim=-1, keepdim=True)).float()
-        is_minor, is_minor_pred = adapter.minority_flags(self.dataset, slot.d_lab[:b, 0], slot.d_lab[:b, 1], pred)   # :219-233
+        is_minor, is_minor_pred = adapter.minority_flags(self.dataset, lab[:, 0], lab[:, 1], pred)   # :219-233
         out = slot.d_out[:b * slot.row_bytes]
         nb = 4 * self.D * b
         out[:nb].view(torch.float32).view(b, self.D).copy_(f32)
@@ -102,7 +113,10 @@ class Extractor:
 
     def _drain(self, slot, writer, acc):
         b, targets, names = slot.meta
+        t0 = time.perf_counter()
         slot.done.synchronize()
+        t1 = time.perf_counter()
+        self.stats["t_result_wait"] += t1 - t0
         raw = slot.h_out[:b * slot.row_bytes].numpy()
         emb = raw[:4 * self.D * b].view(np.float32).reshape(b, self.D)
         tail = raw[4 * self.D * b:].view(np.int64).reshape(3, b)
@@ -110,46 +124,70 @@ class Extractor:
         writer.append(emb, target, target_s, target_g, target_split, tail[0], names)
         acc["pred"].append(tail[0].copy()); acc["is_minor"].append(tail[1].copy()); acc["is_minor_pred"].append(tail[2].copy())
         slot.meta = None
+        self.stats["t_store"] += time.perf_counter() - t1
+
+    def _stage(self, batch, k):
+        """host side of batch k: into its slot's pinned buffers (or straight from the caller's pinned tensor) and onto the side stream"""
+        image, labels, names = batch
+        image = torch.as_tensor(image)
+        b = int(image.shape[0])
+        if b > self.max_batch:
+            raise ValueError(f"batch of {b} images > max_batch {self.max_batch}")
+        if self._slots is None or self._slots[0].h_in.shape[1:] != image.shape[1:] or self._slots[0].h_in.dtype != image.dtype:
+            if image.dtype not in (torch.uint8, torch.float32, torch.float16):
+                raise TypeError(f"images must be uint8 [b,H,W,3] or float [b,3,R,R], got {image.dtype}")
+            if k:
+                raise ValueError("all batches of one run must share geometry and dtype")
+            torch.cuda.synchronize(self.dev)
+            self._slots = [_Slot(self.max_batch, tuple(image.shape[1:]), image.dtype, self.D, self.dev) for _ in range(2)]
+        slot = self._slots[k & 1]
+        t0 = time.perf_counter()
+        target, target_g, target_s, target_split = (np.asarray(t, dtype=np.int64).reshape(-1) for t in labels)
+        # a batch that already lives in pinned memory (a decoder that writes there) is the DMA source itself
+        direct = image.is_pinned() and image.is_contiguous()
+        src = image if direct else slot.h_in[:b].copy_(image)
+        slot.h_lab[:b, 0] = torch.from_numpy(target); slot.h_lab[:b, 1] = torch.from_numpy(target_s)
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(slot.consumed)               # the batch staged here two batches ago has been read by its first kernel
+            slot.d_in[:b].copy_(src, non_blocking=True)
+            slot.d_lab[:b].copy_(slot.h_lab[:b], non_blocking=True)
+            slot.copied.record(self.side)
+        self.stats["h2d_copies"] += 2
+        self.stats["t_stage"] += time.perf_counter() - t0
+        slot.staged = (b, (target, target_g, target_s, target_split), [row_key(self.dataset, nm) for nm in names], direct)
+        return slot
 
     def run(self, batches, path, n_total):
         """batches: iterable of (image, (target, target_g, target_s, target_split), file_names) with host tensors / arrays.
-        Writes `path` (binary store, `n_total` rows) and returns dict(pred, is_minor, is_minor_pred) as int64 arrays."""
+        Writes `path` (binary store, `n_total` rows) and returns dict(pred, is_minor, is_minor_pred) as int64 arrays.
+
+        Submission order matters: the H2D copy of batch k + 1 is handed to the copy engine BEFORE the device work of batch k (which
+        ends in that batch's D2H copy) is enqueued.  Submitted the other way round the H2D queues behind the D2H on the engine and
+        starts only when batch k's encoder has finished (measured: 29 ms of host wait per batch, profiles/r04_extract_probe.log)."""
         writer = store.Writer(path, n_total, self.D, self.dataset)
         acc = {"pred": [], "is_minor": [], "is_minor_pred": []}
         main = torch.cuda.current_stream(self.dev)
+        it = iter(batches)
+        first = next(it, None)
+        staged = self._stage(first, 0) if first is not None else None
         pending = None                                        # slot whose results are in flight
         k = 0
-        for image, labels, names in batches:
-            image = torch.as_tensor(image)
-            b = int(image.shape[0])
-            if b > self.max_batch:
-                raise ValueError(f"batch of {b} images > max_batch {self.max_batch}")
-            if self._slots is None or self._slots[0].h_in.shape[1:] != image.shape[1:] or self._slots[0].h_in.dtype != image.dtype:
-                if image.dtype not in (torch.uint8, torch.float32, torch.float16):
-                    raise TypeError(f"images must be uint8 [b,H,W,3] or float [b,3,R,R], got {image.dtype}")
-                torch.cuda.synchronize(self.dev)
-                self._slots = [_Slot(self.max_batch, tuple(image.shape[1:]), image.dtype, self.D, self.dev) for _ in range(2)]
-            slot = self._slots[k & 1]
-            if slot.meta is not None:                         # (cannot happen with two slots and one pending; kept as a guard)
-                self._drain(slot, writer, acc)
-            target, target_g, target_s, target_split = (np.asarray(t, dtype=np.int64).reshape(-1) for t in labels)
-            # host: stage into pinned memory (the previous batch is computing meanwhile); a batch that already lives in pinned memory
-            # (a decoder that writes there) is the DMA source itself
-            direct = image.is_pinned() and image.is_contiguous()
-            src = image if direct else slot.h_in[:b].copy_(image)
-            slot.h_lab[:b, 0] = torch.from_numpy(target); slot.h_lab[:b, 1] = torch.from_numpy(target_s)
-            with torch.cuda.stream(self.side):
-                self.side.wait_event(slot.consumed)           # the compute of two batches ago has finished reading this slot's inputs
-                slot.d_in[:b].copy_(src, non_blocking=True)
-                slot.d_lab[:b].copy_(slot.h_lab[:b], non_blocking=True)
-                slot.copied.record(self.side)
-            if direct:
-                slot.copied.synchronize()                     # the caller may reuse its buffer once the next batch is requested
-            self.stats["h2d_copies"] += 2
+        while staged is not None:
+            slot = staged
+            b, targets, names, direct = slot.staged
+            if direct:                                        # the caller may reuse its buffer once the next batch is requested
+                t0 = time.perf_counter()
+                slot.copied.synchronize()
+                self.stats["t_h2d_wait"] += time.perf_counter() - t0
+            nxt = next(it, None)
+            staged = self._stage(nxt, k + 1) if nxt is not None else None          # H2D of batch k + 1: ahead of batch k's D2H
+            t0 = time.perf_counter()
             main.wait_event(slot.copied)
             self._compute(slot, b)
-            slot.consumed.record(main)
-            slot.meta = (b, (target, target_g, target_s, target_split), [row_key(self.dataset, nm) for nm in names])
+            if not slot.early:
+                slot.consumed.record(main)                    # float input: the encoder's first kernel reads it; released after the batch
+            slot.meta = (b, targets, names)
+            self.stats["t_enqueue"] += time.perf_counter() - t0
             if pending is not None:
                 self._drain(pending, writer, acc)             # batch k - 1: its D2H finished while batch k was being issued
             pending = slot
