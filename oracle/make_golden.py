@@ -513,6 +513,15 @@ TWO_STAGE = dict(seed=21, n_train=2048, n_val=1600, n_test=1024, dim=1024,
                        "--random_seed", "42"])
 
 
+# a second schedule through the OTHER branches of train_all_epochs: no MultipleAdapter (stage 2 keeps training the stage-1 classifier
+# with a fresh optimiser over all its parameters), no re-balancing (the reg loader itself, shuffle = True), no restart from the best
+# model, group prompts in every stage-2 epoch (`adapter_reg_seq` without --use_cls_prompt_in_reg), step decay inside stage 2
+TWO_STAGE_B = dict(seed=33, n_train=1536, n_val=1200, n_test=768, dim=1024,
+                   argv=["--dataset", "celeba", "--tl_method", "adapter_reg_seq", "--warm_reg", "--epochs", "6", "--epochs_feature_learning", "2",
+                         "--batch_size", "512", "--batch_size_reg", "64", "--learning_rate", "0.2", "--learning_rate_reg", "0.02",
+                         "--lr_decay_epochs", "4,5", "--lr_decay_rate", "0.5", "--random_seed", "7"])
+
+
 def _synthetic_embedding_module(FM, cfg, scale=1.0, log=None):
     """A stand-in for data/celeba_embeddings{,_reg}.py (which read the absent CSV / JSON files): the same dataset protocol
     (data/celeba_embeddings_reg.py:40-84: attributes and the __getitem__ tuple) over synth.embedding_dataset, and the same four loaders
@@ -649,11 +658,11 @@ def run_reference_two_stage(FM, cfg, paths, scale=1.0):
     return rec
 
 
-def gen_two_stage(FM):
+def gen_two_stage(FM, cfg=None, fname="two_stage.npz"):
     """tests/golden/two_stage.npz: per-epoch (n, correct) counters, losses, accuracies, learning rates, batch index streams, the two
     adapter initialisations and the final / zero-shot results of the reference's train_all_epochs on the synthetic embedding set, and
     the same run on embeddings scaled by (1 + 2^-23) -- the reference's own sensitivity to one ulp of its input."""
-    cfg = TWO_STAGE
+    cfg = cfg or TWO_STAGE
     tmp = tempfile.mkdtemp()
     tcls, tspu, tgrp = synth.embedding_text(cfg["seed"], cfg["dim"])
     paths = [os.path.join(tmp, n) for n in ("clip_class.json", "clip_spurious.json", "clip_group.json")]
@@ -675,7 +684,7 @@ def gen_two_stage(FM):
         out[f"p{i}/group_acc"] = np.array([e["group_acc"].get(k, np.nan) for k in keys], dtype=np.float64)
         out[f"p{i}/group_acc_1ulp"] = np.array([pe["group_acc"].get(k, np.nan) for k in keys], dtype=np.float64)
         out[f"p{i}/idx"] = np.asarray(e["idx"], dtype=np.int64); out[f"p{i}/lr"] = np.asarray(e["lr"], dtype=np.float64)
-    for i, (bi, bs) in enumerate(rec["balanced"]):
+    for i, (bi, bs) in enumerate(rec.get("balanced", [])):
         out[f"balanced{i}/indices"], out[f"balanced{i}/batch_size"] = bi.astype(np.int64), np.int64(bs)
     for i, sd in enumerate(rec["inits"]):                                          # both sides draw them from the seeded global RNG:
         for k, v in sd.items():                                                    # checksums + 256 strided samples pin them
@@ -691,7 +700,7 @@ def gen_two_stage(FM):
         d = (np.abs(e["counts"] - pert["epochs"][i]["counts"]).max(), np.abs(e["counts"] - pert8["epochs"][i]["counts"]).max())
         print(f"[two_stage] p{i:02d} {e['kind']:11s} n={e['counts'][:, 0].sum():5d} loss {e['loss']:.4f} acc {e['acc']:.4f} worst "
               f"{e['group_acc'].get('worst_acc', float('nan')):.4f}  group correct {e['counts'][:, 1].tolist()}  |1 / 8 ulp count diff| {d}")
-    np.savez_compressed(os.path.join(GOLD, "two_stage.npz"), **out)
+    np.savez_compressed(os.path.join(GOLD, fname), **out)
 
 
 if __name__ == "__main__":
@@ -717,6 +726,7 @@ if __name__ == "__main__":
         FM = ref_final_main()
         if "two_stage" in which:                  # the reference's own train_all_epochs on a synthetic embedding set
             gen_two_stage(FM)
+            gen_two_stage(FM, TWO_STAGE_B, "two_stage_b.npz")
         if "adapter" in which:
             gen_adapter(FM)
         if "adapter_vit" in which:                # BASELINE configs[3] / [4] adapter widths and global batches

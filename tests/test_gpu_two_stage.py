@@ -25,9 +25,11 @@ def _sample(t, n=256):
     return f[::max(1, f.numel() // n)][:n].float().numpy()
 
 
-@pytest.fixture(scope="module")
-def run(tmp_path_factory):
-    g = np.load(os.path.join(GOLDEN, "two_stage.npz"), allow_pickle=False)
+@pytest.fixture(scope="module", params=["two_stage.npz", "two_stage_b.npz"])
+def run(request, tmp_path_factory):
+    """two_stage.npz: adapter_reg_seq_alter + MultipleAdapter + balance_val + continue_from_best; two_stage_b.npz: adapter_reg_seq on the
+    stage-1 classifier itself (set_optimizer_reg over all its parameters), un-balanced shuffled reg loader, group prompts every epoch"""
+    g = np.load(os.path.join(GOLDEN, request.param), allow_pickle=False)
     cfg, o = json.loads(str(g["config"])), json.loads(str(g["opt"]))
     d = tmp_path_factory.mktemp("two_stage")
     tcls, tspu, tgrp = synth.embedding_text(cfg["seed"], cfg["dim"])
@@ -49,7 +51,7 @@ def run(tmp_path_factory):
 def test_initialisations_come_from_the_same_random_stream(run):
     g, opt, log, _ = run
     inits = [e for e in log if e["kind"] == "init"]
-    assert len(inits) == 2                                   # stage-1 adapter, stage-2 new adapter (drawn after three epochs of loaders)
+    assert len(inits) == (2 if opt.add_adapter else 1)       # stage-1 adapter (+ the stage-2 adapter, drawn after three epochs of loaders)
     for i, e in enumerate(inits):
         for k, v in e["state"].items():
             assert np.array_equal(_sample(v), g[f"init{i}/{k}_sample"]), (i, k)
@@ -67,8 +69,10 @@ def test_batches_and_learning_rates_are_the_references(run):
         if e["kind"] == "train2":
             assert e["use_group"] == bool(g[f"p{i}/use_group"])
         assert np.array_equal(e["counts"][:, 0], g[f"p{i}/counts"][:, 0]), i      # group sizes
-    # stage 2 alternates class / group prompts from the even epoch efl + 1 = 4
-    assert [e["use_group"] for e in passes if e["kind"] == "train2"] == [True, False, True, False, True]
+    if opt.tl_method == "adapter_reg_seq_alter":            # stage 2 alternates class / group prompts from the even epoch efl + 1 = 4
+        assert [e["use_group"] for e in passes if e["kind"] == "train2"] == [True, False, True, False, True]
+    else:                                                    # adapter_reg_seq without --use_cls_prompt_in_reg: group prompts throughout
+        assert all(e["use_group"] for e in passes if e["kind"] == "train2")
 
 
 def test_counts_losses_and_worst_group_accuracy(run):
