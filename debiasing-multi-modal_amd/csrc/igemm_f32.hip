@@ -1749,6 +1749,16 @@ int conv_impl(const float* x, const float* w, const float* bias, const float* re
                 if (rc != DBMM_E_UNSUPPORTED) return rc;
             }
         }
+        if (dbmm_opt(OPT_CONV1X1_BN256) && p.wh && p.nw == 1 && p.a_absmax && p.a_bytes && !p.pool2 && (K % 32) == 0 && (Cout % 256) == 0 &&
+            M >= 8192) {
+            p.tiles_n = (int)(Cout / 256);
+            p.n_tiles = (int)((M + 127) / 128) * p.tiles_n;
+            hipLaunchKernelGGL((igemm_x3_kernel<128, 256, 2, 2, 0, 2, 0, 2, 1, 32>), dim3(p.n_tiles), dim3(256), 0, s, p);
+            const int c[11] = {128, 256, 2, 2, 0, 0, 32, 2, 2, 0, 1};
+            for (int i = 0; i < 11; ++i) g_last_cfg[i] = c[i];
+            DBMM_CHECK_LAUNCH();
+            return DBMM_OK;
+        }
         return launch_modes<0, 0>(p, s, 1, ws, wsb);
     }
     {

@@ -38,6 +38,7 @@ const OptDef kOpts[DBMM_OPT_COUNT] = {
     {"conv1x1_8ph", 1},        // parity 1x1 convs on gemm_pair_8ph_kernel: 0 never / 1 where it measured ahead / 2 wherever it applies
     {"chain8", 0},             // 1: conv3 + residual -> next conv1 of the layer-3 geometry (K = P = 256) on the eight-wave chain kernel (measured
                                //    0.754 ms against 0.686 ms for the two launches: bottleneck_chain8.hip; kept, tested, off)
+    {"conv1x1_bn256", 0},      // 1: parity 1x1 convs with Cout % 256 == 0 on 128 x 256 tiles (A read once per 256 columns)
 };
 
 std::atomic<int> g_val[DBMM_OPT_COUNT];
