@@ -18,7 +18,7 @@ the checkpoint's fp16-exact weight, fp32 accumulate -- error vs fp64 equal to an
 v_mfma_f32_32x32x2_f32 (plan option conv_split = off), measured in the same process.
 
 Besides the contract line, rank 0 reports
-  roofline      every igemm launch of the timed region is bracketed by HIP events on its stream; kernels are
+  roofline      the igemm / chain / patch launches of every 4th timed step are bracketed by HIP events on their stream; kernels are
                 grouped by instantiation (the names rocprofv3 prints) and ranked by MEASURED time share.  The
                 top kernel is reported against its own binding roof: `bound` = whichever of algorithmic
                 FLOPs / MFMA peak and algorithmic bytes / 8 TB/s is the larger time; `kernels` holds the same
@@ -352,7 +352,7 @@ def extra_leg(arch, dtype, Bl, steps, warmup, dev, note):
     return leg
 
 
-def from_uint8_leg(dev, Bl=1024, steps=4, warmup=1, H=218, W=178):
+def from_uint8_leg(dev, Bl=1024, steps=8, warmup=2, H=218, W=178):
     """the headline step fed from DECODED uint8 images resident in HBM (CelebA geometry 218 x 178; clip_inference.py:203-206 feeds the
     encoder from the reference's PIL `preprocess`): device preprocessing (Pillow-exact bicubic resize + centre crop + normalise,
     preprocess.py) -> encode_image -> adapter step.  JPEG decode stays on the host and is not part of this figure."""
@@ -667,11 +667,12 @@ def main():
             del stepper, model, images
             torch.cuda.empty_cache()
             legs = {}
-            legs["rn50_bs512"] = extra_leg("RN50", "f32", 512, 4, 1, dev, "BASELINE configs[1] = one GPU's share of configs[2]")
-            legs["rn50_f16_bs1024"] = extra_leg("RN50", "f16", 1024, 4, 1, dev, "the metric's batch in the reference's GPU-path arithmetic")
-            legs["vit_b32_f32_bs512"] = extra_leg("ViT-B/32", "f32", 512, 4, 1, dev, "one GPU's share of BASELINE configs[3], parity mode")
-            legs["vit_b32_f16_bs512"] = extra_leg("ViT-B/32", "f16", 512, 4, 1, dev, "one GPU's share of BASELINE configs[3], fp16 mode")
-            legs["vit_l14_336_f16_bs1024"] = extra_leg("ViT-L/14@336px", "f16", 1024, 2, 1, dev,
+            # (2 warm-up steps and 6 - 12 timed ones per leg: a leg is a witness of its configuration, and enough steps to A/B on)
+            legs["rn50_bs512"] = extra_leg("RN50", "f32", 512, 8, 2, dev, "BASELINE configs[1] = one GPU's share of configs[2]")
+            legs["rn50_f16_bs1024"] = extra_leg("RN50", "f16", 1024, 8, 2, dev, "the metric's batch in the reference's GPU-path arithmetic")
+            legs["vit_b32_f32_bs512"] = extra_leg("ViT-B/32", "f32", 512, 12, 2, dev, "one GPU's share of BASELINE configs[3], parity mode")
+            legs["vit_b32_f16_bs512"] = extra_leg("ViT-B/32", "f16", 512, 12, 2, dev, "one GPU's share of BASELINE configs[3], fp16 mode")
+            legs["vit_l14_336_f16_bs1024"] = extra_leg("ViT-L/14@336px", "f16", 1024, 3, 1, dev,
                                                        "one GPU's share of BASELINE configs[4] (tests/test_gpu_config_sizes.py runs this size)")
             legs["rn50_from_uint8_bs1024"] = from_uint8_leg(dev)
             legs["rn50_from_host_bs1024"] = from_host_leg(dev)

@@ -853,12 +853,12 @@ inline unsigned grid_for(long long total) {
 
 namespace {
 int gemm_f16_impl(const void* a, int64_t lda, const void* w, int64_t ldw, const float* out_scale, const float* bias, const void* residual,
-                  int64_t ldr, int res_first, void* c, int64_t ldc, int64_t M, int64_t N, int64_t K, int act, void* stream);
+                  int64_t ldr, int res_first, void* c, int64_t ldc, int64_t M, int64_t N, int64_t K, int act, void* stream, int part);
 }
 
 extern "C" int dbmm_gemm_f16(const void* a, int64_t lda, const void* w, int64_t ldw, const float* bias, const void* residual,
                              int64_t ldr, void* c, int64_t ldc, int64_t M, int64_t N, int64_t K, int act, void* stream) {
-    return gemm_f16_impl(a, lda, w, ldw, nullptr, bias, residual, ldr, 0, c, ldc, M, N, K, act, stream);
+    return gemm_f16_impl(a, lda, w, ldw, nullptr, bias, residual, ldr, 0, c, ldc, M, N, K, act, stream, 0);
 }
 
 // 1x1 conv + eval-mode BatchNorm (+ residual) + activation on fp16 NHWC maps = the same GEMM with a per-channel scale and the
@@ -876,12 +876,12 @@ extern "C" int dbmm_conv1x1_bn_act_f16(const void* x, const void* w, const float
         const int rc = dbmm_conv1x1_stream_f16(x, w, scale, bias, residual, y, M, Cin, Cout, act, stream);
         if (rc != DBMM_E_UNSUPPORTED) return rc;
     }
-    return gemm_f16_impl(x, Cin, w, Cin, scale, bias, residual, Cout, 1, y, Cout, M, Cout, Cin, act, stream);
+    return gemm_f16_impl(x, Cin, w, Cin, scale, bias, residual, Cout, 1, y, Cout, M, Cout, Cin, act, stream, 0);
 }
 
 namespace {
 int gemm_f16_impl(const void* a, int64_t lda, const void* w, int64_t ldw, const float* out_scale, const float* bias, const void* residual,
-                  int64_t ldr, int res_first, void* c, int64_t ldc, int64_t M, int64_t N, int64_t K, int act, void* stream) {
+                  int64_t ldr, int res_first, void* c, int64_t ldc, int64_t M, int64_t N, int64_t K, int act, void* stream, int part) {
     if (!a || !w || !c) return DBMM_E_ARG;
     if (M <= 0 || N <= 0 || K <= 0 || M > INT32_MAX || N > INT32_MAX || K > INT32_MAX) return DBMM_E_SHAPE;
     if (act < 0 || act > 2) return DBMM_E_ARG;
@@ -899,9 +899,26 @@ int gemm_f16_impl(const void* a, int64_t lda, const void* w, int64_t ldw, const 
     // (a 32-deep chunk at four workgroups per CU measured the same as the 64-deep one and is gone)
     const int bn256 = dbmm_opt(OPT_F16_BN256);
     {
-        if (dbmm_opt(OPT_F16_8PH) && (N % 256) == 0 && (K % 128) == 0 && M >= 16384) {
+        // part: 0 = the whole problem, 1 = the eight-phase share of a split problem, 2 = its tail (128 x 128 tiles)
+        if (part != 2 && dbmm_opt(OPT_F16_8PH) && (N % 256) == 0 && (K % 128) == 0 && (M >= 16384 || part == 1)) {
             p.tiles_n = (int)(N / 256);
             p.n_tiles = (int)((M + 255) / 256) * p.tiles_n;
+            // Tile quantisation: the persistent kernel runs ceil(tiles / 256) rounds, and a last round of a few tiles costs a whole
+            // one (ViT-B/32 at 512 images: out-proj / c_proj have 100 x 3 = 300 tiles = 2 rounds for 1.17 rounds of work; RN50 layer 3:
+            // 784 tiles = 4 rounds for 3.06).  Whole rounds stay here; the rows of the short last round go to the 128 x 128 kernel, a
+            // launch of <= 512 tiles (one pass over the chip's 2 x 256 slots) that costs about 0.4 of an eight-phase round.
+            if (part == 0 && dbmm_opt(OPT_TAIL_SPLIT) && p.n_tiles > 256 && (p.n_tiles % 256) != 0) {
+                const int64_t mt = (M + 255) / 256, full_rounds = p.n_tiles / 256, mt_full = full_rounds * 256 / p.tiles_n;
+                const int64_t m_split = mt_full * 256, tail_rows = M - m_split;
+                const int64_t tail_tiles = ((tail_rows + 127) / 128) * ((N + 127) / 128);
+                if (mt_full >= 1 && mt_full < mt && tail_tiles <= 512 && (p.n_tiles % 256) <= 128) {
+                    int rc = gemm_f16_impl(a, lda, w, ldw, out_scale, bias, residual, ldr, res_first, c, ldc, m_split, N, K, act, stream, 1);
+                    if (rc != DBMM_OK) return rc;
+                    return gemm_f16_impl((const u16*)a + m_split * lda, lda, w, ldw, out_scale, bias,
+                                         residual ? (const void*)((const u16*)residual + m_split * ldr) : nullptr, ldr, res_first,
+                                         (u16*)c + m_split * ldc, ldc, tail_rows, N, K, act, stream, 2);
+                }
+            }
             const int grid = p.n_tiles < 256 ? p.n_tiles : 256;   // persistent: one workgroup per CU
             hipStream_t s8 = (hipStream_t)stream;
 #define DBMM_8PH(A, R) hipLaunchKernelGGL((gemm_f16_8ph_kernel<A, R>), dim3(grid), dim3(512), 0, s8, p)

@@ -1608,6 +1608,7 @@ struct SplitArgs {
     const float* oscale = nullptr;     // per-output-channel scale of the accumulator (BatchNorm kept out of the weights)
     int pool = 0;                      // 2: average 2x2 output windows in the epilogue
     float* c_full = nullptr;           // pool == 2: also store the un-pooled output here
+    bool no_8ph = false;               // the tail rows of a split 1x1 conv: 128 x 128 tiles only
 };
 
 inline void set_planes(IgemmP& p, const SplitArgs& sx, long long N, long long ldw) {
@@ -1735,16 +1736,31 @@ int conv_impl(const float* x, const float* w, const float* bias, const float* re
             // K <= 256 conv3 shapes (8 K tiles: the tile is prologue and epilogue; 0.399 -> 0.428 ms) and where 256-row tiles quantise
             // badly over the 256 CUs (layer 3's conv1: 784 tiles = 3.06 per CU, 0.287 -> 0.306 ms).
             // conv1x1_8ph = 0 never, 1 (default) by that rule, 2 wherever the kernel applies.
-            const int m8 = dbmm_opt(OPT_CONV1X1_8PH);
-            const long long t8 = ((M + 255) / 256) * (Cout / 256);
-            const bool pays = m8 == 2 || (m8 == 1 && Cin >= 512 && Cout <= 512 && (Cout == 512 || t8 >= 8 * NUM_CUS));
+            const int m8 = sx.no_8ph ? 0 : dbmm_opt(OPT_CONV1X1_8PH);
+            const long long tn8 = Cout / 256, mt8 = (M + 255) / 256, t8 = mt8 * tn8;
+            // Tile quantisation (option tail_split): whole rounds of 256 tiles on the eight-phase kernel, the rows of a short last round on
+            // the 128 x 128 kernel -- layer 3's conv1 (784 tiles = 3.06 rounds) then costs 3 rounds + a 64-tile launch instead of 4.
+            const long long rem8 = t8 % NUM_CUS, mt_full = (t8 / NUM_CUS) * NUM_CUS / (tn8 > 0 ? tn8 : 1);
+            const bool can_split = dbmm_opt(OPT_TAIL_SPLIT) && tn8 > 0 && t8 > NUM_CUS && rem8 != 0 && rem8 <= NUM_CUS / 2 && mt_full >= 1 &&
+                                   mt_full < mt8 && ((M - mt_full * 256 + 127) / 128) * ((Cout + 127) / 128) <= 2 * NUM_CUS;
+            const bool pays = m8 == 2 || (m8 == 1 && Cin >= 512 && Cout <= 512 && (Cout == 512 || t8 >= 8 * NUM_CUS || can_split));
             if (pays && p.wh && p.nw == 1 && p.a_absmax && !p.pool2 && (Cout % 256) == 0 && (Cin % 64) == 0 && M >= 16384 && p.wh_bytes &&
                 dbmm_aligned16(y) && (!residual || dbmm_aligned16(residual)) && 256 * (Cin > Cout ? Cin : Cout) * 4 < 0x7FFFFFF0LL) {
+                // (split only the shape that needs it to get here at all: on shapes the rule already takes, e.g. layer 4's first conv1 with
+                //  6.125 rounds, the second launch cost more than the saved fraction of a round: 0.467 -> 0.482 ms)
+                const int64_t m_head = (can_split && m8 == 1 && !(Cout == 512 || t8 >= 8 * NUM_CUS)) ? mt_full * 256 : M;
                 const int rc = dbmm_gemm_pair_8ph(x, Cin, sx.a_absmax, p.wh, p.w_exp, K, sx.oscale, bias, residual, Cout, y, Cout, sx.absmax_out,
-                                                  M, Cout, K, 1.f, act, stream);
+                                                  m_head, Cout, K, 1.f, act, stream);
                 if (rc == DBMM_OK) {
                     const int cfg[11] = {256, 256, 2, 4, 0, 0, 32, 1, 6, 0, 1};      // [8] = 6: gemm_pair_8ph_kernel
                     for (int i = 0; i < 11; ++i) g_last_cfg[i] = cfg[i];
+                    if (m_head < M) {                                                // the tail rows as their own 1x1 conv on 128 x 128 tiles
+                        SplitArgs st = sx; st.no_8ph = true;
+                        const int rt = conv_impl(x + m_head * Cin, w, bias, residual ? residual + m_head * Cout : nullptr, y + m_head * Cout, 1, 1,
+                                                 M - m_head, Cin, Cout, 1, 1, 1, 0, act, w_layout, ws, wsb, stream, st);
+                        for (int i = 0; i < 11; ++i) g_last_cfg[i] = cfg[i];         // (the launch is reported as the eight-phase kernel)
+                        return rt;
+                    }
                 }
                 if (rc != DBMM_E_UNSUPPORTED) return rc;
             }

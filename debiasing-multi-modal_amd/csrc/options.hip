@@ -39,6 +39,8 @@ const OptDef kOpts[DBMM_OPT_COUNT] = {
     {"chain8", 0},             // 1: conv3 + residual -> next conv1 of the layer-3 geometry (K = P = 256) on the eight-wave chain kernel (measured
                                //    0.754 ms against 0.686 ms for the two launches: bottleneck_chain8.hip; kept, tested, off)
     {"conv1x1_bn256", 0},      // 1: parity 1x1 convs with Cout % 256 == 0 on 128 x 256 tiles (A read once per 256 columns)
+    {"tail_split", 1},         // eight-phase GEMMs whose 256 x 256 tiles leave a short last round on the 256 CUs: whole rounds on the eight-phase
+                               // kernel, the remaining rows on the 128 x 128 kernel (0: one launch)
 };
 
 std::atomic<int> g_val[DBMM_OPT_COUNT];
