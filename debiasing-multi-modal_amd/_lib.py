@@ -30,6 +30,7 @@ KERNEL_SOURCES = (
     ("bottleneck_chain8_kernel", ("bottleneck_chain8.hip", "common.h")),
     ("conv3x3_c32_kernel", ("conv_patch.hip", "common.h")),
     ("gemm_pair_8ph_kernel", ("gemm_pair_8ph.hip", "common.h")),
+    ("conv3x3_halo8", ("conv3x3_halo8.hip", "conv3x3_halo8_epilogue.inc", "common.h")),
     ("mha_pair_kernel", ("mha_pair.hip", "common.h")),
     ("gemm_f16", ("f16_ops.hip", "common.h")), ("mha_f16", ("f16_ops.hip", "common.h")), ("layernorm_f16", ("f16_ops.hip", "common.h")),
     ("conv3x3_f16", ("conv_f16.hip", "common.h")), ("conv1x1_f16", ("conv_f16.hip", "common.h")), ("stem_s2_f16", ("conv_f16.hip", "common.h")),

@@ -18,9 +18,16 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 enum DbmmOpt {
     OPT_IGEMM_EPI_DIRECT, OPT_IGEMM_FAST, OPT_IGEMM_STREAMK, OPT_IGEMM_X3, OPT_IGEMM_X2, OPT_IGEMM_X2_BK, OPT_IGEMM_BK,
     OPT_IGEMM_HALO, OPT_IGEMM_HALO_POOL, OPT_IGEMM_BN256, OPT_IGEMM_BN256_KXK, OPT_GEMM_8PH, OPT_F16_8PH, OPT_F16_BN256,
-    OPT_STEM_MFMA, OPT_MHA_VALU, OPT_CONV_PATCH, OPT_MHA_X2, OPT_ADAPTER_STEP_FUSED, OPT_CONV1X1_STREAM, OPT_CONV1X1_8PH, OPT_CHAIN8, OPT_CONV1X1_BN256, OPT_TAIL_SPLIT, DBMM_OPT_COUNT
+    OPT_STEM_MFMA, OPT_MHA_VALU, OPT_CONV_PATCH, OPT_MHA_X2, OPT_ADAPTER_STEP_FUSED, OPT_CONV1X1_STREAM, OPT_CONV1X1_8PH, OPT_CHAIN8, OPT_CONV1X1_BN256, OPT_TAIL_SPLIT, OPT_HALO8, DBMM_OPT_COUNT
 };
 int dbmm_opt(int id);
+
+// conv3x3_halo8.hip: parity-mode 3x3 / stride 1 / pad 1 conv (+ scale / bias / ReLU, pool = 2: fused 2x2 average pool) on the eight-phase
+// 256 x 256 structure; x NHWC fp32, w ONE fp16 plane [Cout][9 Cin] in the 32-channel-slab K order.  split != 0 + a workspace: the tiles of a short
+// last round are cut along K over the idle CUs.  DBMM_E_UNSUPPORTED: not this kernel's shape.
+int dbmm_conv3x3_halo8(const float* x, const float* x_absmax, const void* w_plane_f16, int w_exp, const float* out_scale, const float* bias,
+                       float* y, float* y_absmax, int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int act, int pool, int split,
+                       void* workspace, size_t workspace_bytes, void* stream);
 
 static inline bool dbmm_aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
 

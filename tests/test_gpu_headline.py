@@ -55,7 +55,7 @@ def test_rn50_bs1024_one_call_rows_vs_golden_and_small_batch(golden):
                  "bottleneck_chain_kernel<128, 128, 0, 0, 1>", "conv3x3_c32_kernel<32, 0>", "conv3x3_c32_kernel<64, 1>"):
         assert want in tags, (want, sorted(tags))
     assert any(t.startswith("igemm_halo_kernel<") and t.endswith(", 1>") for t in tags), sorted(tags)      # pooled halo
-    assert any(t.startswith("igemm_halo_kernel<") and t.endswith(", 0>") for t in tags), sorted(tags)
+    assert "conv3x3_halo8_kernel<0>" in tags and "conv3x3_halo8_kernel<1>" in tags, sorted(tags)           # layers 3 / 4: eight-phase halo
     assert not any(t.startswith("igemm_f32_kernel<") and prof[t][1] > 1e12 for t in tags), sorted(tags)    # no fp32 fallback on a conv
 
 

@@ -552,6 +552,7 @@ def test_conv_pool2_fused_equals_conv_then_avgpool(B, H, Cin, Cout, single, halo
     1 puts the pooled conv on the window-major halo kernel where Cout % 256 != 0, 2 (default) everywhere, 0 nowhere
     (per-tap kernel).  Widths 26 / 14 / 6: the 32 windows of a tile wrap over 3 / 5 / 11+ pooled rows and over images."""
     option("igemm_halo_pool", str(halo_pool))
+    option("halo8", 0)                  # (Cout % 256 == 0 shapes would take conv3x3_halo8_kernel: tests/test_gpu_halo8.py)
     x = rnd(1, "x", (B, Cin, H, H)); w = rnd(2, "w", (Cout, Cin, 3, 3), (Cin * 9) ** -0.5)
     if single:
         w = w.half().float()
@@ -784,6 +785,7 @@ def test_conv3x3_halo_kernel(B, H, W, Cin, Cout, res, option):
     kw = dict(w_planes_f16=ph, w_exp=we, x_absmax=xd.abs().max().reshape(1), out_scale=sc.to(DEV))
     am = torch.zeros(1, device=DEV)
     option("igemm_halo", "1")
+    option("halo8", 0)                 # (this test is about igemm_halo_kernel; conv3x3_halo8_kernel: tests/test_gpu_halo8.py)
     option("conv_patch", "0")          # (the 32-channel stem shape would otherwise take the patch kernel)
     o = ops.conv_bn_act(xd, wp, b.to(DEV), rd, 3, 3, 1, 1, ops.ACT_RELU, wl, y_absmax=am, **kw)
     tag = ops._last_igemm_tag()
