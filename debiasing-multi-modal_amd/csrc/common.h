@@ -18,7 +18,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 enum DbmmOpt {
     OPT_IGEMM_EPI_DIRECT, OPT_IGEMM_FAST, OPT_IGEMM_STREAMK, OPT_IGEMM_X3, OPT_IGEMM_X2, OPT_IGEMM_X2_BK, OPT_IGEMM_BK,
     OPT_IGEMM_HALO, OPT_IGEMM_HALO_POOL, OPT_IGEMM_BN256, OPT_IGEMM_BN256_KXK, OPT_GEMM_8PH, OPT_F16_8PH, OPT_F16_BN256,
-    OPT_STEM_MFMA, OPT_MHA_VALU, OPT_CONV_PATCH, OPT_MHA_X2, OPT_ADAPTER_STEP_FUSED, OPT_CONV1X1_STREAM, OPT_CONV1X1_8PH, OPT_CHAIN8, OPT_CONV1X1_BN256, OPT_TAIL_SPLIT, OPT_HALO8, DBMM_OPT_COUNT
+    OPT_STEM_MFMA, OPT_MHA_VALU, OPT_CONV_PATCH, OPT_MHA_X2, OPT_ADAPTER_STEP_FUSED, OPT_CONV1X1_STREAM, OPT_CONV1X1_8PH, OPT_CHAIN8, OPT_CONV1X1_BN256, OPT_TAIL_SPLIT, OPT_HALO8, OPT_DUAL_8PH, DBMM_OPT_COUNT
 };
 int dbmm_opt(int id);
 
@@ -28,6 +28,12 @@ int dbmm_opt(int id);
 int dbmm_conv3x3_halo8(const float* x, const float* x_absmax, const void* w_plane_f16, int w_exp, const float* out_scale, const float* bias,
                        float* y, float* y_absmax, int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int act, int pool, int split,
                        void* workspace, size_t workspace_bytes, void* stream);
+
+// gemm_pair_8ph.hip: dbmm_gemm_dual_bn_act_x2's GEMM on the eight-phase 256 x 256 kernel (arguments checked by the caller)
+int dbmm_gemm_dual_pair_8ph(const float* a, int64_t lda, const float* a_absmax, const void* w_plane_f16, int w_exp, int64_t ldw, int64_t K,
+                            const float* out_scale, const float* a2, int64_t lda2, const float* a2_absmax, const void* w2_plane_f16, int64_t ldw2,
+                            int64_t K2, const float* ratio, const float* bias, float* c, int64_t ldc, float* c_absmax, int64_t M, int64_t N, int act,
+                            void* stream);
 
 static inline bool dbmm_aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
 

@@ -37,6 +37,11 @@ struct PairP {
     long long lda, ldw, ldr, ldc, a_total, w_total;
     int M, N, K, w_exp, tiles_n, n_tiles;
     float alpha;
+    // TWO: a second operand pair whose K2 / 32 tiles run FIRST (conv3 + downsample branch of a stage's first block as one GEMM, see
+    // dbmm_gemm_dual_bn_act_x2): then the accumulators are multiplied per output channel by ratio[n] * 2^(s - s2) and the main pair continues
+    const float* a2; const float* a2_absmax; const unsigned short* w2; const float* ratio;
+    long long lda2, ldw2, a2_total, w2_total;
+    int K2;
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t desc(const void* base, long long total, long long shift) {
@@ -69,9 +74,9 @@ __device__ __forceinline__ void split2h_pair(float x0, float x1, float sc, unsig
 }
 __device__ __forceinline__ f16x8 frag(const unsigned (&v)[4]) { return __builtin_bit_cast(f16x8, (u32x4){v[0], v[1], v[2], v[3]}); }
 
-template <int ACT, int RES>
+template <int ACT, int RES, int TWO = 0>
 __global__ __launch_bounds__(512, 1) void gemm_pair_8ph_kernel(const PairP p) {
-    __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * BUF];          // 96 KB
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * BUF + (TWO ? 8192 : 0)];   // 96 KB (+ TWO: this thread's four column ratios)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6), wr = wid >> 1, wc = wid & 1, grp = wid >> 2;   // 4 x 2 waves, two groups of four
     const int fr = lane & 31, fh = lane >> 5;
@@ -81,28 +86,51 @@ __global__ __launch_bounds__(512, 1) void gemm_pair_8ph_kernel(const PairP p) {
     const int t_lo = xcd < trm ? xcd * (tq + 1) : trm * (tq + 1) + (xcd - trm) * tq, t_hi = t_lo + tq + (xcd < trm ? 1 : 0);
     const __amdgpu_buffer_rsrc_t rsA0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.a, 0, 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsW0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, 0, 0x00020000);
-    __amdgpu_buffer_rsrc_t rsA = rsA0, rsW = rsW0;
+    __amdgpu_buffer_rsrc_t rsA = rsA0, rsW = rsW0, rsA2 = rsA0, rsW2 = rsW0;
     int m0 = 0, n0 = 0;
     // A half-tile h (128 rows x 32 k): thread -> (local row tid >> 2, k group tid & 3 of 8 k = 32 B of fp32).  Local row lr is
     // tile row (lr >> 5) * 64 + h * 32 + (lr & 31): the h-th 32 rows of every wave row's 64.  W half-tile h by LDS-DMA: chunk
     // tid = local row tid >> 2, slot tid & 3 of a 64-B row, source chunk slot ^ ((row >> 2) & 3); local row lr is tile column
     // (lr >> 6) * 128 + h * 64 + (lr & 63).
+    // (TWO: the per-lane offsets of BOTH operand pairs are recomputed where they are used and the ratios wait in LDS -- kept in registers they
+    //  pushed the loop over the budget, and every spill reload inside it is a vector-memory load the counted waits then drain behind)
     unsigned voffA[2], voffW[2];
+    const int nT2 = TWO ? p.K2 / 32 : 0, nT = nT2 + p.K / 32;         // K tiles of the second pair (they run first) / in all
+    const int s_a = scale_exp(*p.a_absmax), s_a2 = TWO ? scale_exp(*p.a2_absmax) : 0;
+    const float a_sc = pow2f(s_a), acc_scale = pow2f(-s_a - p.w_exp), a_sc2 = pow2f(s_a2);
     auto set_tile = [&](int tile) {
         m0 = (tile / p.tiles_n) * 256; n0 = (tile % p.tiles_n) * 256;
         rsA = desc(p.a, p.a_total, (long long)m0 * p.lda * 4);
         rsW = desc(p.w, p.w_total, (long long)n0 * p.ldw * 2);
+        if constexpr (TWO) {
+            rsA2 = desc(p.a2, p.a2_total, (long long)m0 * p.lda2 * 4);
+            rsW2 = desc(p.w2, p.w2_total, (long long)n0 * p.ldw2 * 2);
+        }
         const int lr = tid >> 2;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int ra = (lr >> 5) * 64 + h * 32 + (lr & 31);
+            const unsigned wrow = (unsigned)((lr >> 6) * 128 + h * 64 + (lr & 63)), wsl = (unsigned)(((tid & 3) ^ ((lr >> 2) & 3)) << 4);
             voffA[h] = m0 + ra < p.M ? (unsigned)ra * (unsigned)(p.lda * 4) + (tid & 3) * 32u : OOR;
-            voffW[h] = (unsigned)((lr >> 6) * 128 + h * 64 + (lr & 63)) * (unsigned)(p.ldw * 2) + (((tid & 3) ^ ((lr >> 2) & 3)) << 4);
+            voffW[h] = wrow * (unsigned)(p.ldw * 2) + wsl;
+        }
+        if constexpr (TWO) {                                          // ratio[n] * 2^(s - s2) of this lane's four columns
+            f32x4 rr;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) rr[j] = p.ratio[n0 + (wid & 1) * 128 + 32 * j + (lane & 31)] * pow2f(s_a - s_a2);
+            *(f32x4*)(lds + 2 * BUF + tid * 16) = rr;
         }
     };
-    const int nT = p.K / 32;
-    const int s_a = scale_exp(*p.a_absmax);
-    const float a_sc = pow2f(s_a), acc_scale = pow2f(-s_a - p.w_exp);
+    auto voff_a = [&](int h, bool second) -> unsigned {               // TWO: the A offset of load_a, from scratch
+        const int lr = tid >> 2, ra = (lr >> 5) * 64 + h * 32 + (lr & 31);
+        const unsigned ld4 = (unsigned)((second ? p.lda2 : p.lda) * 4);
+        return m0 + ra < p.M ? (unsigned)ra * ld4 + (tid & 3) * 32u : OOR;
+    };
+    auto voff_w = [&](int h, bool second) -> unsigned {
+        const int lr = tid >> 2;
+        const unsigned ld2 = (unsigned)((second ? p.ldw2 : p.ldw) * 2);
+        return (unsigned)((lr >> 6) * 128 + h * 64 + (lr & 63)) * ld2 + (((tid & 3) ^ ((lr >> 2) & 3)) << 4);
+    };
     // this thread's 16-B slot inside an fp16 plane of an A half-tile (its 8 k values), and the fragment addresses: A rows
     // wr * 32 + fr, W rows wc * 64 + cb * 32 + fr, chunk 2 ks + fh, 64-B rows swizzled by (row >> 2) & 3
     const int cv_off = (tid >> 2) * 64 + (((tid & 3) ^ (((tid >> 2) >> 2) & 3)) << 4);
@@ -120,24 +148,30 @@ __global__ __launch_bounds__(512, 1) void gemm_pair_8ph_kernel(const PairP p) {
     // A in flight in registers: [half][tile parity][2 x 16 B]
     f32x4 ar[2][2][2];
     auto load_a = [&](int h, int t, int set) {
-        const __amdgpu_buffer_rsrc_t rs = t < nT ? rsA : rsA0;
+        const bool second = TWO && t < nT2;                           // (selects, not branches: the phases stay straight-line code)
+        // (K tiles past the last one -- the final trip's look-ahead -- fetch whatever follows: split, stored, never multiplied)
+        const __amdgpu_buffer_rsrc_t rs = second ? rsA2 : rsA;
+        const unsigned vo = TWO ? voff_a(h, second) : voffA[h], so = (unsigned)(second ? t : t - nT2) * 128u;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
-            ar[h][set][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voffA[h], (unsigned)t * 128u + i * 16u, 0));
+            ar[h][set][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, so + i * 16u, 0));
     };
     // split this thread's 8 values ONCE and store them into the (hi, lo) planes of the half-tile's slot
-    auto convert_a = [&](int h, int set, int buf) {
+    auto convert_a = [&](int h, int set, int buf, int t = 0) {         // t: the K tile the values belong to (TWO: which operand's scale)
         unsigned hi[4], lo[4];
-        split2h_pair(ar[h][set][0][0], ar[h][set][0][1], a_sc, hi[0], lo[0]);
-        split2h_pair(ar[h][set][0][2], ar[h][set][0][3], a_sc, hi[1], lo[1]);
-        split2h_pair(ar[h][set][1][0], ar[h][set][1][1], a_sc, hi[2], lo[2]);
-        split2h_pair(ar[h][set][1][2], ar[h][set][1][3], a_sc, hi[3], lo[3]);
+        const float sc = (TWO && t < nT2) ? a_sc2 : a_sc;
+        split2h_pair(ar[h][set][0][0], ar[h][set][0][1], sc, hi[0], lo[0]);
+        split2h_pair(ar[h][set][0][2], ar[h][set][0][3], sc, hi[1], lo[1]);
+        split2h_pair(ar[h][set][1][0], ar[h][set][1][1], sc, hi[2], lo[2]);
+        split2h_pair(ar[h][set][1][2], ar[h][set][1][3], sc, hi[3], lo[3]);
         unsigned char* slot = lds + buf * BUF + (h ? OFF_AH1 : OFF_AH0) + cv_off;
         *(u32x4*)slot = (u32x4){hi[0], hi[1], hi[2], hi[3]};
         *(u32x4*)(slot + A_HALF / 2) = (u32x4){lo[0], lo[1], lo[2], lo[3]};
     };
     auto dma_w = [&](int h, int t, int buf) {
-        glds16(t < nT ? rsW : rsW0, lds + buf * BUF + (h ? OFF_BH1 : OFF_BH0) + wid * 1024, voffW[h], (unsigned)t * 64u);
+        const bool second = TWO && t < nT2;
+        glds16(second ? rsW2 : rsW, lds + buf * BUF + (h ? OFF_BH1 : OFF_BH0) + wid * 1024, TWO ? voff_w(h, second) : voffW[h],
+               (unsigned)(second ? t : t - nT2) * 64u);
     };
     f32x16 acc[2][4];                                                 // [A half (32 rows)][W half * 2 + column block]
     u32x4 fah[2], fal[2];                                             // [ks]
@@ -167,7 +201,7 @@ __global__ __launch_bounds__(512, 1) void gemm_pair_8ph_kernel(const PairP p) {
                 fah[ks] = *(const u32x4*)(base + OFF_AH0 + aoff[ks]);
                 fal[ks] = *(const u32x4*)(base + OFF_AH0 + A_HALF / 2 + aoff[ks]);
             }
-            convert_a(1, buf, buf);
+            convert_a(1, buf, buf, t);
             __builtin_amdgcn_sched_barrier(0);
             dma_w(1, t + 1, buf ^ 1);
         } else if (ph == 1) {
@@ -183,7 +217,7 @@ __global__ __launch_bounds__(512, 1) void gemm_pair_8ph_kernel(const PairP p) {
                 fah[ks] = *(const u32x4*)(base + OFF_AH1 + aoff[ks]);
                 fal[ks] = *(const u32x4*)(base + OFF_AH1 + A_HALF / 2 + aoff[ks]);
             }
-            convert_a(0, buf ^ 1, buf ^ 1);
+            convert_a(0, buf ^ 1, buf ^ 1, t + 1);
             __builtin_amdgcn_sched_barrier(0);
             load_a(1, t + 2, buf);
         } else {
@@ -228,18 +262,27 @@ __global__ __launch_bounds__(512, 1) void gemm_pair_8ph_kernel(const PairP p) {
         // the activations of the first K tiles go through registers: Ah0(0) is converted here, Ah1(0) / Ah0(1) / Ah1(1) wait in
         // their register sets for the phases that convert them (p0 / p2 of tile 0, p0 of tile 1)
         load_a(0, 0, 0); load_a(1, 0, 0); load_a(0, 1, 1); load_a(1, 1, 1);
-        convert_a(0, 0, 0);
+        convert_a(0, 0, 0, 0);
         // everything older than those loads (the W prologue issued before the previous tile's epilogue, that epilogue's loads and
         // stores) has been retired by the wait the conversion needed; the LDS stores are waited for before the barrier
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         if (grp == 1) __builtin_amdgcn_s_barrier();                   // the second wave group runs one barrier behind
         for (int t2 = 0; t2 < nT; t2 += 2) {
+            if (TWO && t2 == nT2) {                                   // the second pair's sums -> the main pair's scale (both K2 / 32 and t2 are even)
+                const f32x4 rr = *(const f32x4*)(lds + 2 * BUF + tid * 16);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[i][j][r] *= rr[j];
+            }
 #pragma unroll
             for (int j = 0; j < 8; ++j) phase(j, t2);
         }
         if (grp == 0) __builtin_amdgcn_s_barrier();
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the (zero-extent) tail loads / DMA of this tile
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the look-ahead loads / DMA past this tile's last K tile
         __builtin_amdgcn_s_barrier();                                 // every wave is done with the ring
         const int em0 = m0, en0 = n0;
         if (tile + wg_per_xcd < t_hi) { set_tile(tile + wg_per_xcd); prologue_w(); }   // in flight during the epilogue below
@@ -323,6 +366,22 @@ __global__ __launch_bounds__(512, 1) void gemm_pair_8ph_kernel(const PairP p) {
 
 }  // namespace
 
+namespace {
+int pair_8ph_launch(PairP& p, int act, bool two, void* stream) {
+    p.tiles_n = p.N / 256;
+    p.n_tiles = ((p.M + 255) / 256) * p.tiles_n;
+    const int grid = p.n_tiles < 256 ? p.n_tiles : 256;               // persistent: one workgroup per CU
+    hipStream_t s = (hipStream_t)stream;
+#define DBMM_P8(A, R, T) hipLaunchKernelGGL((gemm_pair_8ph_kernel<A, R, T>), dim3(grid), dim3(512), 0, s, p)
+    if (two) { if (act == 0) DBMM_P8(0, 0, 1); else if (act == 1) DBMM_P8(1, 0, 1); else return DBMM_E_UNSUPPORTED; }
+    else if (p.res) { if (act == 0) DBMM_P8(0, 1, 0); else if (act == 1) DBMM_P8(1, 1, 0); else DBMM_P8(2, 1, 0); }
+    else { if (act == 0) DBMM_P8(0, 0, 0); else if (act == 1) DBMM_P8(1, 0, 0); else DBMM_P8(2, 0, 0); }
+#undef DBMM_P8
+    DBMM_CHECK_LAUNCH();
+    return DBMM_OK;
+}
+}  // namespace
+
 // see include/dbmm.h
 extern "C" int dbmm_gemm_pair_8ph(const float* a, int64_t lda, const float* a_absmax, const void* w_plane_f16, int w_exp, int64_t ldw,
                                   const float* out_scale, const float* bias, const float* residual, int64_t ldr, float* c, int64_t ldc,
@@ -341,14 +400,23 @@ extern "C" int dbmm_gemm_pair_8ph(const float* a, int64_t lda, const float* a_ab
     p.c = c; p.c_absmax = c_absmax;
     p.lda = lda; p.ldw = ldw; p.ldr = ldr; p.ldc = ldc; p.a_total = ((M - 1) * lda + K) * 4; p.w_total = wb;
     p.M = (int)M; p.N = (int)N; p.K = (int)K; p.w_exp = w_exp; p.alpha = alpha;
-    p.tiles_n = (int)(N / 256);
-    p.n_tiles = (int)((M + 255) / 256) * p.tiles_n;
-    const int grid = p.n_tiles < 256 ? p.n_tiles : 256;               // persistent: one workgroup per CU
-    hipStream_t s = (hipStream_t)stream;
-#define DBMM_P8(A, R) hipLaunchKernelGGL((gemm_pair_8ph_kernel<A, R>), dim3(grid), dim3(512), 0, s, p)
-    if (residual) { if (act == 0) DBMM_P8(0, 1); else if (act == 1) DBMM_P8(1, 1); else DBMM_P8(2, 1); }
-    else { if (act == 0) DBMM_P8(0, 0); else if (act == 1) DBMM_P8(1, 0); else DBMM_P8(2, 0); }
-#undef DBMM_P8
-    DBMM_CHECK_LAUNCH();
-    return DBMM_OK;
+    return pair_8ph_launch(p, act, false, stream);
+}
+
+// common.h: the dual-source GEMM of dbmm_gemm_dual_bn_act_x2 on this kernel (TWO = 1).  DBMM_E_UNSUPPORTED: not this kernel's shape.
+int dbmm_gemm_dual_pair_8ph(const float* a, int64_t lda, const float* a_absmax, const void* w_plane_f16, int w_exp, int64_t ldw, int64_t K,
+                            const float* out_scale, const float* a2, int64_t lda2, const float* a2_absmax, const void* w2_plane_f16, int64_t ldw2,
+                            int64_t K2, const float* ratio, const float* bias, float* c, int64_t ldc, float* c_absmax, int64_t M, int64_t N, int act,
+                            void* stream) {
+    if ((N % 256) || (K % 64) || (K2 % 64) || M < 16384 || (act != 0 && act != 1)) return DBMM_E_UNSUPPORTED;
+    const long long wb = ((N - 1) * ldw + K) * 2, wb2 = ((N - 1) * ldw2 + K2) * 2;
+    if (wb >= EXT_LIM || wb2 >= EXT_LIM || 256 * lda * 4 >= EXT_LIM || 256 * lda2 * 4 >= EXT_LIM || 256 * ldc * 4 >= EXT_LIM) return DBMM_E_UNSUPPORTED;
+    PairP p{};
+    p.a = a; p.a_absmax = a_absmax; p.w = (const unsigned short*)w_plane_f16; p.oscale = out_scale; p.bias = bias; p.res = nullptr;
+    p.c = c; p.c_absmax = c_absmax;
+    p.lda = lda; p.ldw = ldw; p.ldr = 0; p.ldc = ldc; p.a_total = ((M - 1) * lda + K) * 4; p.w_total = wb;
+    p.M = (int)M; p.N = (int)N; p.K = (int)K; p.w_exp = w_exp; p.alpha = 1.f;
+    p.a2 = a2; p.a2_absmax = a2_absmax; p.w2 = (const unsigned short*)w2_plane_f16; p.ratio = ratio;
+    p.lda2 = lda2; p.ldw2 = ldw2; p.a2_total = ((M - 1) * lda2 + K2) * 4; p.w2_total = wb2; p.K2 = (int)K2;
+    return pair_8ph_launch(p, act, true, stream);
 }

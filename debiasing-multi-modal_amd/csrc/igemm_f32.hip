@@ -1968,6 +1968,16 @@ extern "C" int dbmm_gemm_dual_bn_act_x2(const float* a, int64_t lda, const float
     const long long ab = ((M - 1) * lda + K) * 4, ab2 = ((M - 1) * lda2 + K2) * 4, wb = ((N - 1) * ldw + K) * 2,
                     wb2 = ((N - 1) * ldw2 + K2) * 2, lim = 0x7FFFFFF0LL;
     if (wb >= lim || wb2 >= lim) return DBMM_E_UNSUPPORTED;      // (activations may exceed 2 GiB: tiles rebase, a_desc)
+    // the eight-phase 256 x 256 kernel (gemm_pair_8ph.hip, TWO = 1).  dual_8ph = 0 never, 1 where it measured ahead, 2 wherever it applies.
+    if (dbmm_opt(OPT_DUAL_8PH)) {
+        const int rc = dbmm_gemm_dual_pair_8ph(a, lda, a_absmax, w_plane_f16, w_exp, ldw, K, out_scale, a2, lda2, a2_absmax, w2_plane_f16, ldw2, K2, ratio, bias,
+                                               c, ldc, c_absmax, M, N, act, stream);
+        if (rc == DBMM_OK) {
+            const int cfg[11] = {256, 256, 4, 2, 0, 0, 32, 1, 8, 0, 1};             // [8] = 8: gemm_pair_8ph_kernel, TWO = 1
+            for (int i = 0; i < 11; ++i) g_last_cfg[i] = cfg[i];
+        }
+        if (rc != DBMM_E_UNSUPPORTED) return rc;
+    }
     constexpr int BM = 128, BN = 128, MB = 3;
     IgemmP p{};
     p.epi_direct = epi_direct_env();

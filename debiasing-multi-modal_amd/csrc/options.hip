@@ -42,6 +42,7 @@ const OptDef kOpts[DBMM_OPT_COUNT] = {
     {"tail_split", 1},         // eight-phase GEMMs whose 256 x 256 tiles leave a short last round on the 256 CUs: whole rounds on the eight-phase
                                // kernel, the remaining rows on the 128 x 128 kernel (0: one launch)
     {"halo8", 1},              // parity 3x3 convs with Cout % 256 == 0 on conv3x3_halo8_kernel: 0 never / 1 where it measured ahead / 2 wherever it applies
+    {"dual_8ph", 1},           // conv3 + downsample dual-source GEMM on gemm_pair_8ph_kernel: 0 never / 1 where it measured ahead / 2 wherever it applies
 };
 
 std::atomic<int> g_val[DBMM_OPT_COUNT];

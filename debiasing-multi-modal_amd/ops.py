@@ -74,6 +74,8 @@ def _last_igemm_tag():
     _lib.lib().dbmm_debug_last_igemm(cfg)
     if cfg[8] == 5:        # conv3 + downsample dual-source GEMM: the x3 kernel with TWO = 1
         return f"igemm_x3_kernel<{cfg[0]}, {cfg[1]}, {cfg[2]}, {cfg[3]}, 0, {cfg[7]}, {cfg[9]}, 2, 1, 32, 1>"
+    if cfg[8] == 8:        # the dual-source GEMM on the deep-pipelined kernel: <ACT, RES, TWO = 1>
+        return "gemm_pair_8ph_kernel<dual>"
     if cfg[8] == 6:        # deep-pipelined parity GEMM (gemm_pair_8ph.hip): <ACT, RES> are not reported
         return "gemm_pair_8ph_kernel"
     if cfg[8] == 7:        # eight-phase 3x3 halo kernel (conv3x3_halo8.hip): <POOL, ACT>, ACT not reported

@@ -798,9 +798,10 @@ def test_conv3x3_halo_kernel(B, H, W, Cin, Cout, res, option):
     assert am.item() == o.abs().max().item()
 
 
+@pytest.mark.parametrize("eight", [0, 2])
 @pytest.mark.parametrize("M,N,K,K2", [(25088, 256, 64, 64), (50176, 512, 128, 256), (25088, 1024, 256, 512),
                                       (25000, 2048, 512, 1024)])
-def test_gemm_dual_conv3_plus_downsample(M, N, K, K2):
+def test_gemm_dual_conv3_plus_downsample(M, N, K, K2, eight, option):
     """relu(bn3(conv3(y)) + bn_d(conv_d(x))) as one dual-source GEMM == the two fp32-accurate
     launches (conv_d, then conv3 with the residual) and an fp64 reference; incl. stream-K shapes
     and an M tail."""
@@ -816,8 +817,10 @@ def test_gemm_dual_conv3_plus_downsample(M, N, K, K2):
     ratio = (sc2.double() / sc.double() * 2.0 ** (we - we2)).float().to(DEV)
     ya, xa = yd.abs().max().reshape(1), (xd.abs().max() * 1.7).reshape(1)               # a bound, not the exact max
     cam = torch.zeros(1, device=DEV)
+    option("dual_8ph", eight)        # 2: gemm_pair_8ph_kernel with TWO = 1 (every shape here suits it), 0: the 128 x 128 kernel
     out = ops.gemm_dual(yd, ya, ph, we, sc.to(DEV), xd, xa, ph2, ratio, (b + b2).to(DEV), ops.ACT_RELU, cam)
-    assert out is not None and ops._last_igemm_tag().endswith(", 2, 1, 32, 1>")
+    assert out is not None
+    assert ops._last_igemm_tag() == "gemm_pair_8ph_kernel<dual>" if eight else ops._last_igemm_tag().endswith(", 2, 1, 32, 1>")
     # unfused: identity = conv_d(x) * sc2 + b2 ; out = relu(conv3(y) * sc + b + identity)
     v = lambda t: t.reshape(1, 1, M, -1)
     ident = ops.conv_bn_act(v(xd), w2.to(DEV), b2.to(DEV), None, 1, 1, 1, 0, ops.ACT_NONE, w_planes_f16=ph2, w_exp=we2,
@@ -878,14 +881,17 @@ def test_operands_over_2gib_stay_on_the_split_kernels(option):
     s3 = 0.5 + torch.rand((256,), device=DEV, generator=g); sd = 0.5 + torch.rand((256,), device=DEV, generator=g)
     ratio = (sd.double() / s3.double() * 2.0 ** (e3 - ed)).float()
     bb = torch.randn((256,), device=DEV, generator=g) * 0.1
-    out = ops.gemm_dual(y2, y2.abs().max().reshape(1), p3, e3, s3, x.view(M, Cin), xa, pd, ratio, bb, ops.ACT_RELU)
-    assert out is not None and _last_cfg()[8] == 5, _last_cfg()
-    assert out.numel() * 4 > 2 ** 31
-    for r0 in (0, M // 2 - 64, M - 200):
-        sl = slice(r0, r0 + 200)
-        ref = torch.relu(y2[sl].double() @ w3.double().t() * s3.double() + x.view(M, Cin)[sl].double() @ wd.double().t() * sd.double()
-                         + bb.double())
-        assert relerr(out[sl].double().cpu(), ref.cpu()) < 5e-6, r0
+    for knob, kind in ((0, 5), (2, 8)):          # the 128 x 128 dual-source kernel, then the eight-phase one (both rebase their descriptors per tile)
+        ops.set_option("dual_8ph", knob)
+        out = ops.gemm_dual(y2, y2.abs().max().reshape(1), p3, e3, s3, x.view(M, Cin), xa, pd, ratio, bb, ops.ACT_RELU)
+        assert out is not None and _last_cfg()[8] == kind, _last_cfg()
+        assert out.numel() * 4 > 2 ** 31
+        for r0 in (0, M // 2 - 64, M - 200):
+            sl = slice(r0, r0 + 200)
+            ref = torch.relu(y2[sl].double() @ w3.double().t() * s3.double() + x.view(M, Cin)[sl].double() @ wd.double().t() * sd.double()
+                             + bb.double())
+            assert relerr(out[sl].double().cpu(), ref.cpu()) < 5e-6, r0
+    ops.set_option("dual_8ph", 1)
     # --- conv3-style 1x1 with a residual > 2 GiB and the pooled second output (64-bit row pointers in the epilogue)
     res = out.view(B, H, H, 256)
     (yp, yf), _ = (ops.conv_bn_act(y2.view(B, H, H, 64), w3, bb, res, 1, 1, 1, 0, ops.ACT_RELU, w_planes_f16=p3, w_exp=e3,
