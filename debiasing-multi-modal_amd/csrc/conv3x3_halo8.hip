@@ -381,6 +381,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo8_kernel(const Halo8P p) {
         const bool whole = k < n_whole;
         if (k + 1 < n_items) { set_item(k + 1); prologue(); }         // in flight during the epilogue below
         if (whole) {
+            constexpr int EP_NB = 4, EP_WCOLS = 128;
 #include "conv3x3_halo8_epilogue.inc"
         } else {                                                      // a slice: the raw accumulators, 16 B per thread and store (8 KB per workgroup instruction)
             // (buffer stores with the register's offset in soffset: 128 flat addresses would be hoisted out of the item loop and spilled)
@@ -473,6 +474,240 @@ __global__ __launch_bounds__(512) void conv3x3_halo8_fixup_kernel(const Halo8P p
     halo8_amax(p, out_amax, red, tid);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The same conv for Cout % 128 == 0 (layer 2: 128 channels): tile 256 pixels x 128 channels, 4 x 2 waves of 64 x 64 outputs (64 accumulator
+// registers).  A tap is TWO phases of 8 MFMAs -- q0: row block A0 x both column blocks, q1: A1 x both -- with six fragment reads each
+// (q0: the tap's four W fragments + A1's first k-step; q1: A1's second k-step + the NEXT tap's A0), one 8-KB weight tile per tap by LDS-DMA
+// into a ring of three (issued at q1, three taps = five phases ahead of its first read), and THREE activation buffers: group g's strip is
+// loaded at the first phase of group g - 2 and split / stored in that group's last two phases (the registers are free again before the next
+// load; the ring's third buffer is what lets the store wait that long).  A loop trip = three groups = one 32-channel slab: weight buffer =
+// kw, activation buffer = kh, mask bit = 3 kh + kw are all compile-time.  No K cut of short last rounds (layer 2 has 49+ rounds).
+constexpr int N_W_BUF = 128 * 64;                                 // a tap's weight tile
+constexpr int N_OFF_A = 3 * N_W_BUF;
+constexpr int N_LDS_BYTES = N_OFF_A + 3 * A_BUF;                  // 24,576 + 104,448 = 129,024
+
+template <int POOL, int ACT>
+__global__ __launch_bounds__(512, 1) void conv3x3_halo8n_kernel(const Halo8P p) {
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[N_LDS_BYTES];
+    constexpr int NLD = POOL ? 260 : 258;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6), wr = wid >> 1, wc = wid & 1, grp = wid >> 2;
+    const int fr = lane & 31, fh = lane >> 5;
+    const int nwg = gridDim.x, xcd = blockIdx.x & 7, slot_in_xcd = blockIdx.x >> 3, wg_per_xcd = (nwg - xcd + 7) >> 3;
+    const int tq = p.n_tiles >> 3, trm = p.n_tiles & 7;
+    const int t_lo = xcd < trm ? xcd * (tq + 1) : trm * (tq + 1) + (xcd - trm) * tq, t_hi = t_lo + tq + (xcd < trm ? 1 : 0);
+    __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.a, 0, 0, 0x00020000), rsW = rsA;
+    int m0 = 0, n0 = 0;
+    const int G = 3 * (p.Cin >> 5);
+    const int s_a = scale_exp(*p.a_absmax);
+    const float a_sc = pow2f(s_a), acc_scale = pow2f(-s_a - p.w_exp);
+
+    // activation loader and fragment rows: as conv3x3_halo8_kernel
+    const int lq = tid & 3;
+    int st_off[3];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int j = (tid >> 2) + 128 * i;
+        const int row = POOL ? (j < 130 ? j : j + (STRIP1 - 130)) : j;
+        st_off[i] = row * 64 + ((lq ^ ((row >> 2) & 3)) << 4);
+    }
+    const bool has2 = 256 + (tid >> 3) < NLD;
+    {
+        const int j = 256 + (tid >> 3), row = POOL ? j + (STRIP1 - 130) : j, pc = tid & 7;
+        st_off[2] = row * 64 + (((pc >> 1) ^ ((row >> 2) & 3)) << 4) + (pc & 1) * 8;
+    }
+    // weight tile by LDS-DMA: chunk tid = tile column tid >> 2, slot tid & 3 of its 64-B row
+    const unsigned voffW = (unsigned)(tid >> 2) * (unsigned)(p.ldw * 2) + (((tid & 3) ^ ((tid >> 4) & 3)) << 4);
+    constexpr int A_BLK = POOL ? 1024 : 2048, W_BLK = 2048;
+    int faddr[3], boff;
+    {
+        const int r = wr * 64 + fr;
+        const int lrow = POOL ? ((r >> 1) & 1) * STRIP1 + (r >> 2) * 2 + (r & 1) : r;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) faddr[kw] = N_OFF_A + (lrow + kw) * 64 + ((fh ^ (((lrow + kw) >> 2) & 3)) << 4);
+        const int rw = wc * 64 + fr;
+        boff = rw * 64 + ((fh ^ ((rw >> 2) & 3)) << 4);
+    }
+    unsigned fa_off[3], fmask[2];
+    auto set_tile = [&](int tile) {
+        m0 = (tile / p.tiles_n) * 256; n0 = (tile % p.tiles_n) * 128;
+        const int pxf = POOL ? pool_base_pixel(p, m0 >> 2) : m0;
+        const int px0 = pxf - 1 - p.W > 0 ? pxf - 1 - p.W : 0;
+        rsA = desc(p.a, p.a_total, (long long)px0 * p.Cin * 4);
+        rsW = desc(p.w, p.w_total, (long long)n0 * p.ldw * 2);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int j = i < 2 ? (tid >> 2) + 128 * i : 256 + (tid >> 3);
+            const unsigned piece = i < 2 ? lq * 32u : (tid & 7) * 16u;
+            if constexpr (POOL) {
+                const int dy = j >= 130, c = j - 130 * dy;
+                const int wl = c == 0 ? 0 : (c == 129 ? 63 : (c - 1) >> 1), dxo = c == 0 ? -1 : (c == 129 ? 2 : (c - 1) & 1);
+                const int mp = (m0 >> 2) + wl;
+                fa_off[i] = (j < NLD && 4 * mp < p.M)
+                                ? (unsigned)((pool_base_pixel(p, mp) + dy * p.W + dxo - p.W - px0) * p.Cin) * 4u + piece : OOR;
+            } else {
+                fa_off[i] = j < NLD ? (unsigned)((m0 - 1 + j - p.W - px0) * p.Cin) * 4u + piece : OOR;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int m = m0 + wr * 64 + i * 32 + fr;
+            unsigned msk = 0;
+            if (m < p.M) {
+                int ho, wo;
+                if constexpr (POOL) {
+                    const int q = m & 3, mp = m >> 2, wp2 = p.W >> 1, hwp = (p.H >> 1) * wp2;
+                    const int rem = mp % hwp, hp = rem / wp2;
+                    ho = 2 * hp + (q >> 1); wo = 2 * (rem - hp * wp2) + (q & 1);
+                } else {
+                    const int hw = p.H * p.W, rem = m % hw;
+                    ho = rem / p.W; wo = rem - ho * p.W;
+                }
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw)
+                        if (ho + kh - 1 >= 0 && ho + kh - 1 < p.H && wo + kw - 1 >= 0 && wo + kw - 1 < p.W) msk |= 1u << (kh * 3 + kw);
+            }
+            fmask[i] = msk;
+        }
+    };
+
+    f32x4 ar[2][2], ar2;                                              // the strip in flight (group g + 2 while group g computes)
+    f32x4 br[2][2], br2;                                              // item start only: the item's second group
+    auto load_strip = [&](f32x4 (&r)[2][2], f32x4& r2, int g) {
+        const int slab = g / 3, kh = g - 3 * slab;
+        const unsigned delta = (unsigned)((kh * p.W * p.Cin + slab * 32) * 4);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+                r[i][h] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, fa_off[i] + delta, 16u * h, 0));
+        r2 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, fa_off[2] + delta, 0u, 0));
+    };
+    auto convert = [&](const f32x4 (&r)[2][2], const f32x4& r2, int i, int buf) {
+        if (i < 2) {
+            unsigned hi[4], lo[4];
+            split2h_pair(r[i][0][0], r[i][0][1], a_sc, hi[0], lo[0]);
+            split2h_pair(r[i][0][2], r[i][0][3], a_sc, hi[1], lo[1]);
+            split2h_pair(r[i][1][0], r[i][1][1], a_sc, hi[2], lo[2]);
+            split2h_pair(r[i][1][2], r[i][1][3], a_sc, hi[3], lo[3]);
+            unsigned char* slot = lds + N_OFF_A + buf * A_BUF + st_off[i];
+            *(u32x4*)slot = (u32x4){hi[0], hi[1], hi[2], hi[3]};
+            *(u32x4*)(slot + A_PLANE) = (u32x4){lo[0], lo[1], lo[2], lo[3]};
+        } else {
+            unsigned hi[2], lo[2];
+            split2h_pair(r2[0], r2[1], a_sc, hi[0], lo[0]);
+            split2h_pair(r2[2], r2[3], a_sc, hi[1], lo[1]);
+            unsigned char* slot = lds + N_OFF_A + buf * A_BUF + st_off[2];
+            if (has2) {
+                *(u32x2*)slot = (u32x2){hi[0], hi[1]};
+                *(u32x2*)(slot + A_PLANE) = (u32x2){lo[0], lo[1]};
+            }
+        }
+    };
+    auto dma_w = [&](int t, int buf) { glds16(rsW, lds + buf * N_W_BUF + wid * 1024, voffW, (unsigned)t * 64u); };
+    f32x16 acc[2][2];
+    u32x4 fah[2][2], fal[2][2], fb[2][2];                             // A: [row block][ks]; W: [column block][ks]
+    auto a_addr = [&](int i, int buf, int kw, int tapbit) -> int {
+        const bool ok = (fmask[i] >> tapbit) & 1u;
+        const int f = faddr[kw] + buf * A_BUF;
+        return ok ? f + i * A_BLK : (N_OFF_A + buf * A_BUF + ZROW * 64 + (f & 255));
+    };
+    auto read_fa = [&](int i, int ks, int a0) {
+        const int a = ks ? a0 ^ 32 : a0;
+        fah[i][ks] = *(const u32x4*)(lds + a);
+        fal[i][ks] = *(const u32x4*)(lds + A_PLANE + a);
+    };
+
+    // One phase.  j = phase within the trip (static, 0..17): group gi = j / 6 of the trip (= kh), tap kw = (j % 6) / 2, q = j & 1; the tap is
+    // K tile t = t0 + 3 gi + kw (t0 = 9 * slab).  Staging besides the six fragment reads:
+    //   (kw 0, q0): the five loads of group g + 2's strip        (kw 2, q0) / (kw 2, q1): split + store pass 0 / passes 1, 2 into buffer (kh + 2) % 3
+    //   q1 of every tap: DMA of the weight tile three taps on into this tap's buffer; vmcnt retires the tile of the NEXT tap
+    //   (instructions issued after that tile's DMA: the two later tiles', + the five loads unless they are older: kw 2)
+    auto phase = [&](int j, int t0, int g0) {
+        const int gi = j / 6, kw = (j - 6 * gi) >> 1, q = j & 1, t = t0 + 3 * gi + kw;
+        if (q == 0) {
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) fb[cb][ks] = *(const u32x4*)(lds + kw * N_W_BUF + cb * W_BLK + (ks ? boff ^ 32 : boff));
+            read_fa(1, 0, a_addr(1, gi, kw, 3 * gi + kw));
+            if (kw == 2) convert(ar, ar2, 0, (gi + 2) % 3);
+            __builtin_amdgcn_sched_barrier(0);
+            if (kw == 0) load_strip(ar, ar2, g0 + gi + 2);
+        } else {
+            read_fa(1, 1, a_addr(1, gi, kw, 3 * gi + kw));
+            const int a0 = kw < 2 ? a_addr(0, gi, kw + 1, 3 * gi + kw + 1) : a_addr(0, (gi + 1) % 3, 0, 3 * ((gi + 1) % 3));
+            read_fa(0, 0, a0); read_fa(0, 1, a0);
+            if (kw == 2) { convert(ar, ar2, 1, (gi + 2) % 3); convert(ar, ar2, 2, (gi + 2) % 3); }
+            __builtin_amdgcn_sched_barrier(0);
+            dma_w(t + 3, kw);
+            __builtin_amdgcn_sched_barrier(0);
+            if (kw == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb)                            // (lo, w) first, then (hi, w)
+                acc[q][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fal[q][ks]), __builtin_bit_cast(f16x8, fb[cb][ks]), acc[q][cb], 0, 0, 0);
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb)
+                acc[q][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fah[q][ks]), __builtin_bit_cast(f16x8, fb[cb][ks]), acc[q][cb], 0, 0, 0);
+        }
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+    };
+    float out_amax = 0.f;
+
+    // the zero line of both planes of the three A buffers
+    if (tid < 96) *(u32x4*)(lds + N_OFF_A + (tid >> 5) * A_BUF + ((tid >> 4) & 1) * A_PLANE + ZROW * 64 + (tid & 15) * 16) = (u32x4){0u, 0u, 0u, 0u};
+
+    const int n_items = t_lo + slot_in_xcd < t_hi ? (t_hi - t_lo - slot_in_xcd + wg_per_xcd - 1) / wg_per_xcd : 0;
+    // what a tile needs before its first phases: the weight tiles of its first three taps, its first two groups' strips in registers
+    auto prologue = [&]() {
+        dma_w(0, 0); dma_w(1, 1); dma_w(2, 2);
+        load_strip(ar, ar2, 0); load_strip(br, br2, 1);
+    };
+    if (n_items > 0) { set_tile(t_lo + slot_in_xcd); prologue(); }
+    for (int k = 0; k < n_items; ++k) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        convert(ar, ar2, 0, 0); convert(ar, ar2, 1, 0); convert(ar, ar2, 2, 0);
+        convert(br, br2, 0, 1); convert(br, br2, 1, 1); convert(br, br2, 2, 1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        { const int a0 = a_addr(0, 0, 0, 0); read_fa(0, 0, a0); read_fa(0, 1, a0); }
+        if (grp == 1) __builtin_amdgcn_s_barrier();
+        for (int g0 = 0; g0 < G; g0 += 3) {
+#pragma unroll
+            for (int j = 0; j < 18; ++j) phase(j, 3 * g0, g0);
+        }
+        if (grp == 0) __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const int em0 = m0, en0 = n0;
+        if (k + 1 < n_items) { set_tile(t_lo + slot_in_xcd + (k + 1) * wg_per_xcd); prologue(); }
+        {
+            constexpr int EP_NB = 2, EP_WCOLS = 64;
+#include "conv3x3_halo8_epilogue.inc"
+        }
+    }
+    __syncthreads();
+    halo8_amax(p, out_amax, (float*)lds, tid);
+}
+
 }  // namespace
 
 // see common.h.  DBMM_E_UNSUPPORTED: the caller falls back to igemm_halo_kernel.
@@ -488,7 +723,7 @@ int dbmm_conv3x3_halo8(const float* x, const float* x_absmax, const void* w_plan
     if (act != DBMM_ACT_NONE && act != DBMM_ACT_RELU) return DBMM_E_UNSUPPORTED;
     if (pool != 0 && pool != 2) return DBMM_E_ARG;
     const int64_t M = B * H * W, K = 9 * Cin;
-    if ((Cout % 256) || (Cin % 64) || w_exp < -40 || w_exp > 40 || M > (INT32_MAX >> 1)) return DBMM_E_UNSUPPORTED;
+    if ((Cout % 128) || (Cin % 64) || w_exp < -40 || w_exp > 40 || M > (INT32_MAX >> 1)) return DBMM_E_UNSUPPORTED;
     if (pool && ((H & 1) || (W & 1))) return DBMM_E_UNSUPPORTED;
     if (!dbmm_aligned16(x) || !dbmm_aligned16(w_plane_f16) || !dbmm_aligned16(y)) return DBMM_E_ALIGN;
     const long long wb = Cout * K * 2;
@@ -498,6 +733,19 @@ int dbmm_conv3x3_halo8(const float* x, const float* x_absmax, const void* w_plan
     p.a = x; p.a_absmax = x_absmax; p.w = (const unsigned short*)w_plane_f16; p.oscale = out_scale; p.bias = bias; p.c = y; p.c_absmax = y_absmax;
     p.a_total = M * Cin * 4; p.w_total = wb; p.ldw = K; p.ldc = Cout;
     p.M = (int)M; p.N = (int)Cout; p.Cin = (int)Cin; p.H = (int)H; p.W = (int)W; p.w_exp = w_exp;
+    hipStream_t s = (hipStream_t)stream;
+    if (Cout % 256) {                                                 // 128-channel tiles (layer 2)
+        p.tiles_n = (int)(Cout / 128);
+        p.n_tiles = (int)((M + 255) / 256) * p.tiles_n;
+        p.n_full = p.n_tiles; p.n_cut = 0; p.n_slices = 1; p.ws = nullptr;
+        const int gridn = p.n_tiles < 256 ? p.n_tiles : 256;
+#define DBMM_H8N(P, A) hipLaunchKernelGGL((conv3x3_halo8n_kernel<P, A>), dim3(gridn), dim3(512), 0, s, p)
+        if (pool) { if (act == DBMM_ACT_RELU) DBMM_H8N(1, 1); else DBMM_H8N(1, 0); }
+        else { if (act == DBMM_ACT_RELU) DBMM_H8N(0, 1); else DBMM_H8N(0, 0); }
+#undef DBMM_H8N
+        DBMM_CHECK_LAUNCH();
+        return DBMM_OK;
+    }
     p.tiles_n = (int)(Cout / 256);
     p.n_tiles = (int)((M + 255) / 256) * p.tiles_n;
     p.n_full = p.n_tiles; p.n_cut = 0; p.n_slices = 1; p.ws = nullptr;
@@ -510,7 +758,6 @@ int dbmm_conv3x3_halo8(const float* x, const float* x_absmax, const void* w_plan
         }
     }
     const int grid = p.n_tiles < 256 ? p.n_tiles : 256;               // persistent: one workgroup per CU
-    hipStream_t s = (hipStream_t)stream;
 #define DBMM_H8(P, A) hipLaunchKernelGGL((conv3x3_halo8_kernel<P, A>), dim3(grid), dim3(512), 0, s, p)
     if (pool) { if (act == DBMM_ACT_RELU) DBMM_H8(1, 1); else DBMM_H8(1, 0); }
     else { if (act == DBMM_ACT_RELU) DBMM_H8(0, 1); else DBMM_H8(0, 0); }

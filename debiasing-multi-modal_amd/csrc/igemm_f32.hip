@@ -1796,16 +1796,17 @@ int conv_impl(const float* x, const float* w, const float* bias, const float* re
             return DBMM_OK;
         }
     }
-    // 3x3 / stride 1 / pad 1 with Cout % 256 == 0 (layers 3 / 4): the eight-phase 256 x 256 halo kernel (conv3x3_halo8.hip); option
+    // 3x3 / stride 1 / pad 1 with Cout % 128 == 0 (layers 2 / 3 / 4): the eight-phase halo kernels (conv3x3_halo8.hip: 256 x 256 tiles, 256 x 128
+    // where Cout % 256 != 0); option
     // tail_split lets it cut the tiles of a short last round along K.  Same-box A/B at B = 1024: profiles/r04_ab_halo8.log.
     // halo8 = 0 never, 1 (default) / 2 wherever the kernel applies.
     if (dbmm_opt(OPT_IGEMM_HALO) && dbmm_opt(OPT_HALO8) && KH == 3 && KW == 3 && stride == 1 && pad == 1 && p.slab == 32 && p.wh &&
-        p.nw == 1 && p.a_absmax && (Cin % 64) == 0 && (Cout % 256) == 0 && p.wh_bytes && !residual && !p.c_full && M >= 16384 &&
+        p.nw == 1 && p.a_absmax && (Cin % 64) == 0 && (Cout % 128) == 0 && p.wh_bytes && !residual && !p.c_full && M >= 16384 &&
         (act == DBMM_ACT_NONE || act == DBMM_ACT_RELU)) {
         const int rc = dbmm_conv3x3_halo8(x, sx.a_absmax, p.wh, p.w_exp, sx.oscale, bias, y, sx.absmax_out, B, H, W, Cin, Cout, act, p.pool2 ? 2 : 0,
                                           dbmm_opt(OPT_TAIL_SPLIT), ws, wsb, stream);
         if (rc == DBMM_OK) {
-            const int c[11] = {256, 256, 4, 2, 1, p.pool2, 32, 1, 7, 0, 1};          // [8] = 7: conv3x3_halo8_kernel, [5] = POOL
+            const int c[11] = {256, (Cout % 256) ? 128 : 256, 4, 2, 1, p.pool2, 32, 1, 7, 0, 1};   // [8] = 7: conv3x3_halo8(n)_kernel, [5] = POOL
             for (int i = 0; i < 11; ++i) g_last_cfg[i] = c[i];
         }
         if (rc != DBMM_E_UNSUPPORTED) return rc;

@@ -79,7 +79,7 @@ def _last_igemm_tag():
     if cfg[8] == 6:        # deep-pipelined parity GEMM (gemm_pair_8ph.hip): <ACT, RES> are not reported
         return "gemm_pair_8ph_kernel"
     if cfg[8] == 7:        # eight-phase 3x3 halo kernel (conv3x3_halo8.hip): <POOL, ACT>, ACT not reported
-        return f"conv3x3_halo8_kernel<{cfg[5]}>"
+        return f"conv3x3_halo8{'n' if cfg[1] == 128 else ''}_kernel<{cfg[5]}>"
     if cfg[8] == 4:        # 3x3 halo kernel: <BN, WAVES_M, WAVES_N, MINB, SK, POOL>
         return f"igemm_halo_kernel<{cfg[1]}, {cfg[2]}, {cfg[3]}, {cfg[7]}, {cfg[9]}, {cfg[5]}>"
     if cfg[8] in (2, 3):   # split-precision kernels: <BM, BN, WAVES_M, WAVES_N, AMODE, MINB, SK, NP, NW, BK, TWO>

@@ -31,7 +31,7 @@ def _case(B, H, W, Cin, Cout, pool, relu, option, check_ref=True, head_rows=None
     option("halo8", 2)
     o8 = ops.conv_bn_act(xd, wp, b.to(DEV), None, 3, 3, 1, 1, act, wl, y_absmax=am8, pool=2 if pool else 1, **kw)
     tag = ops._last_igemm_tag()
-    assert tag == f"conv3x3_halo8_kernel<{1 if pool else 0}>", tag
+    assert tag == f"conv3x3_halo8{'n' if Cout % 256 else ''}_kernel<{1 if pool else 0}>", tag
     option("halo8", 0)
     o = ops.conv_bn_act(xd, wp, b.to(DEV), None, 3, 3, 1, 1, act, wl, y_absmax=am, pool=2 if pool else 1, **kw)
     assert ops._last_igemm_tag().startswith("igemm_halo_kernel<"), ops._last_igemm_tag()
@@ -63,6 +63,13 @@ def _case(B, H, W, Cin, Cout, pool, relu, option, check_ref=True, head_rows=None
     (33, 26, 26, 64, 256, 2, True),          # pooled, ragged (5,577 pooled rows), windows wrap over pooled rows inside a tile
     (700, 6, 6, 64, 256, 2, False),          # 3 windows per pooled row: every tile wraps over rows and images
     (3, 80, 72, 64, 256, 0, True),           # a tile inside one image row block (W > 64)
+    # Cout % 256 != 0: conv3x3_halo8n_kernel (256 x 128 tiles)
+    (32, 28, 28, 128, 128, 0, True),         # layer 2's conv2
+    (8, 56, 56, 128, 128, 2, True),          # layer 2's first conv2: pooled
+    (131, 14, 14, 64, 128, 0, False),        # ragged last tile, one slab pair only, no activation
+    (33, 26, 26, 192, 384, 2, True),         # three N tiles, pooled, ragged, windows wrap over pooled rows
+    (700, 6, 6, 64, 128, 2, False),          # every tile wraps over rows and images
+    (40, 26, 30, 128, 128, 0, True),         # non-square maps
 ])
 def test_halo8_equals_halo_kernel_and_fp64(B, H, W, Cin, Cout, pool, relu, option):
     _case(B, H, W, Cin, Cout, pool, relu, option)
@@ -78,9 +85,9 @@ def test_halo8_tail_split(B, Cin, pool, option):
 
 
 def test_halo8_shapes_it_does_not_take_fall_back(option):
-    """Cout % 256 != 0, Cin % 64 != 0, a residual, or a small problem: the library keeps igemm_halo_kernel (no error, same results)."""
+    """Cout % 128 != 0, Cin % 64 != 0, a residual, or a small problem: the library keeps igemm_halo_kernel (no error, same results)."""
     option("halo8", 2)
-    for B, H, Cin, Cout, res in [(64, 14, 256, 128, False), (64, 14, 96, 256, False), (100, 14, 64, 256, True), (8, 14, 64, 256, False)]:
+    for B, H, Cin, Cout, res in [(64, 14, 256, 64, False), (64, 14, 96, 256, False), (100, 14, 64, 256, True), (8, 14, 64, 256, False)]:
         x = rnd(1, "x", (B, Cin, H, H)); w = rnd(2, "w", (Cout, Cin, 3, 3), (Cin * 9) ** -0.5).half().float()
         xd = x.permute(0, 2, 3, 1).contiguous().to(DEV)
         r = rnd(5, "r", (B, H, H, Cout)).to(DEV) if res else None

@@ -54,7 +54,7 @@ def test_rn50_bs1024_one_call_rows_vs_golden_and_small_batch(golden):
     for want in ("bottleneck_chain_kernel<64, 64, 0, 1, 1>", "bottleneck_chain_kernel<64, 64, 0, 0, 1>", "bottleneck_chain_kernel<64, 128, 1, 0>",
                  "bottleneck_chain_kernel<128, 128, 0, 0, 1>", "conv3x3_c32_kernel<32, 0>", "conv3x3_c32_kernel<64, 1>"):
         assert want in tags, (want, sorted(tags))
-    assert any(t.startswith("igemm_halo_kernel<") and t.endswith(", 1>") for t in tags), sorted(tags)      # pooled halo
+    assert "conv3x3_halo8n_kernel<1>" in tags, sorted(tags)                                                # layer 2's pooled 3x3
     assert "conv3x3_halo8_kernel<0>" in tags and "conv3x3_halo8_kernel<1>" in tags, sorted(tags)           # layers 3 / 4: eight-phase halo
     assert not any(t.startswith("igemm_f32_kernel<") and prof[t][1] > 1e12 for t in tags), sorted(tags)    # no fp32 fallback on a conv
 
