@@ -29,6 +29,10 @@ int dbmm_conv3x3_halo8(const float* x, const float* x_absmax, const void* w_plan
                        float* y, float* y_absmax, int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int act, int pool, int split,
                        void* workspace, size_t workspace_bytes, void* stream);
 
+// gemm_pair_8ph.hip: dbmm_gemm_pair_8ph (include/dbmm.h) with a workspace: the tiles of a short last round are cut along K over the idle CUs
+int dbmm_gemm_pair_8ph_ws(const float* a, int64_t lda, const float* a_absmax, const void* w_plane_f16, int w_exp, int64_t ldw,
+                          const float* out_scale, const float* bias, const float* residual, int64_t ldr, float* c, int64_t ldc,
+                          float* c_absmax, int64_t M, int64_t N, int64_t K, float alpha, int act, void* workspace, size_t workspace_bytes, void* stream);
 // gemm_pair_8ph.hip: dbmm_gemm_dual_bn_act_x2's GEMM on the eight-phase 256 x 256 kernel (arguments checked by the caller)
 int dbmm_gemm_dual_pair_8ph(const float* a, int64_t lda, const float* a_absmax, const void* w_plane_f16, int w_exp, int64_t ldw, int64_t K,
                             const float* out_scale, const float* a2, int64_t lda2, const float* a2_absmax, const void* w2_plane_f16, int64_t ldw2,

@@ -42,6 +42,11 @@ struct PairP {
     const float* a2; const float* a2_absmax; const unsigned short* w2; const float* ratio;
     long long lda2, ldw2, a2_total, w2_total;
     int K2;
+    // the tiles of a short last round, cut along K (see pair_8ph_launch): tiles [0, n_full) are computed whole; tile n_full + l (l < n_cut) by
+    // n_slices workgroups over a share of the loop trips each, which leave their accumulators in ws[(l * n_slices + s)][32][512][4] for
+    // gemm_pair_8ph_fixup_kernel.  Not with TWO.
+    int n_full, n_cut, n_slices;
+    float* ws;
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t desc(const void* base, long long total, long long shift) {
@@ -82,7 +87,7 @@ __global__ __launch_bounds__(512, 1) void gemm_pair_8ph_kernel(const PairP p) {
     const int fr = lane & 31, fh = lane >> 5;
     // this workgroup's tiles: its XCD's contiguous range (xcd_remap's split), walked with the stride of the XCD's workgroups
     const int nwg = gridDim.x, xcd = blockIdx.x & 7, slot_in_xcd = blockIdx.x >> 3, wg_per_xcd = (nwg - xcd + 7) >> 3;
-    const int tq = p.n_tiles >> 3, trm = p.n_tiles & 7;
+    const int tq = p.n_full >> 3, trm = p.n_full & 7;
     const int t_lo = xcd < trm ? xcd * (tq + 1) : trm * (tq + 1) + (xcd - trm) * tq, t_hi = t_lo + tq + (xcd < trm ? 1 : 0);
     const __amdgpu_buffer_rsrc_t rsA0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.a, 0, 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsW0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, 0, 0x00020000);
@@ -248,27 +253,40 @@ __global__ __launch_bounds__(512, 1) void gemm_pair_8ph_kernel(const PairP p) {
     const int wm0 = wr * 64, wn0 = wc * 128;
     float out_amax = 0.f;
 
-    int tile = t_lo + slot_in_xcd;
-    // the W half-tiles a tile needs before its first phases: Bh0(0), Bh1(0) into buffer 0, Bh0(1) into buffer 1
-    auto prologue_w = [&]() { dma_w(0, 0, 0); dma_w(1, 0, 0); dma_w(0, 1, 1); };
-    if (tile < t_hi) { set_tile(tile); prologue_w(); }
-    for (; tile < t_hi; tile += wg_per_xcd) {
+    // Work items of this workgroup: its whole tiles (all K tiles), then -- if there are cut tiles and this workgroup's index is below
+    // n_cut * n_slices -- one slice: a cut tile's loop trips [s T / S, (s + 1) T / S)
+    const int n_whole = t_lo + slot_in_xcd < t_hi ? (t_hi - t_lo - slot_in_xcd + wg_per_xcd - 1) / wg_per_xcd : 0;
+    const bool has_slice = !TWO && (int)blockIdx.x < p.n_cut * p.n_slices;
+    const int n_items = n_whole + (has_slice ? 1 : 0);
+    int tb = 0, te = nT;                                              // the current item's K tiles [tb, te), both even
+    auto set_item = [&](int k) {
+        if (k < n_whole) { tb = 0; te = nT; set_tile(t_lo + slot_in_xcd + k * wg_per_xcd); }
+        else {
+            const int l = blockIdx.x / p.n_slices, sl = blockIdx.x - l * p.n_slices, T = nT >> 1;
+            tb = 2 * (sl * T / p.n_slices); te = 2 * ((sl + 1) * T / p.n_slices);
+            set_tile(p.n_full + l);
+        }
+    };
+    // the W half-tiles an item needs before its first phases: Bh0, Bh1 of its first K tile into buffer 0, Bh0 of the second into buffer 1
+    auto prologue_w = [&]() { dma_w(0, tb, 0); dma_w(1, tb, 0); dma_w(0, tb + 1, 1); };
+    if (n_items > 0) { set_item(0); prologue_w(); }
+    for (int k = 0; k < n_items; ++k) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-        // the activations of the first K tiles go through registers: Ah0(0) is converted here, Ah1(0) / Ah0(1) / Ah1(1) wait in
-        // their register sets for the phases that convert them (p0 / p2 of tile 0, p0 of tile 1)
-        load_a(0, 0, 0); load_a(1, 0, 0); load_a(0, 1, 1); load_a(1, 1, 1);
-        convert_a(0, 0, 0, 0);
-        // everything older than those loads (the W prologue issued before the previous tile's epilogue, that epilogue's loads and
+        // the activations of the first K tiles go through registers: Ah0 of the first is converted here, its Ah1 and the second tile's halves
+        // wait in their register sets for the phases that convert them (p0 / p2 of the first tile, p0 of the second)
+        load_a(0, tb, 0); load_a(1, tb, 0); load_a(0, tb + 1, 1); load_a(1, tb + 1, 1);
+        convert_a(0, 0, 0, tb);
+        // everything older than those loads (the W prologue issued before the previous item's epilogue, that epilogue's loads and
         // stores) has been retired by the wait the conversion needed; the LDS stores are waited for before the barrier
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         if (grp == 1) __builtin_amdgcn_s_barrier();                   // the second wave group runs one barrier behind
-        for (int t2 = 0; t2 < nT; t2 += 2) {
+        for (int t2 = tb; t2 < te; t2 += 2) {
             if (TWO && t2 == nT2) {                                   // the second pair's sums -> the main pair's scale (both K2 / 32 and t2 are even)
                 const f32x4 rr = *(const f32x4*)(lds + 2 * BUF + tid * 16);
 #pragma unroll
@@ -282,10 +300,25 @@ __global__ __launch_bounds__(512, 1) void gemm_pair_8ph_kernel(const PairP p) {
             for (int j = 0; j < 8; ++j) phase(j, t2);
         }
         if (grp == 0) __builtin_amdgcn_s_barrier();
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the look-ahead loads / DMA past this tile's last K tile
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the look-ahead loads / DMA past this item's last K tile
         __builtin_amdgcn_s_barrier();                                 // every wave is done with the ring
         const int em0 = m0, en0 = n0;
-        if (tile + wg_per_xcd < t_hi) { set_tile(tile + wg_per_xcd); prologue_w(); }   // in flight during the epilogue below
+        const bool whole = k < n_whole;
+        if (k + 1 < n_items) { set_item(k + 1); prologue_w(); }       // in flight during the epilogue below
+        if (!whole) {                                                 // a slice: the raw accumulators, 16 B per thread and store
+            const __amdgpu_buffer_rsrc_t rsP = __builtin_amdgcn_make_buffer_rsrc((void*)(p.ws + (size_t)blockIdx.x * (128 * 512)), 0, 128 * 512 * 4, 0x00020000);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const u32x4 v = {__float_as_uint(acc[i][j][4 * q]), __float_as_uint(acc[i][j][4 * q + 1]), __float_as_uint(acc[i][j][4 * q + 2]),
+                                         __float_as_uint(acc[i][j][4 * q + 3])};
+                        __builtin_amdgcn_raw_buffer_store_b128(v, rsP, (unsigned)tid * 16u, (unsigned)(((i * 4 + j) * 4 + q) * 8192), 0);
+                    }
+            continue;
+        }
 
         // epilogue straight from the accumulators: lane (fr, fh) holds column 32 j + fr of the wave's 128 (blocks j = 0..3), rows
         // 32 i + (r & 3) + 8 (r >> 2) + 4 fh: one register = two 128-B row segments per wave instruction.  Rows >= M fall off
@@ -367,9 +400,88 @@ __global__ __launch_bounds__(512, 1) void gemm_pair_8ph_kernel(const PairP p) {
 }  // namespace
 
 namespace {
-int pair_8ph_launch(PairP& p, int act, bool two, void* stream) {
+// The cut tiles: sum the slices' accumulators in slice order (same thread <-> element mapping as the main kernel), then the main kernel's
+// epilogue for ONE 32 x 32 block (i, j) of every wave's 64 x 128 per workgroup -- grid (n_cut, 8).
+template <int ACT, int RES>
+__global__ __launch_bounds__(512) void gemm_pair_8ph_fixup_kernel(const PairP p) {
+    __shared__ float red[8];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, wr = wid >> 1, wc = wid & 1, fr = lane & 31, fh = lane >> 5;
+    const int tile = p.n_full + blockIdx.x, m0 = (tile / p.tiles_n) * 256, n0 = (tile % p.tiles_n) * 256;
+    const int bi = blockIdx.y >> 2, bj = blockIdx.y & 3;
+    f32x16 a;
+    const f32x4* src = (const f32x4*)(p.ws + (size_t)blockIdx.x * p.n_slices * (128 * 512)) + (size_t)blockIdx.y * 4 * 512 + tid;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 v = src[q * 512];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a[4 * q + e] = v[e];
+    }
+    for (int sl = 1; sl < p.n_slices; ++sl) {
+        src += 32 * 512;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 v = src[q * 512];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a[4 * q + e] += v[e];
+        }
+    }
+    const int s_a = scale_exp(*p.a_absmax);
+    const int n = n0 + wc * 128 + 32 * bj + fr, mw = m0 + wr * 64;
+    const float sv = (p.oscale ? p.oscale[n] : 1.f) * pow2f(-s_a - p.w_exp), bv = p.bias ? p.bias[n] : 0.f;
+    const long long rows_left = (long long)p.M - mw;
+    const __amdgpu_buffer_rsrc_t rsC = desc(p.c, rows_left > 0 ? ((rows_left - 1) * p.ldc + p.N) * 4 + (long long)mw * p.ldc * 4 : 0, (long long)mw * p.ldc * 4);
+    const __amdgpu_buffer_rsrc_t rsR = RES ? desc(p.res, rows_left > 0 ? ((rows_left - 1) * p.ldr + p.N) * 4 + (long long)mw * p.ldr * 4 : 0,
+                                                  (long long)mw * p.ldr * 4)
+                                           : __builtin_amdgcn_make_buffer_rsrc((void*)p.c, 0, 0, 0x00020000);
+    const unsigned vc = (unsigned)((4 * fh * p.ldc + n) * 4), vr = (unsigned)((4 * fh * p.ldr + n) * 4);
+    const int row_lim = (int)(rows_left < 1024 ? rows_left : 1024) - 4 * fh;
+    float rv[16], out_amax = 0.f;
+    if constexpr (RES) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ru = 32 * bi + (r & 3) + 8 * (r >> 2);
+            rv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsR, ru < row_lim ? vr : 0x80000000u, (unsigned)(ru * p.ldr * 4), 0));
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float v = (a[r] * sv + bv) * p.alpha;
+        if constexpr (RES) v += rv[r];
+        if (ACT == DBMM_ACT_RELU) v = fmaxf(v, 0.f);
+        else if (ACT == DBMM_ACT_QUICKGELU) v = v / (1.f + expf(-1.702f * v));
+        const int ru = 32 * bi + (r & 3) + 8 * (r >> 2);
+        const bool valid = ru < row_lim;
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsC, valid ? vc : 0x80000000u, (unsigned)(ru * p.ldc * 4), 0);
+        if (valid) out_amax = fmaxf(out_amax, fabsf(v));
+    }
+    if (p.c_absmax) {
+        out_amax = wave_max(out_amax);
+        if (lane == 0) red[wid] = out_amax;
+        __syncthreads();
+        if (tid == 0) {
+            float m = red[0];
+#pragma unroll
+            for (int i = 1; i < 8; ++i) m = fmaxf(m, red[i]);
+            if (m > *(volatile const float*)p.c_absmax) atomicMax((unsigned*)p.c_absmax, __float_as_uint(m));
+        }
+    }
+}
+
+// Tile quantisation: the persistent grid works in rounds of 256 tiles.  With a workspace the tiles of a short last round (at most 128 of them)
+// are cut along K into S = min(256 / n_cut, trips) slices, one workgroup each, and a small second launch sums the slices and runs the
+// epilogue (as conv3x3_halo8.hip does).
+int pair_8ph_launch(PairP& p, int act, bool two, void* workspace, size_t workspace_bytes, void* stream) {
     p.tiles_n = p.N / 256;
     p.n_tiles = ((p.M + 255) / 256) * p.tiles_n;
+    p.n_full = p.n_tiles; p.n_cut = 0; p.n_slices = 1; p.ws = nullptr;
+    const int rem = p.n_tiles % 256, trips = p.K / 64;
+    if (!two && workspace && dbmm_aligned16(workspace) && p.n_tiles > 256 && rem != 0 && rem <= 128) {
+        int S = 256 / rem;
+        S = S < trips ? S : trips;
+        if (S >= 2 && (size_t)rem * S * (128 * 512 * sizeof(float)) <= workspace_bytes) {
+            p.n_full = p.n_tiles - rem; p.n_cut = rem; p.n_slices = S; p.ws = (float*)workspace;
+        }
+    }
     const int grid = p.n_tiles < 256 ? p.n_tiles : 256;               // persistent: one workgroup per CU
     hipStream_t s = (hipStream_t)stream;
 #define DBMM_P8(A, R, T) hipLaunchKernelGGL((gemm_pair_8ph_kernel<A, R, T>), dim3(grid), dim3(512), 0, s, p)
@@ -378,14 +490,21 @@ int pair_8ph_launch(PairP& p, int act, bool two, void* stream) {
     else { if (act == 0) DBMM_P8(0, 0, 0); else if (act == 1) DBMM_P8(1, 0, 0); else DBMM_P8(2, 0, 0); }
 #undef DBMM_P8
     DBMM_CHECK_LAUNCH();
+    if (p.n_cut) {
+#define DBMM_P8F(A, R) hipLaunchKernelGGL((gemm_pair_8ph_fixup_kernel<A, R>), dim3(p.n_cut, 8), dim3(512), 0, s, p)
+        if (p.res) { if (act == 0) DBMM_P8F(0, 1); else if (act == 1) DBMM_P8F(1, 1); else DBMM_P8F(2, 1); }
+        else { if (act == 0) DBMM_P8F(0, 0); else if (act == 1) DBMM_P8F(1, 0); else DBMM_P8F(2, 0); }
+#undef DBMM_P8F
+        DBMM_CHECK_LAUNCH();
+    }
     return DBMM_OK;
 }
 }  // namespace
 
-// see include/dbmm.h
-extern "C" int dbmm_gemm_pair_8ph(const float* a, int64_t lda, const float* a_absmax, const void* w_plane_f16, int w_exp, int64_t ldw,
-                                  const float* out_scale, const float* bias, const float* residual, int64_t ldr, float* c, int64_t ldc,
-                                  float* c_absmax, int64_t M, int64_t N, int64_t K, float alpha, int act, void* stream) {
+// common.h: dbmm_gemm_pair_8ph with a workspace for the K cut of a short last round (null: one launch)
+int dbmm_gemm_pair_8ph_ws(const float* a, int64_t lda, const float* a_absmax, const void* w_plane_f16, int w_exp, int64_t ldw,
+                          const float* out_scale, const float* bias, const float* residual, int64_t ldr, float* c, int64_t ldc,
+                          float* c_absmax, int64_t M, int64_t N, int64_t K, float alpha, int act, void* workspace, size_t workspace_bytes, void* stream) {
     if (!a || !a_absmax || !w_plane_f16 || !c) return DBMM_E_ARG;
     if (M <= 0 || N <= 0 || K <= 0 || M > INT32_MAX || N > INT32_MAX || K > INT32_MAX) return DBMM_E_SHAPE;
     if (act < 0 || act > 2) return DBMM_E_ARG;
@@ -400,7 +519,15 @@ extern "C" int dbmm_gemm_pair_8ph(const float* a, int64_t lda, const float* a_ab
     p.c = c; p.c_absmax = c_absmax;
     p.lda = lda; p.ldw = ldw; p.ldr = ldr; p.ldc = ldc; p.a_total = ((M - 1) * lda + K) * 4; p.w_total = wb;
     p.M = (int)M; p.N = (int)N; p.K = (int)K; p.w_exp = w_exp; p.alpha = alpha;
-    return pair_8ph_launch(p, act, false, stream);
+    return pair_8ph_launch(p, act, false, workspace, workspace_bytes, stream);
+}
+
+// see include/dbmm.h
+extern "C" int dbmm_gemm_pair_8ph(const float* a, int64_t lda, const float* a_absmax, const void* w_plane_f16, int w_exp, int64_t ldw,
+                                  const float* out_scale, const float* bias, const float* residual, int64_t ldr, float* c, int64_t ldc,
+                                  float* c_absmax, int64_t M, int64_t N, int64_t K, float alpha, int act, void* stream) {
+    return dbmm_gemm_pair_8ph_ws(a, lda, a_absmax, w_plane_f16, w_exp, ldw, out_scale, bias, residual, ldr, c, ldc, c_absmax, M, N, K, alpha, act, nullptr, 0,
+                                 stream);
 }
 
 // common.h: the dual-source GEMM of dbmm_gemm_dual_bn_act_x2 on this kernel (TWO = 1).  DBMM_E_UNSUPPORTED: not this kernel's shape.
@@ -418,5 +545,5 @@ int dbmm_gemm_dual_pair_8ph(const float* a, int64_t lda, const float* a_absmax, 
     p.M = (int)M; p.N = (int)N; p.K = (int)K; p.w_exp = w_exp; p.alpha = 1.f;
     p.a2 = a2; p.a2_absmax = a2_absmax; p.w2 = (const unsigned short*)w2_plane_f16; p.ratio = ratio;
     p.lda2 = lda2; p.ldw2 = ldw2; p.a2_total = ((M - 1) * lda2 + K2) * 4; p.w2_total = wb2; p.K2 = (int)K2;
-    return pair_8ph_launch(p, act, true, stream);
+    return pair_8ph_launch(p, act, true, nullptr, 0, stream);
 }

@@ -1649,19 +1649,21 @@ int gemm_impl(const float* a, int64_t lda, int trans_a, const float* w, int64_t 
         // wide GEMMs (transformer projections): a 128 x 256 tile halves the per-FLOP cost of fetching and splitting the fp32
         // activations (the A tile is shared by twice as many output columns); 128 accumulator registers, 2 workgroups per CU.
         // DBMM_IGEMM_BN256=0 disables.
-        // The deep-pipelined 256 x 256 kernel (gemm_pair_8ph.hip) where it measured ahead of this one on the ViT-L/14@336
-        // shapes (same box, TF fp32-equivalent): N 3072 K 1024 389 -> 466, N 4096 K 1024 QuickGELU 426 -> 455, N 1024 K 4096
-        // + residual 501 -> 529; it loses where N is narrow and K short (N 1024 K 1024 + residual 421 -> 394, the ViT-B/32
-        // shapes 0.83 - 1.0 x): its in-order prefetch is four to five phases deep and a tile's first round trip is exposed.
-        // DBMM_GEMM_8PH = 0 never, 1 (default) by that rule, 2 wherever the kernel applies (the tests run all three).
+        // The deep-pipelined 256 x 256 kernel (gemm_pair_8ph.hip).  Round 4, with the tiles of a short last round cut along K (same box,
+        // tools/bench_gemm_pair.py, profiles/r04_ab_gemm_pair_8ph.log, TF fp32-equivalent): ViT-B/32 at 512 images qkv 353 -> 431, c_fc 349 -> 397,
+        // c_proj 406 -> 477; ViT-L/14@336 at 256 images 449 -> 522 / 433 -> 470 / 505 -> 559, out_proj (N = K = 1024) 425 -> 455; text tower
+        // qkv 310 -> 385.  It still loses where N is narrow AND K short -- the out projections of the 768- and 512-wide towers (296 -> 274,
+        // 303 -> 262): 12 / 8 K tiles per 256 x 256 tile are prologue and epilogue.
+        // gemm_8ph = 0 never, 1 (default) by that rule (K >= 1024 or N >= 1536), 2 wherever the kernel applies (the tests run all three).
         {
             const int m8 = dbmm_opt(OPT_GEMM_8PH);
-            const bool pays = m8 == 2 || (m8 == 1 && ((N >= 3072 && K >= 1024) || K >= 4096));
+            const bool pays = m8 == 2 || (m8 == 1 && (K >= 1024 || N >= 1536));
             if (pays && p.wh && p.nw == 1 && p.a_absmax && (N % 256) == 0 && (K % 64) == 0 && M >= 16384 && (lda & 3) == 0 &&
                 (ldw & 7) == 0 && dbmm_aligned16(c) && (!residual || dbmm_aligned16(residual)) && 256 * (lda > ldc ? lda : ldc) * 4 < 0x7FFFFFF0LL &&
                 p.wh_bytes) {
-                const int rc = dbmm_gemm_pair_8ph(a, lda, sx.a_absmax, p.wh, p.w_exp, ldw, sx.oscale, bias, residual, ldr, c, ldc, sx.absmax_out,
-                                                  M, N, K, alpha, act, stream);
+                const bool cut = dbmm_opt(OPT_TAIL_SPLIT) != 0;                       // a short last round's tiles cut along K (needs the workspace)
+                const int rc = dbmm_gemm_pair_8ph_ws(a, lda, sx.a_absmax, p.wh, p.w_exp, ldw, sx.oscale, bias, residual, ldr, c, ldc, sx.absmax_out,
+                                                     M, N, K, alpha, act, cut ? ws : nullptr, cut ? wsb : 0, stream);
                 if (rc == DBMM_OK) {
                     const int cfg[11] = {256, 256, 2, 4, 0, 0, 32, 1, 6, 0, 1};      // [8] = 6: gemm_pair_8ph_kernel
                     for (int i = 0; i < 11; ++i) g_last_cfg[i] = cfg[i];
@@ -1738,29 +1740,18 @@ int conv_impl(const float* x, const float* w, const float* bias, const float* re
             // conv1x1_8ph = 0 never, 1 (default) by that rule, 2 wherever the kernel applies.
             const int m8 = sx.no_8ph ? 0 : dbmm_opt(OPT_CONV1X1_8PH);
             const long long tn8 = Cout / 256, mt8 = (M + 255) / 256, t8 = mt8 * tn8;
-            // Tile quantisation (option tail_split): whole rounds of 256 tiles on the eight-phase kernel, the rows of a short last round on
-            // the 128 x 128 kernel -- layer 3's conv1 (784 tiles = 3.06 rounds) then costs 3 rounds + a 64-tile launch instead of 4.
-            const long long rem8 = t8 % NUM_CUS, mt_full = (t8 / NUM_CUS) * NUM_CUS / (tn8 > 0 ? tn8 : 1);
-            const bool can_split = dbmm_opt(OPT_TAIL_SPLIT) && tn8 > 0 && t8 > NUM_CUS && rem8 != 0 && rem8 <= NUM_CUS / 2 && mt_full >= 1 &&
-                                   mt_full < mt8 && ((M - mt_full * 256 + 127) / 128) * ((Cout + 127) / 128) <= 2 * NUM_CUS;
-            const bool pays = m8 == 2 || (m8 == 1 && Cin >= 512 && Cout <= 512 && (Cout == 512 || t8 >= 8 * NUM_CUS || can_split));
+            // Tile quantisation (option tail_split): the tiles of a short last round (at most 128) are cut along K over the idle CUs inside
+            // dbmm_gemm_pair_8ph_ws -- layer 3's conv1 (784 tiles = 3.06 rounds) then costs 3 rounds + 16 x 16 slices instead of 4 rounds.
+            const long long rem8 = t8 % NUM_CUS;
+            const bool cut = dbmm_opt(OPT_TAIL_SPLIT) && ws && t8 > NUM_CUS && rem8 != 0 && rem8 <= NUM_CUS / 2;
+            const bool pays = m8 == 2 || (m8 == 1 && Cin >= 512 && Cout <= 512 && (Cout == 512 || t8 >= 8 * NUM_CUS || cut));
             if (pays && p.wh && p.nw == 1 && p.a_absmax && !p.pool2 && (Cout % 256) == 0 && (Cin % 64) == 0 && M >= 16384 && p.wh_bytes &&
                 dbmm_aligned16(y) && (!residual || dbmm_aligned16(residual)) && 256 * (Cin > Cout ? Cin : Cout) * 4 < 0x7FFFFFF0LL) {
-                // (split only the shape that needs it to get here at all: on shapes the rule already takes, e.g. layer 4's first conv1 with
-                //  6.125 rounds, the second launch cost more than the saved fraction of a round: 0.467 -> 0.482 ms)
-                const int64_t m_head = (can_split && m8 == 1 && !(Cout == 512 || t8 >= 8 * NUM_CUS)) ? mt_full * 256 : M;
-                const int rc = dbmm_gemm_pair_8ph(x, Cin, sx.a_absmax, p.wh, p.w_exp, K, sx.oscale, bias, residual, Cout, y, Cout, sx.absmax_out,
-                                                  m_head, Cout, K, 1.f, act, stream);
+                const int rc = dbmm_gemm_pair_8ph_ws(x, Cin, sx.a_absmax, p.wh, p.w_exp, K, sx.oscale, bias, residual, Cout, y, Cout, sx.absmax_out,
+                                                     M, Cout, K, 1.f, act, cut ? ws : nullptr, cut ? wsb : 0, stream);
                 if (rc == DBMM_OK) {
                     const int cfg[11] = {256, 256, 2, 4, 0, 0, 32, 1, 6, 0, 1};      // [8] = 6: gemm_pair_8ph_kernel
                     for (int i = 0; i < 11; ++i) g_last_cfg[i] = cfg[i];
-                    if (m_head < M) {                                                // the tail rows as their own 1x1 conv on 128 x 128 tiles
-                        SplitArgs st = sx; st.no_8ph = true;
-                        const int rt = conv_impl(x + m_head * Cin, w, bias, residual ? residual + m_head * Cout : nullptr, y + m_head * Cout, 1, 1,
-                                                 M - m_head, Cin, Cout, 1, 1, 1, 0, act, w_layout, ws, wsb, stream, st);
-                        for (int i = 0; i < 11; ++i) g_last_cfg[i] = cfg[i];         // (the launch is reported as the eight-phase kernel)
-                        return rt;
-                    }
                 }
                 if (rc != DBMM_E_UNSUPPORTED) return rc;
             }

@@ -637,7 +637,10 @@ def test_direct_epilogue_equals_staged_epilogue(M, N, K, res, act, option):
 
 
 @pytest.mark.parametrize("M,N,K,res,act", [(16384 + 77, 512, 128, True, 2), (25600, 2304, 768, False, 0), (20000, 1024, 4096, True, 0), (16500, 256, 256, False, 0),
-                                           (577 * 32, 3072, 1024, False, 2), (16384, 768, 3072, True, 1)])
+                                           (577 * 32, 3072, 1024, False, 2), (16384, 768, 3072, True, 1),
+                                           # a short last round cut along K (tail_split): 274 tiles = 256 + 18 x 8 slices of one trip; 300 tiles =
+                                           # 256 + 44 x 5 slices of 2 / 3 trips (the ViT-B/32 projections at 512 images); above: 316 = 256 + 60 x 4, 876 = 768 + 108 x 2
+                                           (70000, 256, 512, True, 1), (25600, 768, 768, True, 0)])
 def test_gemm_pair_deep_pipelined_kernel(M, N, K, res, act, option):
     """parity-mode GEMM on the 256 x 256 eight-phase kernel (gemm_pair_8ph.hip; N % 256 == 0, K % 64 == 0, M >= 16384):
     element-wise against fp64 -- a staging race would show as a few wrong tiles -- over repeated launches, against the
