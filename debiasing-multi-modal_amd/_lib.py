@@ -115,9 +115,11 @@ _SIGS = {
     "dbmm_bottleneck_chain_x2": [_P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _L, _L, _L, _L, _L, _L, _P],
     "dbmm_bottleneck_chain_dual_x2": [_P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _L, _L, _L, _L, _L, _P],
     "dbmm_gemm_f16": [_P, _L, _P, _L, _P, _P, _L, _P, _L, _L, _L, _L, _I, _P],
+    "dbmm_gemm_f16_ws": [_P, _L, _P, _L, _P, _P, _L, _P, _L, _L, _L, _L, _I, _P, _Z, _P],
     "dbmm_mha_core_f16": [_P, _P, _L, _L, _L, _L, _I, _P],
     "dbmm_layernorm_f16": [_P, _L, _P, _P, _P, _L, _L, _L, _F, _P],
     "dbmm_conv1x1_bn_act_f16": [_P, _P, _P, _P, _P, _P, _L, _L, _L, _I, _P],
+    "dbmm_conv1x1_bn_act_f16_ws": [_P, _P, _P, _P, _P, _P, _L, _L, _L, _I, _P, _Z, _P],
     "dbmm_conv3x3_bn_relu_f16": [_P, _P, _P, _P, _P, _L, _L, _L, _L, _L, _I, _P],
     "dbmm_conv_stem_s2_f16": [_P, _I, _P, _P, _P, _L, _L, _L, _L, _P],
     "dbmm_avgpool2_f16": [_P, _P, _L, _L, _L, _L, _P],

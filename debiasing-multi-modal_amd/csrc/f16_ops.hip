@@ -66,6 +66,11 @@ struct GemmHP {
     int M, N, K, act, tiles_n, n_tiles;
     const float* oscale;        // optional per-output-channel scale of the accumulator (eval-mode BatchNorm of a 1x1 conv)
     int res_first;              // 0: act(acc * s + b) + residual (transformer blocks); 1: act(acc * s + b + residual) (bottleneck conv3)
+    // gemm_f16_8ph_kernel: the tiles of a short last round cut along K (gemm_f16_impl): tiles [0, n_full) whole; tile n_full + l (l < n_cut)
+    // by n_slices workgroups over a share of the loop trips each, accumulators left in ws[(l * n_slices + s)][32][512][4] for
+    // gemm_f16_8ph_fixup_kernel.  Kernels that do not cut ignore these (n_full is only read by the eight-phase kernel).
+    int n_full, n_cut, n_slices;
+    float* ws;
 };
 
 constexpr int GBM = 128;
@@ -292,7 +297,7 @@ __global__ __launch_bounds__(512, 1) void gemm_f16_8ph_kernel(const GemmHP p) {
     const int fr = lane & 31, fh = lane >> 5;
     // this workgroup's tiles: the XCD's contiguous range (xcd_remap's split), walked with the stride of the XCD's workgroups
     const int nwg = gridDim.x, xcd = blockIdx.x & 7, slot_in_xcd = blockIdx.x >> 3, wg_per_xcd = (nwg - xcd + 7) >> 3;
-    const int tq = p.n_tiles >> 3, trm = p.n_tiles & 7;
+    const int tq = p.n_full >> 3, trm = p.n_full & 7;
     const int t_lo = xcd < trm ? xcd * (tq + 1) : trm * (tq + 1) + (xcd - trm) * tq, t_hi = t_lo + tq + (xcd < trm ? 1 : 0);
     const __amdgpu_buffer_rsrc_t rsA0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.a, 0, 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsW0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, 0, 0x00020000);
@@ -392,14 +397,27 @@ __global__ __launch_bounds__(512, 1) void gemm_f16_8ph_kernel(const GemmHP p) {
         __builtin_amdgcn_s_barrier();
     };
 
-    // prologue of a tile: stages 0 .. 7 = its first two K tiles, both buffers
+    // Work items of this workgroup: its whole tiles (all K tiles), then -- if there are cut tiles and this workgroup's index is below
+    // n_cut * n_slices -- one slice: a cut tile's loop trips [s T / S, (s + 1) T / S)
+    const int n_whole = t_lo + slot_in_xcd < t_hi ? (t_hi - t_lo - slot_in_xcd + wg_per_xcd - 1) / wg_per_xcd : 0;
+    const bool has_slice = (int)blockIdx.x < p.n_cut * p.n_slices;
+    const int n_items = n_whole + (has_slice ? 1 : 0);
+    int tb = 0, te = nT;                                              // the current item's K tiles [tb, te), both even
+    auto set_item = [&](int k) {
+        if (k < n_whole) { tb = 0; te = nT; set_tile(t_lo + slot_in_xcd + k * wg_per_xcd); }
+        else {
+            const int l = blockIdx.x / p.n_slices, sl = blockIdx.x - l * p.n_slices, T = nT >> 1;
+            tb = 2 * (sl * T / p.n_slices); te = 2 * ((sl + 1) * T / p.n_slices);
+            set_tile(p.n_full + l);
+        }
+    };
+    // prologue of an item: stages 0 .. 7 = its first two K tiles, both buffers
     auto prologue = [&]() {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) stage(q & 3, (q >> 2) & 1, q >> 2);
+        for (int q = 0; q < 8; ++q) stage(q & 3, (q >> 2) & 1, tb + (q >> 2));
     };
     const int wm0 = wr * 128, wn0 = wc * 64;
 
-    int tile = t_lo + slot_in_xcd;
     bool first_tile = true;
     // De-phase the workgroups.  Every tile takes the same time, so persistent workgroups that start together reach their
     // epilogues together: 256 x (128 KB of C + residual + the next A tile) hit HBM in one burst while it idles during
@@ -411,8 +429,8 @@ __global__ __launch_bounds__(512, 1) void gemm_f16_8ph_kernel(const GemmHP p) {
         const int units = (int)((long long)grp * nT * 1400 / ngrp) >> 10;       // ~1400 cycles per K tile, s_sleep 16 = 1024 cycles
         for (int u = 0; u < units; ++u) __builtin_amdgcn_s_sleep(16);
     }
-    if (tile < t_hi) { set_tile(tile); prologue(); }
-    for (; tile < t_hi; tile += wg_per_xcd) {
+    if (n_items > 0) { set_item(0); prologue(); }
+    for (int k = 0; k < n_items; ++k) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -428,16 +446,31 @@ __global__ __launch_bounds__(512, 1) void gemm_f16_8ph_kernel(const GemmHP p) {
     __builtin_amdgcn_s_barrier();
     if (wr == 1) __builtin_amdgcn_s_barrier();                        // the second wave row runs one barrier behind
 #pragma unroll
-    for (int j = 0; j < 8; ++j) phase(j, 0, true);
-    for (int t2 = 2; t2 < ((GF16_ABL & 8) ? 2 : nT); t2 += 2) {
+    for (int j = 0; j < 8; ++j) phase(j, tb, true);
+    for (int t2 = tb + 2; t2 < ((GF16_ABL & 8) ? tb + 2 : te); t2 += 2) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) phase(j, t2, false);
     }
     if (wr == 0) __builtin_amdgcn_s_barrier();
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // the (zero-extent) tail DMA of this tile
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // the look-ahead DMA past this item's last K tile
     __builtin_amdgcn_s_barrier();                                     // every wave is done with the ring
     const int em0 = m0, en0 = n0;
-    if (tile + wg_per_xcd < t_hi) { set_tile(tile + wg_per_xcd); prologue(); }   // in flight during the epilogue below
+    const bool whole = k < n_whole;
+    if (k + 1 < n_items) { set_item(k + 1); prologue(); }             // in flight during the epilogue below
+    if (!whole) {                                                     // a slice: the raw accumulators, 16 B per thread and store
+        const __amdgpu_buffer_rsrc_t rsP = __builtin_amdgcn_make_buffer_rsrc((void*)(p.ws + (size_t)blockIdx.x * (128 * 512)), 0, 128 * 512 * 4, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const u32x4 v = {__float_as_uint(acc[i][j][4 * q]), __float_as_uint(acc[i][j][4 * q + 1]), __float_as_uint(acc[i][j][4 * q + 2]),
+                                     __float_as_uint(acc[i][j][4 * q + 3])};
+                    __builtin_amdgcn_raw_buffer_store_b128(v, rsP, (unsigned)tid * 16u, (unsigned)(((i * 2 + j) * 4 + q) * 8192), 0);
+                }
+        continue;
+    }
 
     // epilogue straight from the accumulators, no LDS: lane (fr, fh) holds output columns 2 fr and 2 fr + 1 (blocks j = 0 / 1,
     // see the stager's column map) of rows 32 i + (r & 3) + 8 (r >> 2) + 4 fh: one packed dword per register, 32 lanes = one
@@ -494,6 +527,59 @@ __global__ __launch_bounds__(512, 1) void gemm_f16_8ph_kernel(const GemmHP p) {
         };
         if (rows_left >= 128) epilogue(std::true_type{}); else epilogue(std::false_type{});
     }
+    }
+}
+
+// The cut tiles of gemm_f16_8ph_kernel: sum the slices' accumulators in slice order (same thread <-> element mapping), then that kernel's
+// epilogue for ONE 32-row block i of every wave's 128 x 64 per workgroup -- grid (n_cut, 4).
+template <int ACT, int RES>
+__global__ __launch_bounds__(512) void gemm_f16_8ph_fixup_kernel(const GemmHP p) {
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, wr = wid >> 2, wc = wid & 3, fr = lane & 31, fh = lane >> 5;
+    const int tile = p.n_full + blockIdx.x, m0 = (tile / p.tiles_n) * 256, n0 = (tile % p.tiles_n) * 256, bi = blockIdx.y;
+    f32x16 a0, a1;
+    const f32x4* src = (const f32x4*)(p.ws + (size_t)blockIdx.x * p.n_slices * (128 * 512)) + (size_t)bi * 8 * 512 + tid;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 v = src[q * 512], u = src[(4 + q) * 512];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { a0[4 * q + e] = v[e]; a1[4 * q + e] = u[e]; }
+    }
+    for (int sl = 1; sl < p.n_slices; ++sl) {
+        src += 32 * 512;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 v = src[q * 512], u = src[(4 + q) * 512];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { a0[4 * q + e] += v[e]; a1[4 * q + e] += u[e]; }
+        }
+    }
+    const int n = n0 + wc * 64 + 2 * fr, mw = m0 + wr * 128;
+    float bn0 = 0.f, bn1 = 0.f, sn0 = 1.f, sn1 = 1.f;
+    if (p.bias) { bn0 = p.bias[n]; bn1 = p.bias[n + 1]; }
+    if (p.oscale) { sn0 = p.oscale[n]; sn1 = p.oscale[n + 1]; }
+    const bool rf = p.res_first != 0;
+    const long long rows_left = (long long)p.M - mw;
+    const __amdgpu_buffer_rsrc_t rsC = desc(p.c, rows_left > 0 ? ((rows_left - 1) * p.ldc + p.N) * 2 + (long long)mw * p.ldc * 2 : 0, (long long)mw * p.ldc * 2);
+    const __amdgpu_buffer_rsrc_t rsR = p.res ? desc(p.res, rows_left > 0 ? ((rows_left - 1) * p.ldr + p.N) * 2 + (long long)mw * p.ldr * 2 : 0, (long long)mw * p.ldr * 2)
+                                             : __builtin_amdgcn_make_buffer_rsrc((void*)p.c, 0, 0, 0x00020000);
+    const unsigned vc = (unsigned)((4 * fh * p.ldc + n) * 2), vr = (unsigned)((4 * fh * p.ldr + n) * 2);
+    const int row_lim = (int)(rows_left < 1024 ? rows_left : 1024) - 4 * fh;
+    unsigned rvv[16];
+    if constexpr (RES) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ru = 32 * bi + (r & 3) + 8 * (r >> 2);
+            rvv[r] = __builtin_amdgcn_raw_buffer_load_b32(rsR, ru < row_lim ? vr : OOR, (unsigned)(ru * p.ldr * 2), 0);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const f16x2 rh = __builtin_bit_cast(f16x2, RES ? rvv[r] : 0u);
+        const float r0 = RES ? (float)rh[0] : 0.f, r1 = RES ? (float)rh[1] : 0.f;
+        float o0 = act_f(fmaf(a0[r], sn0, bn0) + (rf ? r0 : 0.f), ACT), o1 = act_f(fmaf(a1[r], sn1, bn1) + (rf ? r1 : 0.f), ACT);
+        if (RES) { o0 += rf ? 0.f : r0; o1 += rf ? 0.f : r1; }
+        const int ru = 32 * bi + (r & 3) + 8 * (r >> 2);
+        __builtin_amdgcn_raw_buffer_store_b32(pack2(o0, o1), rsC, ru < row_lim ? vc : OOR, (unsigned)(ru * p.ldc * 2), 0);
     }
 }
 
@@ -853,12 +939,20 @@ inline unsigned grid_for(long long total) {
 
 namespace {
 int gemm_f16_impl(const void* a, int64_t lda, const void* w, int64_t ldw, const float* out_scale, const float* bias, const void* residual,
-                  int64_t ldr, int res_first, void* c, int64_t ldc, int64_t M, int64_t N, int64_t K, int act, void* stream, int part);
+                  int64_t ldr, int res_first, void* c, int64_t ldc, int64_t M, int64_t N, int64_t K, int act, void* stream, int part,
+                  void* workspace = nullptr, size_t workspace_bytes = 0);
 }
 
 extern "C" int dbmm_gemm_f16(const void* a, int64_t lda, const void* w, int64_t ldw, const float* bias, const void* residual,
                              int64_t ldr, void* c, int64_t ldc, int64_t M, int64_t N, int64_t K, int act, void* stream) {
     return gemm_f16_impl(a, lda, w, ldw, nullptr, bias, residual, ldr, 0, c, ldc, M, N, K, act, stream, 0);
+}
+
+// see include/dbmm.h: dbmm_gemm_f16 with a workspace (the tiles of a short last round of the eight-phase kernel are cut along K)
+extern "C" int dbmm_gemm_f16_ws(const void* a, int64_t lda, const void* w, int64_t ldw, const float* bias, const void* residual,
+                                int64_t ldr, void* c, int64_t ldc, int64_t M, int64_t N, int64_t K, int act, void* workspace,
+                                size_t workspace_bytes, void* stream) {
+    return gemm_f16_impl(a, lda, w, ldw, nullptr, bias, residual, ldr, 0, c, ldc, M, N, K, act, stream, 0, workspace, workspace_bytes);
 }
 
 // 1x1 conv + eval-mode BatchNorm (+ residual) + activation on fp16 NHWC maps = the same GEMM with a per-channel scale and the
@@ -879,9 +973,22 @@ extern "C" int dbmm_conv1x1_bn_act_f16(const void* x, const void* w, const float
     return gemm_f16_impl(x, Cin, w, Cin, scale, bias, residual, Cout, 1, y, Cout, M, Cout, Cin, act, stream, 0);
 }
 
+// see include/dbmm.h: dbmm_conv1x1_bn_act_f16 with a workspace
+extern "C" int dbmm_conv1x1_bn_act_f16_ws(const void* x, const void* w, const float* scale, const float* bias, const void* residual, void* y,
+                                          int64_t M, int64_t Cin, int64_t Cout, int act, void* workspace, size_t workspace_bytes, void* stream) {
+    const int mode = dbmm_opt(OPT_CONV1X1_STREAM);
+    const bool gemm8 = (Cout % 256) == 0 && (Cin % 128) == 0 && M >= 16384;
+    if ((mode == 2 || (mode == 1 && !gemm8)) && (act == DBMM_ACT_NONE || act == DBMM_ACT_RELU) && (Cin % 32) == 0) {
+        const int rc = dbmm_conv1x1_stream_f16(x, w, scale, bias, residual, y, M, Cin, Cout, act, stream);
+        if (rc != DBMM_E_UNSUPPORTED) return rc;
+    }
+    return gemm_f16_impl(x, Cin, w, Cin, scale, bias, residual, Cout, 1, y, Cout, M, Cout, Cin, act, stream, 0, workspace, workspace_bytes);
+}
+
 namespace {
 int gemm_f16_impl(const void* a, int64_t lda, const void* w, int64_t ldw, const float* out_scale, const float* bias, const void* residual,
-                  int64_t ldr, int res_first, void* c, int64_t ldc, int64_t M, int64_t N, int64_t K, int act, void* stream, int part) {
+                  int64_t ldr, int res_first, void* c, int64_t ldc, int64_t M, int64_t N, int64_t K, int act, void* stream, int part,
+                  void* workspace, size_t workspace_bytes) {
     if (!a || !w || !c) return DBMM_E_ARG;
     if (M <= 0 || N <= 0 || K <= 0 || M > INT32_MAX || N > INT32_MAX || K > INT32_MAX) return DBMM_E_SHAPE;
     if (act < 0 || act > 2) return DBMM_E_ARG;
@@ -907,16 +1014,33 @@ int gemm_f16_impl(const void* a, int64_t lda, const void* w, int64_t ldw, const 
             // one (ViT-B/32 at 512 images: out-proj / c_proj have 100 x 3 = 300 tiles = 2 rounds for 1.17 rounds of work; RN50 layer 3:
             // 784 tiles = 4 rounds for 3.06).  Whole rounds stay here; the rows of the short last round go to the 128 x 128 kernel, a
             // launch of <= 512 tiles (one pass over the chip's 2 x 256 slots) that costs about 0.4 of an eight-phase round.
+            // With a workspace the tiles of the short last round (at most 128) are instead cut along K into S = min(256 / tiles, trips)
+            // slices, one workgroup each, and gemm_f16_8ph_fixup_kernel sums them and runs the epilogue (as gemm_pair_8ph.hip).
+            p.n_full = p.n_tiles; p.n_cut = 0; p.n_slices = 1; p.ws = nullptr;
             if (part == 0 && dbmm_opt(OPT_TAIL_SPLIT) && p.n_tiles > 256 && (p.n_tiles % 256) != 0) {
+                const int rem = p.n_tiles % 256, trips = (int)(K / 128);
+                int S = rem <= 128 ? 256 / rem : 1;
+                S = S < trips ? S : trips;
+                const int mode = dbmm_opt(OPT_TAIL_SPLIT);            // 1: by rule, 2: the K cut wherever it applies, 3: the row split only
+                // same box, tools/bench_tail_f16.py (profiles/r04_ab_tail_f16.log): the cut pays on long K only -- ViT-B/32's c_proj (K 3072, 300 /
+                // 600 tiles) 160 -> 149 us / 261 -> 251 us; K <= 2048 shapes lose 1-10 % to the slices' fixed cost (prologue, 256 KB of fp32
+                // partial sums per slice against a 128-KB fp16 tile, the second launch)
+                const bool cut_pays = K >= 3072 && rem >= 32;
+                if ((mode == 2 || (mode == 1 && cut_pays)) && workspace && dbmm_aligned16(workspace) && S >= 2 &&
+                    (size_t)rem * S * (128 * 512 * sizeof(float)) <= workspace_bytes) {
+                    p.n_full = p.n_tiles - rem; p.n_cut = rem; p.n_slices = S; p.ws = (float*)workspace;
+                } else {
                 const int64_t mt = (M + 255) / 256, full_rounds = p.n_tiles / 256, mt_full = full_rounds * 256 / p.tiles_n;
                 const int64_t m_split = mt_full * 256, tail_rows = M - m_split;
                 const int64_t tail_tiles = ((tail_rows + 127) / 128) * ((N + 127) / 128);
-                if (mt_full >= 1 && mt_full < mt && tail_tiles <= 512 && (p.n_tiles % 256) <= 128) {
-                    int rc = gemm_f16_impl(a, lda, w, ldw, out_scale, bias, residual, ldr, res_first, c, ldc, m_split, N, K, act, stream, 1);
+                // (the row split: +1-2 % on the 300-tile projections of ViT-B/32 at 512 images, a loss from 600 tiles on)
+                if ((mode == 3 || (mode == 1 && p.n_tiles <= 512)) && mt_full >= 1 && mt_full < mt && tail_tiles <= 512 && (p.n_tiles % 256) <= 128) {
+                    int rc = gemm_f16_impl(a, lda, w, ldw, out_scale, bias, residual, ldr, res_first, c, ldc, m_split, N, K, act, stream, 1, nullptr, 0);
                     if (rc != DBMM_OK) return rc;
                     return gemm_f16_impl((const u16*)a + m_split * lda, lda, w, ldw, out_scale, bias,
                                          residual ? (const void*)((const u16*)residual + m_split * ldr) : nullptr, ldr, res_first,
-                                         (u16*)c + m_split * ldc, ldc, tail_rows, N, K, act, stream, 2);
+                                         (u16*)c + m_split * ldc, ldc, tail_rows, N, K, act, stream, 2, nullptr, 0);
+                }
                 }
             }
             const int grid = p.n_tiles < 256 ? p.n_tiles : 256;   // persistent: one workgroup per CU
@@ -926,6 +1050,13 @@ int gemm_f16_impl(const void* a, int64_t lda, const void* w, int64_t ldw, const 
             else { if (act == 0) DBMM_8PH(0, 0); else if (act == 1) DBMM_8PH(1, 0); else DBMM_8PH(2, 0); }
 #undef DBMM_8PH
             DBMM_CHECK_LAUNCH();
+            if (p.n_cut) {
+#define DBMM_8PHF(A, R) hipLaunchKernelGGL((gemm_f16_8ph_fixup_kernel<A, R>), dim3(p.n_cut, 4), dim3(512), 0, s8, p)
+                if (residual) { if (act == 0) DBMM_8PHF(0, 1); else if (act == 1) DBMM_8PHF(1, 1); else DBMM_8PHF(2, 1); }
+                else { if (act == 0) DBMM_8PHF(0, 0); else if (act == 1) DBMM_8PHF(1, 0); else DBMM_8PHF(2, 0); }
+#undef DBMM_8PHF
+                DBMM_CHECK_LAUNCH();
+            }
             return DBMM_OK;
         }
     }

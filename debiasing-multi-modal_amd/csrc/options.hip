@@ -39,8 +39,9 @@ const OptDef kOpts[DBMM_OPT_COUNT] = {
     {"chain8", 0},             // 1: conv3 + residual -> next conv1 of the layer-3 geometry (K = P = 256) on the eight-wave chain kernel (measured
                                //    0.754 ms against 0.686 ms for the two launches: bottleneck_chain8.hip; kept, tested, off)
     {"conv1x1_bn256", 0},      // 1: parity 1x1 convs with Cout % 256 == 0 on 128 x 256 tiles (A read once per 256 columns)
-    {"tail_split", 1},         // eight-phase GEMMs whose 256 x 256 tiles leave a short last round on the 256 CUs: whole rounds on the eight-phase
-                               // kernel, the remaining rows on the 128 x 128 kernel (0: one launch)
+    {"tail_split", 1},         // eight-phase kernels whose 256 x 256 tiles leave a short last round on the 256 CUs: 0 one launch / 1 by rule: the round's
+                               // tiles cut along K over the idle CUs + a summing launch (parity kernels; fp16 GEMMs with K >= 3072), or its rows on the
+                               // 128 x 128 kernel (fp16 GEMMs of at most two rounds) / 2 the K cut wherever it applies / 3 (fp16 GEMMs) the row split only
     {"halo8", 1},              // parity 3x3 convs with Cout % 256 == 0 on conv3x3_halo8_kernel: 0 never / 1 where it measured ahead / 2 wherever it applies
     {"dual_8ph", 1},           // conv3 + downsample dual-source GEMM on gemm_pair_8ph_kernel: 0 never / 1 where it measured ahead / 2 wherever it applies
 };

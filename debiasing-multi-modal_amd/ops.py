@@ -759,8 +759,9 @@ def gemm_f16(a, w, bias=None, residual=None, act=ACT_NONE, M=None, lda=None):
     deep = N % 256 == 0 and K % 128 == 0 and M >= 16384 and get_option("f16_8ph")   # dbmm_gemm_f16's own rule
     with _TimedTag(f"gemm_f16_8ph_kernel<{act}, {int(residual is not None)}>" if deep else _gemm_f16_tag(M, N), 2.0 * M * N * K,
                    2 * (M * K + N * K + M * N * (2 if residual is not None else 1))):
-        check(_lib.lib().dbmm_gemm_f16(ptr(a), lda, ptr(w), K, ptr(bias), ptr(residual), N if residual is not None else 0, ptr(c), N,
-                                       M, N, K, act, stream()), "gemm_f16")
+        ws = igemm_workspace(a.device)
+        check(_lib.lib().dbmm_gemm_f16_ws(ptr(a), lda, ptr(w), K, ptr(bias), ptr(residual), N if residual is not None else 0, ptr(c), N,
+                                          M, N, K, act, ptr(ws), ws.numel() * 4, stream()), "gemm_f16")
     return c
 
 
@@ -843,7 +844,9 @@ def conv1x1_f16(x, w, scale, bias, residual=None, act=ACT_RELU):
     t = _TimedTag(tag, 2.0 * M * Cout * Cin,
                   2 * (M * Cin + Cout * Cin + M * Cout * (2 if residual is not None else 1)))
     t.__enter__()
-    rc = _lib.lib().dbmm_conv1x1_bn_act_f16(ptr(x), ptr(w), ptr(scale), ptr(bias), ptr(residual), ptr(y), M, Cin, Cout, act, stream())
+    ws = igemm_workspace(x.device)
+    rc = _lib.lib().dbmm_conv1x1_bn_act_f16_ws(ptr(x), ptr(w), ptr(scale), ptr(bias), ptr(residual), ptr(y), M, Cin, Cout, act, ptr(ws),
+                                               ws.numel() * 4, stream())
     t.__exit__(None if rc == 0 else DbmmUnsupported, None, None)      # nothing is recorded for a launch that did not happen
     if rc == _lib.E_UNSUPPORTED:
         return None

@@ -258,6 +258,11 @@ int dbmm_gemm_pair_8ph(const float* a, int64_t lda, const float* a_absmax, const
 /* c f16 [M][ldc] = act(a f16 [M][lda] @ w f16 [N][ldw]^T + bias f32 [N]) + residual f16 [M][ldr].  K % 64 == 0, N % 8 == 0. */
 int dbmm_gemm_f16(const void* a, int64_t lda, const void* w, int64_t ldw, const float* bias, const void* residual,
                   int64_t ldr, void* c, int64_t ldc, int64_t M, int64_t N, int64_t K, int act, void* stream);
+/* The same with a workspace (16-B aligned, dbmm_workspace_bytes_igemm() bytes are enough): when the 256 x 256 tiles of the deep-pipelined
+ * kernel leave a short last round on the 256 CUs, its tiles are cut along K over the idle CUs and summed by a second launch. */
+int dbmm_gemm_f16_ws(const void* a, int64_t lda, const void* w, int64_t ldw, const float* bias, const void* residual,
+                     int64_t ldr, void* c, int64_t ldc, int64_t M, int64_t N, int64_t K, int act, void* workspace,
+                     size_t workspace_bytes, void* stream);
 /* fp16 mode of the ModifiedResNet towers (clip/model.py:10-154 on the reference's GPU path: the image is cast to fp16, :146,
  * conv weights are fp16, BatchNorm parameters fp32).  Activations f16 NHWC; eval-mode BatchNorm as fp32 per-channel
  * scale / bias on the fp32 accumulator, residual add, ReLU and AvgPool2d(2) fused, ONE rounding to fp16 when stored.
@@ -270,6 +275,9 @@ int dbmm_gemm_f16(const void* a, int64_t lda, const void* w, int64_t ldw, const 
  *   avgpool2: AvgPool2d(2) on f16 NHWC (the downsample branch of a stride-2 block, clip/model.py:36-38). */
 int dbmm_conv1x1_bn_act_f16(const void* x, const void* w, const float* scale, const float* bias, const void* residual, void* y,
                             int64_t M, int64_t Cin, int64_t Cout, int act, void* stream);
+int dbmm_conv1x1_bn_act_f16_ws(const void* x, const void* w, const float* scale, const float* bias, const void* residual, void* y,
+                               int64_t M, int64_t Cin, int64_t Cout, int act, void* workspace, size_t workspace_bytes,
+                               void* stream);          /* with a workspace, as dbmm_gemm_f16_ws */
 int dbmm_conv3x3_bn_relu_f16(const void* x, const void* w, const float* scale, const float* bias, void* y, int64_t B, int64_t H,
                              int64_t W, int64_t Cin, int64_t Cout, int pool, void* stream);
 int dbmm_conv_stem_s2_f16(const void* x_nchw, int x_is_f16, const float* w, const float* bias, void* y_nhwc, int64_t B, int64_t H,

@@ -42,7 +42,10 @@ def test_gemm_f16(M, N, K, res, act):
 
 
 @pytest.mark.parametrize("M,N,K,res,act", [(16384 + 77, 512, 256, True, 2), (32768, 256, 128, False, 0), (20000, 1024, 4096, True, 0),
-                                           (577 * 64, 3072, 1024, False, 2), (16384, 768, 3072, True, 0)])
+                                           (577 * 64, 3072, 1024, False, 2), (16384, 768, 3072, True, 0),
+                                           # a short last round cut along K (tail_split): 300 tiles = 256 + 44 x 5 slices (the ViT-B/32 projections at
+                                           # 512 images), 274 = 256 + 18 x 4; above: 316 = 256 + 60 x 4
+                                           (25600, 768, 768, True, 0), (25600, 768, 3072, True, 0), (70000, 256, 512, False, 1)])
 def test_gemm_f16_deep_pipelined_kernel(M, N, K, res, act, option):
     """the 256 x 256 x 64 eight-phase kernel (N % 256 == 0, K % 128 == 0, M >= 16384) against fp64 ELEMENT-wise -- a staging
     race would show as a few wrong tiles, which a norm-wise error hides -- over repeated launches, and against the
@@ -58,7 +61,8 @@ def test_gemm_f16_deep_pipelined_kernel(M, N, K, res, act, option):
     option("f16_8ph", "0")
     base = ops.gemm_f16(a, w, b, residual=r, act=act)
     option("f16_8ph", "1")
-    for _ in range(4):
+    for it in range(4):
+        option("tail_split", 2 if it & 1 else 1)       # 1: by the library's rule, 2: a short last round's tiles cut along K wherever that applies
         out = ops.gemm_f16(a, w, b, residual=r, act=act)
         assert torch.allclose(out[rows].double(), v, rtol=2e-3, atol=2e-3)
         # same products, fp32 accumulation in another order, one fp16 rounding: at most an ulp or two apart, everywhere
