@@ -608,13 +608,15 @@ __device__ __forceinline__ u32x4 vt_frag(const unsigned char* p) {
 #endif
 }
 
-template <int QT>
-__global__ __launch_bounds__(256, 2) void mha_f16_kernel(const u16* __restrict__ qkv, u16* __restrict__ out, int L, int E,
-                                                         int heads, int causal, float scale_log2e) {
+// NW = waves per workgroup: 4, or 2 for sequences of at most 64 tokens (ViT-B/32's 50: two of four waves multiplied clamped queries)
+template <int QT, int NW = 4>
+__global__ __launch_bounds__(64 * NW, 2) void mha_f16_kernel(const u16* __restrict__ qkv, u16* __restrict__ out, int L, int E,
+                                                             int heads, int causal, float scale_log2e) {
     __shared__ __attribute__((aligned(16))) u16 Ks[64 * 64];
     __shared__ __attribute__((aligned(16))) u16 Vt[64 * 64];
-    __shared__ __attribute__((aligned(16))) u16 Os[4 * 32 * A_OROW];
-    constexpr int QB = 128 * QT;                                 // queries per workgroup
+    __shared__ __attribute__((aligned(16))) u16 Os[NW * 32 * A_OROW];
+    constexpr int QB = 32 * NW * QT;                             // queries per workgroup
+    constexpr int KPI = 8 * NW, NI = 64 / KPI;                   // key rows per staging pass, passes per 64-key tile
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 31, fh = lane >> 5;
     const int qb = blockIdx.x, head = blockIdx.y, b = blockIdx.z;
@@ -638,16 +640,16 @@ __global__ __launch_bounds__(256, 2) void mha_f16_kernel(const u16* __restrict__
         m_run[qt] = -INFINITY; l_run[qt] = 0.f;
     }
 
-    // staging: thread loads 16 B (8 d) of key rows tid >> 3 and (tid >> 3) + 32 for K and V
+    // staging: thread loads 16 B (8 d) of key rows (tid >> 3) + KPI i for K and V
     const int lc = tid & 7, lk = tid >> 3;
-    u32x4 k_r[2], v_r[2];
+    u32x4 k_r[NI], v_r[NI];
     const int q_hi = qb * QB + QB - 1 < L - 1 ? qb * QB + QB - 1 : L - 1;
     const int n_keys = causal ? q_hi + 1 : L;                   // causal: keys past the block's last query never count
     const int T = (n_keys + 63) / 64;
     auto load_tile = [&](int t) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            int key = t * 64 + lk + 32 * i;
+        for (int i = 0; i < NI; ++i) {
+            int key = t * 64 + lk + KPI * i;
             key = key < L ? key : L - 1;
             const u16* base = qkv + (row0 + key) * ld + head * 64 + lc * 8;
             k_r[i] = *(const u32x4*)(base + E);
@@ -656,8 +658,8 @@ __global__ __launch_bounds__(256, 2) void mha_f16_kernel(const u16* __restrict__
     };
     auto store_tile = [&]() {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int key = lk + 32 * i;
+        for (int i = 0; i < NI; ++i) {
+            const int key = lk + KPI * i;
             *(u32x4*)(Ks + key * 64 + ((lc ^ swz64(key)) << 3)) = k_r[i];
             // V stays ROW-major ([key][64 d], one 16-B store like K): the V^T fragments are formed by the hardware
             // transpose read below.  Chunk XOR 4 on rows 2, 3 (mod 4) keeps the four rows of a transposed block on
@@ -1079,9 +1081,14 @@ extern "C" int dbmm_mha_core_f16(const void* qkv, void* out, int64_t B, int64_t 
     if (!dbmm_aligned16(qkv) || !dbmm_aligned16(out)) return DBMM_E_ALIGN;
     // (64 queries per wave measured 8 % slower on ViT-L/14@336 -- 256 registers hold occupancy at 2 workgroups per CU where
     // this 32-query form, 161 registers, runs 3 -- and is not instantiated)
-    const dim3 grid((unsigned)((L + 127) / 128), (unsigned)heads, (unsigned)B);
-    hipLaunchKernelGGL(mha_f16_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, (const u16*)qkv, (u16*)out, (int)L, (int)E,
-                       (int)heads, causal ? 1 : 0, 0.125f * 1.4426950408889634f);
+    if (L <= 64 && dbmm_opt(OPT_MHA_SHORT)) {
+        hipLaunchKernelGGL((mha_f16_kernel<1, 2>), dim3(1, (unsigned)heads, (unsigned)B), dim3(128), 0, (hipStream_t)stream, (const u16*)qkv, (u16*)out,
+                           (int)L, (int)E, (int)heads, causal ? 1 : 0, 0.125f * 1.4426950408889634f);
+    } else {
+        const dim3 grid((unsigned)((L + 127) / 128), (unsigned)heads, (unsigned)B);
+        hipLaunchKernelGGL(mha_f16_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, (const u16*)qkv, (u16*)out, (int)L, (int)E,
+                           (int)heads, causal ? 1 : 0, 0.125f * 1.4426950408889634f);
+    }
     DBMM_CHECK_LAUNCH();
     return DBMM_OK;
 }

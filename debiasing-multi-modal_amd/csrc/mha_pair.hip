@@ -58,16 +58,20 @@ __device__ __forceinline__ u32x4 vt_frag(const unsigned char* p) {
 #endif
 }
 
-__global__ __launch_bounds__(256, 2) void mha_pair_kernel(const float* __restrict__ qkv, const float* __restrict__ qkv_absmax,
-                                                          float* __restrict__ out, int L, int E, int causal) {
+// NW = waves per workgroup: 4 (128 queries; the default) or 2 (64 queries: sequences of at most 64 tokens -- ViT-B/32's 50 -- left two of
+// four waves multiplying clamped queries; with two waves three workgroups fit a CU).
+template <int NW>
+__global__ __launch_bounds__(64 * NW, 2) void mha_pair_kernel(const float* __restrict__ qkv, const float* __restrict__ qkv_absmax,
+                                                                             float* __restrict__ out, int L, int E, int causal) {
+    constexpr int QB = 32 * NW, KPI = 4 * NW, NI = 64 / KPI;      // queries per workgroup; key rows per staging pass, passes per 64-key tile
     __shared__ __attribute__((aligned(16))) u16 Ks[2 * PL];      // [hi | lo][key][64 d]
     __shared__ __attribute__((aligned(16))) u16 Vt[2 * PL];      // [hi | lo][key][64 d]
-    __shared__ __attribute__((aligned(16))) float Os[4 * 32 * O_ROW];
+    __shared__ __attribute__((aligned(16))) float Os[NW * 32 * O_ROW];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 31, fh = lane >> 5;
     const int qb = blockIdx.x, head = blockIdx.y, b = blockIdx.z;
     const long long row0 = (long long)b * L, ld = 3LL * E;
-    const int q_idx = qb * 128 + wave * 32 + fr, q_wave0 = qb * 128 + wave * 32;   // this lane's query, the wave's first
+    const int q_idx = qb * QB + wave * 32 + fr, q_wave0 = qb * QB + wave * 32;     // this lane's query, the wave's first
     const int q_ld = q_idx < L ? q_idx : L - 1;
     const int s_x = scale_exp(*qkv_absmax);
     const float x_sc = pow2f(s_x);
@@ -92,16 +96,16 @@ __global__ __launch_bounds__(256, 2) void mha_pair_kernel(const float* __restric
         for (int r = 0; r < 16; ++r) o_acc[j][r] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
 
-    // staging: thread loads 16 B (4 d) of key rows (tid >> 4) + 16 i for K and V
+    // staging: thread loads 16 B (4 d) of key rows (tid >> 4) + KPI i for K and V
     const int lc = tid & 15, lk = tid >> 4;
-    f32x4 k_r[4], v_r[4];
-    const int q_hi = qb * 128 + 127 < L - 1 ? qb * 128 + 127 : L - 1;
+    f32x4 k_r[NI], v_r[NI];
+    const int q_hi = qb * QB + QB - 1 < L - 1 ? qb * QB + QB - 1 : L - 1;
     const int n_keys = causal ? q_hi + 1 : L;
     const int T = (n_keys + 63) / 64;
     auto load_tile = [&](int t) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            int key = t * 64 + lk + 16 * i;
+        for (int i = 0; i < NI; ++i) {
+            int key = t * 64 + lk + KPI * i;
             key = key < L ? key : L - 1;
             const float* base = qkv + (row0 + key) * ld + head * 64 + lc * 4;
             k_r[i] = *(const f32x4*)(base + E);
@@ -110,8 +114,8 @@ __global__ __launch_bounds__(256, 2) void mha_pair_kernel(const float* __restric
     };
     auto store_tile = [&]() {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int key = lk + 16 * i;
+        for (int i = 0; i < NI; ++i) {
+            const int key = lk + KPI * i;
             unsigned h[2], l[2];
             split2h_pair(k_r[i][0], k_r[i][1], x_sc, h[0], l[0]); split2h_pair(k_r[i][2], k_r[i][3], x_sc, h[1], l[1]);
             const int koff = key * 64 + (((lc >> 1) ^ swz64(key)) << 3) + ((lc & 1) << 2);
@@ -229,7 +233,7 @@ __global__ __launch_bounds__(256, 2) void mha_pair_kernel(const float* __restric
         }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        const int row = (lane >> 4) + 4 * i, q = qb * 128 + wave * 32 + row;
+        const int row = (lane >> 4) + 4 * i, q = qb * QB + wave * 32 + row;
         if (q < L) *(f32x4*)(out + (row0 + q) * (long long)E + head * 64 + (lane & 15) * 4) = *(const f32x4*)(Ow + row * O_ROW + (lane & 15) * 4);
     }
 }
@@ -242,8 +246,13 @@ extern "C" int dbmm_mha_core_x2(const float* qkv, const float* qkv_absmax, float
     if (!qkv || !qkv_absmax || !out) return DBMM_E_ARG;
     if (B <= 0 || L <= 0 || heads <= 0 || E != heads * 64 || B > 65535 || heads > 65535) return DBMM_E_SHAPE;
     if (!dbmm_aligned16(qkv) || !dbmm_aligned16(out)) return DBMM_E_ALIGN;
-    const dim3 grid((unsigned)((L + 127) / 128), (unsigned)heads, (unsigned)B);
-    hipLaunchKernelGGL(mha_pair_kernel, grid, dim3(256), 0, (hipStream_t)stream, qkv, qkv_absmax, out, (int)L, (int)E, causal ? 1 : 0);
+    if (L <= 64 && dbmm_opt(OPT_MHA_SHORT)) {
+        hipLaunchKernelGGL(mha_pair_kernel<2>, dim3(1, (unsigned)heads, (unsigned)B), dim3(128), 0, (hipStream_t)stream, qkv, qkv_absmax, out, (int)L,
+                           (int)E, causal ? 1 : 0);
+    } else {
+        const dim3 grid((unsigned)((L + 127) / 128), (unsigned)heads, (unsigned)B);
+        hipLaunchKernelGGL(mha_pair_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, qkv, qkv_absmax, out, (int)L, (int)E, causal ? 1 : 0);
+    }
     DBMM_CHECK_LAUNCH();
     return DBMM_OK;
 }

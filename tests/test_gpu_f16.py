@@ -83,7 +83,8 @@ def test_gemm_f16_strided_rows_and_rejects():
 
 
 @pytest.mark.parametrize("B,L,heads,causal", [(3, 50, 2, False), (2, 77, 8, True), (2, 130, 1, False), (1, 577, 4, False),
-                                              (2, 1, 1, False), (1, 128, 2, True), (2, 129, 1, True)])
+                                              (2, 1, 1, False), (1, 128, 2, True), (2, 129, 1, True),
+                                              (2, 64, 2, True), (3, 33, 1, True)])          # <= 64 tokens: the two-wave workgroups
 def test_mha_core_f16(B, L, heads, causal):
     E = heads * 64
     g = torch.Generator(device=DEV); g.manual_seed(L + heads)

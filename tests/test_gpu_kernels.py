@@ -1057,7 +1057,8 @@ def test_conv3x3_c32_patch_kernel(B, H, W, Cout, pool, option):
 
 
 @pytest.mark.parametrize("B,L,heads,causal", [(3, 50, 2, False), (2, 77, 8, True), (2, 130, 1, False), (1, 577, 2, False),
-                                              (2, 1, 1, False), (1, 128, 2, True), (2, 129, 1, True), (2, 300, 2, True)])
+                                              (2, 1, 1, False), (1, 128, 2, True), (2, 129, 1, True), (2, 300, 2, True),
+                                              (2, 64, 2, True), (3, 33, 1, True)])         # <= 64 tokens: the two-wave workgroups
 @pytest.mark.parametrize("bound", [1.0, 37.0])
 def test_mha_core_fp16_pair_kernel(B, L, heads, causal, bound):
     """parity-mode attention core on fp16-pair products (three partial products, scale from a bound of max|qkv|) against
