@@ -130,6 +130,31 @@ def kernel_products(tag):
     return 1
 
 
+def pmc_lookup(tag, kernels):
+    """the PMC record of a profile tag.  rocprofv3 spells every template argument; the library's tag leaves out the ones it does not
+    report (activation / residual of the eight-phase kernels): "conv3x3_halo8_kernel<1>" is "conv3x3_halo8_kernel<1, ACT>",
+    "gemm_pair_8ph_kernel" is "<ACT, RES, 0>", "gemm_pair_8ph_kernel<dual>" is "<ACT, 0, 1>" -- the launch-weighted mean of those."""
+    if tag in kernels:
+        return kernels[tag]
+    if tag.startswith(("conv3x3_halo8_kernel<", "conv3x3_halo8n_kernel<")):
+        hits = [v for k, v in kernels.items() if k.startswith(tag[:-1] + ",")]
+    elif tag == "gemm_pair_8ph_kernel":
+        hits = [v for k, v in kernels.items() if k.startswith("gemm_pair_8ph_kernel<") and k.endswith(", 0>")]
+    elif tag == "gemm_pair_8ph_kernel<dual>":
+        hits = [v for k, v in kernels.items() if k.startswith("gemm_pair_8ph_kernel<") and k.endswith(", 1>")]
+    else:
+        hits = []
+    if not hits:
+        return None
+    n = sum(h.get("launches", 1) for h in hits)
+    out = {"launches": n}
+    for key in ("hbm_bytes_per_launch", "avg_launch_ms", "mfma_busy", "waves_per_simd", "lds_bank_conflict"):
+        vals = [(h[key], h.get("launches", 1)) for h in hits if h.get(key) is not None]
+        if vals:
+            out[key] = sum(v * w for v, w in vals) / sum(w for _, w in vals)
+    return out
+
+
 def kernel_rows(prof, steps, step_ms, pmc):
     """one roofline record per kernel instantiation, ranked by measured time: each against the roof that binds it"""
     rows = []
@@ -151,7 +176,7 @@ def kernel_rows(prof, steps, step_ms, pmc):
                "flops_per_launch": fl / n, "bytes_per_launch": by / n,
                "partial_products_per_fp32_product": nprod, "traffic": None, "traffic_over_algorithmic": None,
                "mfma_busy": None, "hbm_tbps": None}
-        k = (pmc or {}).get("kernels", {}).get(tag)
+        k = pmc_lookup(tag, (pmc or {}).get("kernels", {}))
         if k:                                            # committed rocprofv3 --pmc passes of this very command
             if k.get("hbm_bytes_per_launch"):
                 row["traffic"] = round(k["hbm_bytes_per_launch"])
