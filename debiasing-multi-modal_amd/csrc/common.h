@@ -39,6 +39,18 @@ int dbmm_gemm_dual_pair_8ph(const float* a, int64_t lda, const float* a_absmax, 
                             int64_t K2, const float* ratio, const float* bias, float* c, int64_t ldc, float* c_absmax, int64_t M, int64_t N, int act,
                             void* stream);
 
+// K cut of a short last round of the 256-tile persistent kernels: `rem` tiles left for 256 workgroups, `trips` loop trips per tile -> slices
+// per tile (0: no cut).  One slice per workgroup at most: a slice costs ~0.3 of a layer-3 tile on top of its share of the loop (prologue,
+// 256 KB of partial sums) and the summing launch reads rem x S x 256 KB, so a second slice per workgroup (rem > 128) never paid
+// (HISTORY.md, round 4); with rem = 64 and S = 4 the cut is already neutral.
+static inline int dbmm_cut_slices(int rem, int trips) {
+    if (rem <= 0 || rem > 128) return 0;
+    int S = 256 / rem;
+    S = S < trips ? S : trips;
+    S = S < 16 ? S : 16;
+    return S >= 2 ? S : 0;
+}
+
 static inline bool dbmm_aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
 
 // wave64 butterfly sum / max (all lanes get the result)

@@ -333,16 +333,18 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo8_kernel(const Halo8P p) {
     // the zero line of both planes of both A buffers (never written by the loader)
     if (tid < 64) *(u32x4*)(lds + OFF_A + (tid >> 5) * A_BUF + ((tid >> 4) & 1) * A_PLANE + ZROW * 64 + (tid & 15) * 16) = (u32x4){0u, 0u, 0u, 0u};
 
-    // Work items of this workgroup: its whole tiles (all groups), then -- if there are cut tiles and this workgroup's index is
-    // below n_cut * n_slices -- one slice: a cut tile's loop trips [s T / S, (s + 1) T / S).
+    // Work items of this workgroup: its whole tiles (all groups), then its share of the n_cut * n_slices slices (slice i = cut tile i / S,
+    // loop trips [s T / S, (s + 1) T / S) with s = i % S), dealt round-robin over the workgroups.
     const int n_whole = t_lo + slot_in_xcd < t_hi ? (t_hi - t_lo - slot_in_xcd + wg_per_xcd - 1) / wg_per_xcd : 0;
-    const bool has_slice = (int)blockIdx.x < p.n_cut * p.n_slices;
-    const int n_items = n_whole + (has_slice ? 1 : 0);
-    int gb = 0, ge = G;                                               // the current item's groups [gb, ge), both even
+    const int n_sl_all = p.n_cut * p.n_slices;                        // slices: number blockIdx.x + j * gridDim.x goes to this workgroup
+    const int n_sl = (int)blockIdx.x < n_sl_all ? (n_sl_all - 1 - (int)blockIdx.x) / nwg + 1 : 0;
+    const int n_items = n_whole + n_sl;
+    int gb = 0, ge = G, slice_id = 0;                                 // the current item's groups [gb, ge), both even; its slice number
     auto set_item = [&](int k) {
         if (k < n_whole) { gb = 0; ge = G; set_tile(t_lo + slot_in_xcd + k * wg_per_xcd); }
         else {
-            const int l = blockIdx.x / p.n_slices, sl = blockIdx.x - l * p.n_slices, T = G >> 1;
+            slice_id = blockIdx.x + (k - n_whole) * nwg;
+            const int l = slice_id / p.n_slices, sl = slice_id - l * p.n_slices, T = G >> 1;
             gb = 2 * (sl * T / p.n_slices); ge = 2 * ((sl + 1) * T / p.n_slices);
             set_tile(p.n_full + l);
         }
@@ -377,7 +379,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo8_kernel(const Halo8P p) {
         if (grp == 0) __builtin_amdgcn_s_barrier();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the look-ahead loads / DMA past this item's last tap
         __builtin_amdgcn_s_barrier();                                 // every wave is done with the LDS
-        const int em0 = m0, en0 = n0;
+        const int em0 = m0, en0 = n0, e_slice = slice_id;
         const bool whole = k < n_whole;
         if (k + 1 < n_items) { set_item(k + 1); prologue(); }         // in flight during the epilogue below
         if (whole) {
@@ -385,7 +387,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo8_kernel(const Halo8P p) {
 #include "conv3x3_halo8_epilogue.inc"
         } else {                                                      // a slice: the raw accumulators, 16 B per thread and store (8 KB per workgroup instruction)
             // (buffer stores with the register's offset in soffset: 128 flat addresses would be hoisted out of the item loop and spilled)
-            const __amdgpu_buffer_rsrc_t rsP = __builtin_amdgcn_make_buffer_rsrc((void*)(p.ws + (size_t)blockIdx.x * (128 * 512)), 0, 128 * 512 * 4, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rsP = __builtin_amdgcn_make_buffer_rsrc((void*)(p.ws + (size_t)e_slice * (128 * 512)), 0, 128 * 512 * 4, 0x00020000);
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -712,9 +714,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo8n_kernel(const Halo8P p) 
 
 // see common.h.  DBMM_E_UNSUPPORTED: the caller falls back to igemm_halo_kernel.
 // Tile quantisation: the persistent grid works in rounds of 256 tiles (layer 3 at B = 1024: 784 tiles = 3.06 rounds = the time of 4).
-// With a workspace and split != 0 the tiles of a short last round (at most 128 of them) are cut along K into S = min(256 / n_cut, trips)
-// slices, one workgroup each, and a small second launch sums the slices and runs the epilogue: the last round then costs ~1 / S of a round
-// plus 2 x n_cut x S x 256 KB of traffic.
+// With a workspace and split != 0 the tiles of a short last round are cut along K into S slices (dbmm_cut_slices, common.h) dealt over the
+// workgroups, and a small second launch sums the slices and runs the epilogue: the last round then costs ~1 / S of a round plus the slices'
+// fixed costs and 2 x tiles x S x 256 KB of traffic.
 int dbmm_conv3x3_halo8(const float* x, const float* x_absmax, const void* w_plane_f16, int w_exp, const float* out_scale, const float* bias,
                        float* y, float* y_absmax, int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int act, int pool, int split,
                        void* workspace, size_t workspace_bytes, void* stream) {
@@ -750,9 +752,8 @@ int dbmm_conv3x3_halo8(const float* x, const float* x_absmax, const void* w_plan
     p.n_tiles = (int)((M + 255) / 256) * p.tiles_n;
     p.n_full = p.n_tiles; p.n_cut = 0; p.n_slices = 1; p.ws = nullptr;
     const int rem = p.n_tiles % 256, trips = (int)(3 * (Cin / 32) / 2);
-    if (split && workspace && dbmm_aligned16(workspace) && p.n_tiles > 256 && rem != 0 && rem <= 128) {
-        int S = 256 / rem;
-        S = S < trips ? S : trips;
+    if (split && workspace && dbmm_aligned16(workspace) && p.n_tiles > 256 && rem != 0) {
+        const int S = dbmm_cut_slices(rem, trips);
         if (S >= 2 && (size_t)rem * S * (128 * 512 * sizeof(float)) <= workspace_bytes) {
             p.n_full = p.n_tiles - rem; p.n_cut = rem; p.n_slices = S; p.ws = (float*)workspace;
         }

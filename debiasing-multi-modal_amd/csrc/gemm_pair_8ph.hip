@@ -256,13 +256,15 @@ __global__ __launch_bounds__(512, 1) void gemm_pair_8ph_kernel(const PairP p) {
     // Work items of this workgroup: its whole tiles (all K tiles), then -- if there are cut tiles and this workgroup's index is below
     // n_cut * n_slices -- one slice: a cut tile's loop trips [s T / S, (s + 1) T / S)
     const int n_whole = t_lo + slot_in_xcd < t_hi ? (t_hi - t_lo - slot_in_xcd + wg_per_xcd - 1) / wg_per_xcd : 0;
-    const bool has_slice = !TWO && (int)blockIdx.x < p.n_cut * p.n_slices;
-    const int n_items = n_whole + (has_slice ? 1 : 0);
-    int tb = 0, te = nT;                                              // the current item's K tiles [tb, te), both even
+    const int n_sl_all = TWO ? 0 : p.n_cut * p.n_slices;              // slices: number blockIdx.x + j * gridDim.x goes to this workgroup
+    const int n_sl = (int)blockIdx.x < n_sl_all ? (n_sl_all - 1 - (int)blockIdx.x) / nwg + 1 : 0;
+    const int n_items = n_whole + n_sl;
+    int tb = 0, te = nT, slice_id = 0;                                // the current item's K tiles [tb, te), both even; its slice number
     auto set_item = [&](int k) {
         if (k < n_whole) { tb = 0; te = nT; set_tile(t_lo + slot_in_xcd + k * wg_per_xcd); }
         else {
-            const int l = blockIdx.x / p.n_slices, sl = blockIdx.x - l * p.n_slices, T = nT >> 1;
+            slice_id = blockIdx.x + (k - n_whole) * nwg;
+            const int l = slice_id / p.n_slices, sl = slice_id - l * p.n_slices, T = nT >> 1;
             tb = 2 * (sl * T / p.n_slices); te = 2 * ((sl + 1) * T / p.n_slices);
             set_tile(p.n_full + l);
         }
@@ -302,11 +304,11 @@ __global__ __launch_bounds__(512, 1) void gemm_pair_8ph_kernel(const PairP p) {
         if (grp == 0) __builtin_amdgcn_s_barrier();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the look-ahead loads / DMA past this item's last K tile
         __builtin_amdgcn_s_barrier();                                 // every wave is done with the ring
-        const int em0 = m0, en0 = n0;
+        const int em0 = m0, en0 = n0, e_slice = slice_id;
         const bool whole = k < n_whole;
         if (k + 1 < n_items) { set_item(k + 1); prologue_w(); }       // in flight during the epilogue below
         if (!whole) {                                                 // a slice: the raw accumulators, 16 B per thread and store
-            const __amdgpu_buffer_rsrc_t rsP = __builtin_amdgcn_make_buffer_rsrc((void*)(p.ws + (size_t)blockIdx.x * (128 * 512)), 0, 128 * 512 * 4, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rsP = __builtin_amdgcn_make_buffer_rsrc((void*)(p.ws + (size_t)e_slice * (128 * 512)), 0, 128 * 512 * 4, 0x00020000);
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -467,17 +469,16 @@ __global__ __launch_bounds__(512) void gemm_pair_8ph_fixup_kernel(const PairP p)
     }
 }
 
-// Tile quantisation: the persistent grid works in rounds of 256 tiles.  With a workspace the tiles of a short last round (at most 128 of them)
-// are cut along K into S = min(256 / n_cut, trips) slices, one workgroup each, and a small second launch sums the slices and runs the
-// epilogue (as conv3x3_halo8.hip does).
+// Tile quantisation: the persistent grid works in rounds of 256 tiles.  With a workspace the tiles of a short last round are cut along K into
+// S slices (dbmm_cut_slices, common.h) dealt over the workgroups, and a small second launch sums the slices and runs the epilogue (as
+// conv3x3_halo8.hip does).
 int pair_8ph_launch(PairP& p, int act, bool two, void* workspace, size_t workspace_bytes, void* stream) {
     p.tiles_n = p.N / 256;
     p.n_tiles = ((p.M + 255) / 256) * p.tiles_n;
     p.n_full = p.n_tiles; p.n_cut = 0; p.n_slices = 1; p.ws = nullptr;
     const int rem = p.n_tiles % 256, trips = p.K / 64;
-    if (!two && workspace && dbmm_aligned16(workspace) && p.n_tiles > 256 && rem != 0 && rem <= 128) {
-        int S = 256 / rem;
-        S = S < trips ? S : trips;
+    if (!two && workspace && dbmm_aligned16(workspace) && p.n_tiles > 256 && rem != 0) {
+        const int S = dbmm_cut_slices(rem, trips);
         if (S >= 2 && (size_t)rem * S * (128 * 512 * sizeof(float)) <= workspace_bytes) {
             p.n_full = p.n_tiles - rem; p.n_cut = rem; p.n_slices = S; p.ws = (float*)workspace;
         }
