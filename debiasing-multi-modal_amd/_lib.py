@@ -138,6 +138,7 @@ _SIGS = {
     "dbmm_avgpool2d": [_P, _P, _L, _L, _L, _L, _L, _P],
     "dbmm_workspace_bytes_attnpool": [_L, _L, _L],
     "dbmm_attnpool": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _L, _L, _L, _L, _P, _Z, _P],
+    "dbmm_attnpool_x": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _L, _L, _L, _L, _L, _P, _Z, _P],
     "dbmm_layernorm": [_P, _L, _P, _P, _P, _L, _L, _L, _F, _P, _P],
     "dbmm_mha_core": [_P, _P, _L, _L, _L, _L, _I, _P],
     "dbmm_mha_core_x2": [_P, _P, _P, _L, _L, _L, _L, _I, _P],

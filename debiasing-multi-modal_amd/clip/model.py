@@ -342,8 +342,8 @@ class ModifiedResNet(nn.Module):
                 x = ops.conv1x1_f16(out, *e["c3"], residual=identity)   # bn3(conv3) + identity, ReLU
             stages[f"layer{li}"] = x
         a = P["attn"]
-        # attention pool: the fp32-accurate kernels on the fp16 feature map (0.2 MB per image), result rounded to fp16
-        out = ops.attnpool(x.float(), a["pos"], a["wq"], a["bq"], a["wkv"], a["bkv"], a["wc"], a["bc"], self.attnpool.num_heads)
+        # attention pool: the fp32-accurate kernels on the fp16 feature map (0.2 MB per image, read as fp16), result rounded to fp16
+        out = ops.attnpool(x, a["pos"], a["wq"], a["bq"], a["wkv"], a["bkv"], a["wc"], a["bc"], self.attnpool.num_heads)
         out = out.to(torch.float16)
         return (out, stages) if return_stages else out
 

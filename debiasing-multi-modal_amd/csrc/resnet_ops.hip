@@ -370,18 +370,26 @@ __global__ __launch_bounds__(256) void avgpool_kernel(const float* __restrict__ 
 // ---------------------------------------------------------------------------------------
 // (token rows are padded with zero rows up to Lp = a multiple of 4 so that the token matrix can
 //  be used as a K-major GEMM operand)
-__global__ __launch_bounds__(256) void attnpool_tokens_kernel(const float* __restrict__ x,
+// XH = 1: x is fp16 (the fp16 mode's feature map, read directly instead of through a cast pass)
+template <int XH>
+__global__ __launch_bounds__(256) void attnpool_tokens_kernel(const void* __restrict__ x,
                                                               const float* __restrict__ pos,
                                                               float* __restrict__ t, int HW, int C4, int Lp) {
     const int b = blockIdx.y;
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C4) return;
-    const f32x4* xb = (const f32x4*)x + (long long)b * HW * C4 + c;
     const f32x4* pp = (const f32x4*)pos + c;
     f32x4* tb = (f32x4*)t + (long long)b * Lp * C4 + c;
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
     for (int j = 0; j < HW; ++j) {
-        const f32x4 v = xb[(long long)j * C4];
+        f32x4 v;
+        if constexpr (XH) {
+            typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+            const f16x4 h = ((const f16x4*)x)[((long long)b * HW + j) * C4 + c];
+            v = (f32x4){(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+        } else {
+            v = ((const f32x4*)x)[((long long)b * HW + j) * C4 + c];
+        }
         s += v;
         tb[(long long)(j + 1) * C4] = v + pp[(long long)(j + 1) * C4];
     }
@@ -469,10 +477,23 @@ extern "C" size_t dbmm_workspace_bytes_attnpool(int64_t B, int64_t HW, int64_t C
 //   score_h[j] = q_h . (Wk_h t_j + bk_h) = (Wk_h^T q_h) . t_j + const   -> softmax drops the const
 //   out_h      = sum_j p_h[j] (Wv_h t_j + bv_h) = Wv_h (sum_j p_h[j] t_j) + bv_h   (sum_j p = 1)
 // i.e. 2*(HW+1)*C*C MACs per image become ~4*C*C.  All products are (batched) MFMA GEMMs.
+extern "C" int dbmm_attnpool_x(const void* x, int x_is_f16, const float* pos, const float* wq, const float* bq,
+                               const float* wkv, const float* bkv, const float* wc, const float* bc, float* out,
+                               int64_t B, int64_t HW, int64_t C, int64_t heads, int64_t Dout, void* workspace,
+                               size_t workspace_bytes, void* stream);
+
 extern "C" int dbmm_attnpool(const float* x, const float* pos, const float* wq, const float* bq,
                              const float* wkv, const float* bkv, const float* wc, const float* bc, float* out,
                              int64_t B, int64_t HW, int64_t C, int64_t heads, int64_t Dout, void* workspace,
                              size_t workspace_bytes, void* stream) {
+    return dbmm_attnpool_x(x, 0, pos, wq, bq, wkv, bkv, wc, bc, out, B, HW, C, heads, Dout, workspace, workspace_bytes, stream);
+}
+
+// see include/dbmm.h: the same with the feature map in fp32 (x_is_f16 = 0) or fp16 (1; every later product in fp32 as before)
+extern "C" int dbmm_attnpool_x(const void* x, int x_is_f16, const float* pos, const float* wq, const float* bq,
+                               const float* wkv, const float* bkv, const float* wc, const float* bc, float* out,
+                               int64_t B, int64_t HW, int64_t C, int64_t heads, int64_t Dout, void* workspace,
+                               size_t workspace_bytes, void* stream) {
     if (!x || !pos || !wq || !wkv || !bkv || !wc || !out || !workspace) return DBMM_E_ARG;
     if (B <= 0 || HW <= 0 || C <= 0 || heads <= 0 || C != heads * 64 || (C & 3) || Dout <= 0 || B > 65535)
         return DBMM_E_SHAPE;
@@ -486,8 +507,10 @@ extern "C" int dbmm_attnpool(const float* x, const float* pos, const float* wq, 
     float* o = S + B * heads * Lp;           // [B][C]
     hipStream_t s = (hipStream_t)stream;
     const int C4 = (int)(C / 4);
-    hipLaunchKernelGGL(attnpool_tokens_kernel, dim3((C4 + 255) / 256, (unsigned)B), dim3(256), 0, s, x, pos, tok,
-                       (int)HW, C4, (int)Lp);
+    if (x_is_f16)
+        hipLaunchKernelGGL(attnpool_tokens_kernel<1>, dim3((C4 + 255) / 256, (unsigned)B), dim3(256), 0, s, x, pos, tok, (int)HW, C4, (int)Lp);
+    else
+        hipLaunchKernelGGL(attnpool_tokens_kernel<0>, dim3((C4 + 255) / 256, (unsigned)B), dim3(256), 0, s, x, pos, tok, (int)HW, C4, (int)Lp);
     DBMM_CHECK_LAUNCH();
     int rc;
     // q = (t_0 Wq^T + bq) * head_dim^-0.5          (token 0 of every image: row stride Lp*C)

@@ -469,17 +469,20 @@ def avgpool2d(x, k):
 
 
 def attnpool(x, pos, wq, bq, wkv, bkv, wc, bc, heads):
-    """x NHWC [B,h,w,C] feature map -> [B, Dout]."""
+    """x NHWC [B,h,w,C] feature map, fp32 or (fp16 mode) fp16 -> fp32 [B, Dout]."""
     require_cuda(x)
-    _f32c(x)
+    if x.dtype != torch.float16:
+        _f32c(x)
+    elif not x.is_contiguous():
+        raise _lib.DbmmError("attnpool: expected a contiguous tensor")
     B, H, W, C = x.shape
     HW = H * W
     Dout = wc.shape[0]
     nbytes = _lib.lib().dbmm_workspace_bytes_attnpool(B, HW, C)
     ws = _empty(nbytes // 4, device=x.device, dtype=torch.float32)
     out = _empty((B, Dout), device=x.device, dtype=torch.float32)
-    check(_lib.lib().dbmm_attnpool(ptr(x), ptr(pos), ptr(wq), ptr(bq), ptr(wkv), ptr(bkv), ptr(wc), ptr(bc),
-                                   ptr(out), B, HW, C, heads, Dout, ptr(ws), nbytes, stream()), "attnpool")
+    check(_lib.lib().dbmm_attnpool_x(ptr(x), int(x.dtype == torch.float16), ptr(pos), ptr(wq), ptr(bq), ptr(wkv), ptr(bkv), ptr(wc), ptr(bc),
+                                     ptr(out), B, HW, C, heads, Dout, ptr(ws), nbytes, stream()), "attnpool")
     return out
 
 

@@ -360,6 +360,12 @@ int dbmm_attnpool(const float* x, const float* pos, const float* wq, const float
                   const float* wkv, const float* bkv, const float* wc, const float* bc,
                   float* out, int64_t B, int64_t HW, int64_t C, int64_t heads, int64_t Dout,
                   void* workspace, size_t workspace_bytes, void* stream);
+/* The same on an fp32 (x_is_f16 = 0) or fp16 (1) feature map: the fp16 mode of the ModifiedResNet towers hands its fp16 map over without a
+ * cast pass; tokens, projections and softmax stay in fp32 as above. */
+int dbmm_attnpool_x(const void* x, int x_is_f16, const float* pos, const float* wq, const float* bq,
+                    const float* wkv, const float* bkv, const float* wc, const float* bc, float* out,
+                    int64_t B, int64_t HW, int64_t C, int64_t heads, int64_t Dout, void* workspace,
+                    size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Transformer pieces (clip/model.py:157-240, 343-356)

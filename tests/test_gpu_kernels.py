@@ -137,6 +137,12 @@ def test_attnpool():
                        torch.cat([d[p + "k_proj.bias"], d[p + "v_proj.bias"]]).contiguous(),
                        d[p + "c_proj.weight"], d[p + "c_proj.bias"], heads)
     assert relerr(out.cpu(), ref) < 1e-5
+    # the fp16 mode hands its fp16 feature map over as it is (dbmm_attnpool_x): same as casting it to fp32 first, bit for bit
+    xh = x.permute(0, 2, 3, 1).contiguous().to(DEV).half()
+    args = (d[p + "positional_embedding"], d[p + "q_proj.weight"], d[p + "q_proj.bias"],
+            torch.cat([d[p + "k_proj.weight"], d[p + "v_proj.weight"]]).contiguous(),
+            torch.cat([d[p + "k_proj.bias"], d[p + "v_proj.bias"]]).contiguous(), d[p + "c_proj.weight"], d[p + "c_proj.bias"], heads)
+    assert torch.equal(ops.attnpool(xh, *args), ops.attnpool(xh.float(), *args))
 
 
 @pytest.mark.parametrize("rows,E", [(7, 64), (100, 768), (33, 1024), (5, 100)])
