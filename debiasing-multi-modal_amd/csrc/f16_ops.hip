@@ -970,8 +970,8 @@ extern "C" int dbmm_conv1x1_bn_act_f16(const void* x, const void* w, const float
     // what dbmm_gemm_f16 gives the eight-phase kernel -- except the conv3 + residual shapes with K <= 256 (layers 2 / 3: two or four K tiles
     // per 256 x 256 tile, all prologue and epilogue): the streaming kernel is 6-7 % faster there (tools/bench_conv_f16.py, B = 1024:
     // 128 -> 512 + residual 397 -> 370 us, 256 -> 1024 + residual 246 -> 230 us)
-    const bool gemm8 = (Cout % 256) == 0 && (Cin % 128) == 0 && M >= 16384 && !(residual && Cin <= 256);
-    if ((mode == 2 || (mode == 1 && !gemm8)) && (act == DBMM_ACT_NONE || act == DBMM_ACT_RELU) && (Cin % 32) == 0) {
+    const bool gemm8 = (Cout % 256) == 0 && (Cin % 128) == 0 && M >= 16384 && !(residual && Cin <= 256 && mode != 3);
+    if ((mode == 2 || ((mode == 1 || mode == 3) && !gemm8)) && (act == DBMM_ACT_NONE || act == DBMM_ACT_RELU) && (Cin % 32) == 0) {
         const int rc = dbmm_conv1x1_stream_f16(x, w, scale, bias, residual, y, M, Cin, Cout, act, stream);
         if (rc != DBMM_E_UNSUPPORTED) return rc;
     }
@@ -982,8 +982,8 @@ extern "C" int dbmm_conv1x1_bn_act_f16(const void* x, const void* w, const float
 extern "C" int dbmm_conv1x1_bn_act_f16_ws(const void* x, const void* w, const float* scale, const float* bias, const void* residual, void* y,
                                           int64_t M, int64_t Cin, int64_t Cout, int act, void* workspace, size_t workspace_bytes, void* stream) {
     const int mode = dbmm_opt(OPT_CONV1X1_STREAM);
-    const bool gemm8 = (Cout % 256) == 0 && (Cin % 128) == 0 && M >= 16384 && !(residual && Cin <= 256);
-    if ((mode == 2 || (mode == 1 && !gemm8)) && (act == DBMM_ACT_NONE || act == DBMM_ACT_RELU) && (Cin % 32) == 0) {
+    const bool gemm8 = (Cout % 256) == 0 && (Cin % 128) == 0 && M >= 16384 && !(residual && Cin <= 256 && mode != 3);
+    if ((mode == 2 || ((mode == 1 || mode == 3) && !gemm8)) && (act == DBMM_ACT_NONE || act == DBMM_ACT_RELU) && (Cin % 32) == 0) {
         const int rc = dbmm_conv1x1_stream_f16(x, w, scale, bias, residual, y, M, Cin, Cout, act, stream);
         if (rc != DBMM_E_UNSUPPORTED) return rc;
     }

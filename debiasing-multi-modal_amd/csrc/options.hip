@@ -34,7 +34,8 @@ const OptDef kOpts[DBMM_OPT_COUNT] = {
     {"conv_patch", 1},         // (host wrappers) 32-channel stem convs on the persistent patch kernel
     {"mha_x2", 1},             // (host wrappers) parity attention core on fp16-pair products
     {"adapter_step_fused", 1}, // adapter forward / backward on the purpose-built kernels of adapter_step.hip (0: the general GEMM kernel)
-    {"conv1x1_stream", 1},     // fp16 mode 1x1 convs: 0 the GEMM kernels / 1 the streaming kernel for HBM-bound shapes / 2 wherever it applies
+    {"conv1x1_stream", 1},     // fp16 mode 1x1 convs: 0 the GEMM kernels / 1 the streaming kernel for HBM-bound shapes (incl. conv3 + residual with K <= 256) /
+                               // 2 wherever it applies / 3 round 3's rule (without that exception; same-box fp16 RN50: 52.57 k -> 53.05 k img/s for 1)
     {"conv1x1_8ph", 1},        // parity 1x1 convs on gemm_pair_8ph_kernel: 0 never / 1 where it measured ahead / 2 wherever it applies
     {"chain8", 0},             // 1: conv3 + residual -> next conv1 of the layer-3 geometry (K = P = 256) on the eight-wave chain kernel (measured
                                //    0.754 ms against 0.686 ms for the two launches: bottleneck_chain8.hip; kept, tested, off)

@@ -841,7 +841,8 @@ def conv1x1_f16(x, w, scale, bias, residual=None, act=ACT_RELU):
     deep = Cout % 256 == 0 and Cin % 128 == 0 and M >= 16384                            # what dbmm_gemm_f16 gives the eight-phase kernel
     mode = get_option("conv1x1_stream")
     # dbmm_conv1x1_bn_act_f16's own routing rule: the streaming kernel where the GEMM is not deep-pipelined, and for conv3 + residual with K <= 256
-    stream_k = (mode == 2 or (mode == 1 and not (deep and not (residual is not None and Cin <= 256)))) and act in (ACT_NONE, ACT_RELU) and Cin % 32 == 0
+    stream_k = ((mode == 2 or (mode == 1 and not (deep and not (residual is not None and Cin <= 256))) or (mode == 3 and not deep))
+                and act in (ACT_NONE, ACT_RELU) and Cin % 32 == 0)           # (mode 3: round 3's rule, without the conv3 + residual exception)
     res = int(residual is not None)
     tag = (f"conv1x1_f16_kernel<{'4, 1, 2' if Cout <= 64 else '2, 2, 4'}, {res}>" if stream_k
            else (f"gemm_f16_8ph_kernel<{act}, {res}>" if deep and get_option("f16_8ph") else _gemm_f16_tag(M, Cout)))
