@@ -302,6 +302,9 @@ class ModifiedResNet(nn.Module):
                 e = {"stride": blk.stride, "c1": c1x1(blk.conv1, blk.bn1), "c2": c3x3(blk.conv2, blk.bn2), "c3": c1x1(blk.conv3, blk.bn3)}
                 if blk.downsample is not None:
                     e["ds"] = c1x1(getattr(blk.downsample, "0"), getattr(blk.downsample, "1"))
+                    s3, sd = e["c3"][1], e["ds"][1]
+                    if float(s3.abs().min()) > 1e-20:                       # conv3 + downsample as one dual-source GEMM (ratio of the BN scales)
+                        e["dual"] = ((sd / s3).contiguous(), (e["c3"][2] + e["ds"][2]).contiguous())
                 blocks.append(e)
         P["blocks"] = blocks
         ap = self.attnpool
@@ -338,6 +341,12 @@ class ModifiedResNet(nn.Module):
                 if "ds" in e:
                     if e["stride"] == 2:
                         identity = ops.avgpool2_f16(x)
+                    fused = None
+                    if "dual" in e and _opt["fuse_ds"]:                     # conv3 + downsample branch in one launch where the library has the shape
+                        fused = ops.conv1x1_dual_f16(out, e["c3"][0], e["c3"][1], identity, e["ds"][0], *e["dual"])
+                    if fused is not None:
+                        x = fused
+                        continue
                     identity = ops.conv1x1_f16(identity, *e["ds"], act=ops.ACT_NONE)
                 x = ops.conv1x1_f16(out, *e["c3"], residual=identity)   # bn3(conv3) + identity, ReLU
             stages[f"layer{li}"] = x

@@ -71,6 +71,11 @@ struct GemmHP {
     // gemm_f16_8ph_fixup_kernel.  Kernels that do not cut ignore these (n_full is only read by the eight-phase kernel).
     int n_full, n_cut, n_slices;
     float* ws;
+    // gemm_f16_8ph_kernel<.., TWO = 1>: a second operand pair (a2 [M][K2], w2 [N][K2]) whose K2 / 64 tiles run FIRST; then the accumulators
+    // are multiplied per output column by ratio[n] and the main pair continues (conv3 + downsample branch as one GEMM, as gemm_pair_8ph.hip)
+    const u16* a2; const u16* w2; const float* ratio;
+    long long lda2, ldw2, a2_total, w2_total;
+    int K2;
 };
 
 constexpr int GBM = 128;
@@ -289,7 +294,7 @@ __device__ __forceinline__ void glds16(__amdgpu_buffer_rsrc_t r, unsigned char* 
 #endif
 }
 
-template <int ACT, int RES>                                          // epilogue specialised: a run-time `act` costs 22 VALU per output pair
+template <int ACT, int RES, int TWO = 0>                             // epilogue specialised: a run-time `act` costs 22 VALU per output pair
 __global__ __launch_bounds__(512, 1) void gemm_f16_8ph_kernel(const GemmHP p) {
     __shared__ __attribute__((aligned(1024))) unsigned char lds[8 * PH_HALF];      // [buffer 2][Ah0, Bh0, Bh1, Ah1] = 128 KB
     const int tid = threadIdx.x, lane = tid & 63;
@@ -301,8 +306,9 @@ __global__ __launch_bounds__(512, 1) void gemm_f16_8ph_kernel(const GemmHP p) {
     const int t_lo = xcd < trm ? xcd * (tq + 1) : trm * (tq + 1) + (xcd - trm) * tq, t_hi = t_lo + tq + (xcd < trm ? 1 : 0);
     const __amdgpu_buffer_rsrc_t rsA0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.a, 0, 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsW0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, 0, 0x00020000);
-    __amdgpu_buffer_rsrc_t rsA = rsA0, rsW = rsW0;
+    __amdgpu_buffer_rsrc_t rsA = rsA0, rsW = rsW0, rsA2 = rsA0, rsW2 = rsW0;
     int m0 = 0, n0 = 0;
+    float rr0 = 1.f, rr1 = 1.f;                                      // TWO: ratio of this lane's two output columns
     // stager: thread -> LDS chunk (tid + 512 i) of a half-tile = local row (tid >> 3) + 64 i, slot tid & 7; it fetches
     // source chunk slot ^ swz(row).  Half-tile kind k = 0..3 (Ah0, Bh0, Bh1, Ah1) -> operand rows:
     //   A half h: tile row (lr >> 6) * 128 + h * 64 + (lr & 63);   W half h: tile column (lr >> 5) * 64 + 2 * (lr & 31) + h
@@ -313,6 +319,13 @@ __global__ __launch_bounds__(512, 1) void gemm_f16_8ph_kernel(const GemmHP p) {
         m0 = (tile / p.tiles_n) * 256; n0 = (tile % p.tiles_n) * 256;
         rsA = desc(p.a, p.a_total, (long long)m0 * p.lda * 2);
         rsW = desc(p.w, p.w_total, (long long)n0 * p.ldw * 2);
+        if constexpr (TWO) {
+            rsA2 = desc(p.a2, p.a2_total, (long long)m0 * p.lda2 * 2);
+            rsW2 = desc(p.w2, p.w2_total, (long long)n0 * p.ldw2 * 2);
+            const int n = n0 + (wid & 3) * 64 + 2 * (lane & 31);
+            rr0 = p.ratio[n]; rr1 = p.ratio[n + 1];
+        }
+        if constexpr (!TWO)
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int lr = (tid >> 3) + 64 * i, c = (tid & 7) ^ ((lr >> 1) & 7);
@@ -324,15 +337,32 @@ __global__ __launch_bounds__(512, 1) void gemm_f16_8ph_kernel(const GemmHP p) {
             }
         }
     };
-    const int nT = p.K / 64;
+    const int nT2 = TWO ? p.K2 / 64 : 0, nT = nT2 + p.K / 64;       // K tiles of the second pair (they run first) / in all
     // stage number q: kind q & 3 of K tile q >> 2 into buffer (q >> 2) & 1; tiles past the end go through the zero-extent
     // descriptors so that every phase issues exactly two DMA instructions per wave (the vmcnt arithmetic relies on it)
+    // (TWO: the second pair's lane offsets are recomputed here -- eight more registers spilled inside the loop --, and tiles past the end
+    //  fetch whatever follows into buffers no phase reads again: two-way descriptor selects only)
     auto stage = [&](int kind, int buf, int t) {
-        const bool isA = kind == 0 || kind == 3, valid = t < nT;
-        const __amdgpu_buffer_rsrc_t rs = isA ? (valid ? rsA : rsA0) : (valid ? rsW : rsW0);
+        const bool isA = kind == 0 || kind == 3, valid = t < nT, second = TWO && t < nT2;
         unsigned char* slot = lds + (buf * 4 + kind) * PH_HALF + wid * 1024;
+        if constexpr (TWO) {
+            const __amdgpu_buffer_rsrc_t rs = isA ? (second ? rsA2 : rsA) : (second ? rsW2 : rsW);
+            const int h = kind >> 1;                                  // kinds 0, 1 -> half 0; 2, 3 -> half 1
+            int tid_o = tid;
+            asm volatile("" : "+v"(tid_o));                           // opaque: the offsets below are loop-invariant and would be hoisted (and spilled)
+            const unsigned ld2 = (unsigned)((isA ? (second ? p.lda2 : p.lda) : (second ? p.ldw2 : p.ldw)) * 2);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) glds16(rs, slot + i * 8192, voff[kind][i], (unsigned)t * 128u);
+            for (int i = 0; i < 2; ++i) {
+                const int lr = (tid_o >> 3) + 64 * i, c = (tid_o & 7) ^ ((lr >> 1) & 7);
+                const int ra = (lr >> 6) * 128 + h * 64 + (lr & 63), rw = (lr >> 5) * 64 + 2 * (lr & 31) + h;
+                const unsigned vo = isA ? (m0 + ra < p.M ? (unsigned)ra * ld2 + c * 16u : OOR) : (unsigned)rw * ld2 + c * 16u;
+                glds16(rs, slot + i * 8192, vo, (unsigned)(second ? t : t - nT2) * 128u);
+            }
+        } else {
+            const __amdgpu_buffer_rsrc_t rs = isA ? (valid ? rsA : rsA0) : (valid ? rsW : rsW0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) glds16(rs, slot + i * 8192, voff[kind][i], (unsigned)t * 128u);
+        }
     };
     // fragment addresses inside a half-tile (bytes): A rows wr * 64 + blk * 32 + fr, W rows wc * 32 + fr, chunk (2 ks + fh) ^ swz
     int aoff[2][4], boff[4];
@@ -400,7 +430,7 @@ __global__ __launch_bounds__(512, 1) void gemm_f16_8ph_kernel(const GemmHP p) {
     // Work items of this workgroup: its whole tiles (all K tiles), then -- if there are cut tiles and this workgroup's index is below
     // n_cut * n_slices -- one slice: a cut tile's loop trips [s T / S, (s + 1) T / S)
     const int n_whole = t_lo + slot_in_xcd < t_hi ? (t_hi - t_lo - slot_in_xcd + wg_per_xcd - 1) / wg_per_xcd : 0;
-    const bool has_slice = (int)blockIdx.x < p.n_cut * p.n_slices;
+    const bool has_slice = !TWO && (int)blockIdx.x < p.n_cut * p.n_slices;
     const int n_items = n_whole + (has_slice ? 1 : 0);
     int tb = 0, te = nT;                                              // the current item's K tiles [tb, te), both even
     auto set_item = [&](int k) {
@@ -448,6 +478,12 @@ __global__ __launch_bounds__(512, 1) void gemm_f16_8ph_kernel(const GemmHP p) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) phase(j, tb, true);
     for (int t2 = tb + 2; t2 < ((GF16_ABL & 8) ? tb + 2 : te); t2 += 2) {
+        if (TWO && t2 == nT2) {                                       // the second pair's sums -> the main pair's scale (K2 / 64 and t2 are even)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { acc[i][0][r] *= rr0; acc[i][1][r] *= rr1; }
+        }
 #pragma unroll
         for (int j = 0; j < 8; ++j) phase(j, t2, false);
     }
@@ -988,6 +1024,32 @@ extern "C" int dbmm_conv1x1_bn_act_f16_ws(const void* x, const void* w, const fl
         if (rc != DBMM_E_UNSUPPORTED) return rc;
     }
     return gemm_f16_impl(x, Cin, w, Cin, scale, bias, residual, Cout, 1, y, Cout, M, Cout, Cin, act, stream, 0, workspace, workspace_bytes);
+}
+
+// see include/dbmm.h: conv3 + downsample branch of a stage's first block as ONE GEMM on the eight-phase kernel (TWO = 1)
+extern "C" int dbmm_conv1x1_dual_bn_act_f16(const void* y2, const void* w3, const float* scale3, const void* xp, const void* wd, const float* ratio,
+                                            const float* bias, void* out, int64_t M, int64_t K, int64_t K2, int64_t Cout, int act, void* stream) {
+    if (!y2 || !w3 || !scale3 || !xp || !wd || !ratio || !out) return DBMM_E_ARG;
+    if (M <= 0 || K <= 0 || K2 <= 0 || Cout <= 0 || M > INT32_MAX) return DBMM_E_SHAPE;
+    if (act != DBMM_ACT_NONE && act != DBMM_ACT_RELU) return DBMM_E_ARG;
+    if (!dbmm_opt(OPT_F16_8PH) || (Cout % 256) || (K % 128) || (K2 % 128) || M < 16384) return DBMM_E_UNSUPPORTED;
+    if (!dbmm_aligned16(y2) || !dbmm_aligned16(w3) || !dbmm_aligned16(xp) || !dbmm_aligned16(wd) || !dbmm_aligned16(out) || !dbmm_aligned16(scale3) ||
+        (bias && !dbmm_aligned16(bias)))
+        return DBMM_E_ALIGN;
+    GemmHP p{};
+    p.a = (const u16*)y2; p.w = (const u16*)w3; p.bias = bias; p.res = nullptr; p.c = (u16*)out; p.oscale = scale3; p.res_first = 1;
+    p.lda = K; p.ldw = K; p.ldr = 0; p.ldc = Cout; p.a_total = M * K * 2; p.w_total = Cout * K * 2;
+    p.a2 = (const u16*)xp; p.w2 = (const u16*)wd; p.ratio = ratio; p.lda2 = K2; p.ldw2 = K2; p.a2_total = M * K2 * 2; p.w2_total = Cout * K2 * 2;
+    p.K2 = (int)K2;
+    p.M = (int)M; p.N = (int)Cout; p.K = (int)K; p.act = act;
+    p.tiles_n = (int)(Cout / 256);
+    p.n_tiles = (int)((M + 255) / 256) * p.tiles_n;
+    p.n_full = p.n_tiles; p.n_cut = 0; p.n_slices = 1; p.ws = nullptr;
+    const int grid = p.n_tiles < 256 ? p.n_tiles : 256;
+    if (act == DBMM_ACT_RELU) hipLaunchKernelGGL((gemm_f16_8ph_kernel<1, 0, 1>), dim3(grid), dim3(512), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((gemm_f16_8ph_kernel<0, 0, 1>), dim3(grid), dim3(512), 0, (hipStream_t)stream, p);
+    DBMM_CHECK_LAUNCH();
+    return DBMM_OK;
 }
 
 namespace {

@@ -859,6 +859,26 @@ def conv1x1_f16(x, w, scale, bias, residual=None, act=ACT_RELU):
     return y
 
 
+def conv1x1_dual_f16(y2, w3, scale3, xp, wd, ratio, bias, act=ACT_RELU):
+    """fp16 mode: act(conv3(y2) * scale3 + conv_d(xp) * scale_d + bias) as one dual-source GEMM (dbmm_conv1x1_dual_bn_act_f16);
+    ratio = scale_d / scale3, bias = both BatchNorm biases.  None when the library has no kernel for the shape."""
+    require_cuda(y2, xp)
+    _f16c(y2); _f16c(xp); _f16c(w3); _f16c(wd)
+    Cout, K = w3.shape
+    K2 = wd.shape[1]
+    M = y2.numel() // K
+    out = _empty(tuple(y2.shape[:-1]) + (Cout,), device=y2.device, dtype=torch.float16)
+    t = _TimedTag("gemm_f16_8ph_kernel<dual>", 2.0 * M * Cout * (K + K2), 2 * (M * (K + K2) + Cout * (K + K2) + M * Cout))
+    t.__enter__()
+    rc = _lib.lib().dbmm_conv1x1_dual_bn_act_f16(ptr(y2), ptr(w3), ptr(scale3), ptr(xp), ptr(wd), ptr(ratio), ptr(bias), ptr(out), M, K, K2, Cout,
+                                                 act, stream())
+    t.__exit__(None if rc == 0 else DbmmUnsupported, None, None)
+    if rc == _lib.E_UNSUPPORTED:
+        return None
+    check(rc, "conv1x1_dual_bn_act_f16")
+    return out
+
+
 def conv3x3_f16(x, w, scale, bias, pool=1):
     """y f16 NHWC = [AvgPool2d(2)] relu(conv3x3(x, stride 1, pad 1) * scale + bias); x f16 [B,H,W,Cin], w f16 [Cout][(cin/32, kh, kw, 32)];
     None when the library has no kernel for the shape."""

@@ -366,3 +366,24 @@ def test_fp16_conv_kernels_on_operands_over_2gib():
                 ref = F.avg_pool2d(ref, 2)
             assert relerr(y[i].double().cpu(), ref[0].permute(1, 2, 0).cpu()) < 1.5e-3, (pool, i)
         del y
+
+
+@pytest.mark.parametrize("M,K,K2,N", [(28 * 28 * 24, 128, 256, 512), (14 * 14 * 90 + 12, 256, 512, 1024), (7 * 7 * 340, 512, 1024, 2048)])
+def test_conv1x1_dual_f16(M, K, K2, N):
+    """fp16 mode, first block of a stage: relu(bn3(conv3(y2)) + bn_d(conv_d(xp))) as ONE dual-source GEMM on the eight-phase kernel
+    (clip/model.py:36-38, 42-55) against fp64 and against the two launches it replaces (one fp16 rounding less: the identity is never
+    rounded to fp16); shapes the library does not take answer None"""
+    g = torch.Generator(device=DEV); g.manual_seed(M + K)
+    y2 = torch.relu(torch.randn((M, K), device=DEV, generator=g)).half(); xp = torch.relu(torch.randn((M, K2), device=DEV, generator=g) * 2.0).half()
+    w3 = (torch.randn((N, K), device=DEV, generator=g) * K ** -0.5).half(); wd = (torch.randn((N, K2), device=DEV, generator=g) * K2 ** -0.5).half()
+    s3 = 0.5 + torch.rand((N,), device=DEV, generator=g); sd = 0.5 + torch.rand((N,), device=DEV, generator=g)
+    b3 = torch.randn((N,), device=DEV, generator=g) * 0.1; bd = torch.randn((N,), device=DEV, generator=g) * 0.1
+    out = ops.conv1x1_dual_f16(y2, w3, s3, xp, wd, (sd / s3).contiguous(), (b3 + bd).contiguous())
+    assert out is not None and out.dtype == torch.float16 and tuple(out.shape) == (M, N)
+    rows = torch.cat([torch.arange(0, 300, device=DEV), torch.randint(0, M, (1500,), device=DEV, generator=g), torch.arange(M - 300, M, device=DEV)])
+    ref = torch.relu(y2[rows].double() @ w3.double().t() * s3.double() + xp[rows].double() @ wd.double().t() * sd.double() + (b3 + bd).double())
+    assert torch.allclose(out[rows].double(), ref, rtol=2e-3, atol=2e-3)
+    ident = ops.conv1x1_f16(xp, wd, sd, bd, act=ops.ACT_NONE)
+    two = ops.conv1x1_f16(y2, w3, s3, b3, residual=ident)
+    assert (out.float() - two.float()).abs().max().item() <= 8e-3 * max(1.0, two.float().abs().max().item())
+    assert ops.conv1x1_dual_f16(y2[:1000], w3, s3, xp[:1000], wd, (sd / s3).contiguous(), (b3 + bd).contiguous()) is None      # M < 16384
