@@ -65,6 +65,9 @@ struct ConvHP {
     int B, H, W, Cin, N, M;                     // M = B * H * W conv output pixels
     int tiles_n, n_tiles;
     const u16* res; int act;                    // 1x1 kernel: residual [M][N] added before the activation; act 0 | 1 (ReLU)
+    // 1x1 kernel, TWO = 1 (conv3 + downsample branch of a stage's first block as one launch): a second operand pair x2 [M][Cin2], w2 [N][Cin2]
+    // whose chunks run first; then the accumulators are multiplied per output channel by ratio[n] and the main pair continues
+    const u16* x2; const u16* w2; const float* ratio; long long x2_total, w2_total; int Cin2;
 };
 
 // standard-order pixel of the corner of pooled pixel mp (2x2 windows of an H x W map)
@@ -331,7 +334,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16_kernel(const ConvHP p) {
 // TM = 2: 256 x 64 for Cout <= 64).  Epilogue from the accumulator layout; the residual is loaded in the same shape
 // (one packed dword = two channels per lane, 128-B row segments), a row block's 16 loads in flight together.
 // ---------------------------------------------------------------------------------------------------------------
-template <int WM, int WN, int TM, int RES>
+template <int WM, int WN, int TM, int RES, int TWO = 0>
 __global__ __launch_bounds__(256, 2) void conv1x1_f16_kernel(const ConvHP p) {
     static_assert(WM * WN == 4 && (TM == 2 || TM == 4), "4 waves; a wave tile is 32 TM rows x 64 columns");
     constexpr int TN = 2, BM = WM * TM * 32, BN = WN * 64;
@@ -348,12 +351,16 @@ __global__ __launch_bounds__(256, 2) void conv1x1_f16_kernel(const ConvHP p) {
     const int m0 = (tile / p.tiles_n) * BM, n0 = (tile % p.tiles_n) * BN;
     const __amdgpu_buffer_rsrc_t rsA = desc(p.x, p.x_total, (long long)m0 * p.Cin * 2);
     const __amdgpu_buffer_rsrc_t rsW = desc(p.w, p.w_total, (long long)n0 * p.Cin * 2);
+    const __amdgpu_buffer_rsrc_t rsA2 = TWO ? desc(p.x2, p.x2_total, (long long)m0 * p.Cin2 * 2) : rsA;
+    const __amdgpu_buffer_rsrc_t rsW2 = TWO ? desc(p.w2, p.w2_total, (long long)n0 * p.Cin2 * 2) : rsW;
+    const int G2 = TWO ? p.Cin2 >> 5 : 0;                        // chunks of the second pair (they run first)
 
-    unsigned fa_off[NA], fw_off[NWI];
+    unsigned fa_off[NA], fw_off[NWI], fa_off2[TWO ? NA : 1], fw_off2[TWO ? NWI : 1];
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
         const int k = wave + 4 * i, row = 16 * k + (lane >> 2), c = (lane & 3) ^ ((row >> 2) & 3);
         fa_off[i] = m0 + row < p.M ? (unsigned)row * (unsigned)(p.Cin * 2) + c * 16u : OOR;
+        if constexpr (TWO) fa_off2[i] = m0 + row < p.M ? (unsigned)row * (unsigned)(p.Cin2 * 2) + c * 16u : OOR;
     }
 #pragma unroll
     for (int i = 0; i < NWI; ++i) {
@@ -361,15 +368,18 @@ __global__ __launch_bounds__(256, 2) void conv1x1_f16_kernel(const ConvHP p) {
         const int wq = row >> 6, within = row & 63, j = within >> 5, cc = within & 31;
         const int nrel = wq * 64 + 2 * cc + j;                                       // block j, column cc <-> channel 2 cc + j
         fw_off[i] = (k < NWT && n0 + nrel < p.N) ? (unsigned)nrel * (unsigned)(p.Cin * 2) + c * 16u : OOR;
+        if constexpr (TWO) fw_off2[i] = (k < NWT && n0 + nrel < p.N) ? (unsigned)nrel * (unsigned)(p.Cin2 * 2) + c * 16u : OOR;
     }
     auto issue = [&](int t, int slot, bool valid) {              // K chunk t = channels [32 t, 32 t + 32) of both operands
-        const unsigned so = valid ? (unsigned)t * 64u : 0u;      // a chunk past K: out of range by lane (voffset = OOR), zero scalar offset
+        const bool second = TWO && t < G2;
+        const unsigned so = valid ? (unsigned)(second ? t : t - G2) * 64u : 0u;      // a chunk past K: out of range by lane (voffset = OOR), zero scalar offset
 #pragma unroll
-        for (int i = 0; i < NA; ++i) glds16(rsA, lds + slot * SLOT + (wave + 4 * i) * 1024, valid ? fa_off[i] : OOR, so);
+        for (int i = 0; i < NA; ++i)
+            glds16(second ? rsA2 : rsA, lds + slot * SLOT + (wave + 4 * i) * 1024, valid ? (second ? fa_off2[TWO ? i : 0] : fa_off[i]) : OOR, so);
 #pragma unroll
         for (int i = 0; i < NWI; ++i) {
             const int k = wave + 4 * i;
-            glds16(rsW, k < NWT ? lds + slot * SLOT + A_BYTES + k * 1024 : lds + DUMP, valid ? fw_off[i] : OOR, so);
+            glds16(second ? rsW2 : rsW, k < NWT ? lds + slot * SLOT + A_BYTES + k * 1024 : lds + DUMP, valid ? (second ? fw_off2[TWO ? i : 0] : fw_off[i]) : OOR, so);
         }
     };
     int faddr[TM], waddr[TN];
@@ -391,11 +401,19 @@ __global__ __launch_bounds__(256, 2) void conv1x1_f16_kernel(const ConvHP p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int G = p.Cin >> 5;
+    const int G = G2 + (p.Cin >> 5);
     issue(0, 0, true);
     issue(1, 1, 1 < G);
     int slot = 0;
     for (int t = 0; t < G; ++t) {
+        if (TWO && t == G2) {                                    // the second pair's sums -> the main pair's scale
+            const int nc = n0 + wn * 64 + 2 * fr;
+            const float r0 = nc < p.N ? p.ratio[nc] : 1.f, r1 = nc + 1 < p.N ? p.ratio[nc + 1] : 1.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { acc[i][0][r] *= r0; acc[i][1][r] *= r1; }
+        }
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA + NWI) : "memory");       // chunk t has landed; chunk t + 1 may be in flight
         __builtin_amdgcn_s_barrier();
         {
@@ -604,6 +622,23 @@ int dbmm_conv1x1_stream_f16(const void* x, const void* w, const float* scale, co
         if (residual) hipLaunchKernelGGL((conv1x1_f16_kernel<2, 2, 4, 1>), dim3(p.n_tiles), dim3(256), 0, s, p);
         else hipLaunchKernelGGL((conv1x1_f16_kernel<2, 2, 4, 0>), dim3(p.n_tiles), dim3(256), 0, s, p);
     }
+    DBMM_CHECK_LAUNCH();
+    return DBMM_OK;
+}
+
+// the streaming kernel with a second operand pair (dbmm_conv1x1_dual_bn_act_f16 in f16_ops.hip routes here what its GEMM kernel does not take)
+int dbmm_conv1x1_dual_stream_f16(const void* y2, const void* w3, const float* scale3, const void* xp, const void* wd, const float* ratio,
+                                 const float* bias, void* out, int64_t M, int64_t K, int64_t K2, int64_t Cout, int act, void* stream) {
+    if (M <= 0 || M > INT32_MAX - 1024) return DBMM_E_SHAPE;
+    if ((K % 32) || (K2 % 32) || (Cout % 8) || Cout <= 64) return DBMM_E_UNSUPPORTED;
+    if (Cout * (K > K2 ? K : K2) * 2 >= EXT_LIM || 512LL * (K > K2 ? K : K2) * 2 >= EXT_LIM || 512LL * Cout * 2 >= EXT_LIM) return DBMM_E_UNSUPPORTED;
+    ConvHP p{};
+    p.x = (const u16*)y2; p.w = (const u16*)w3; p.scale = scale3; p.bias = bias; p.y = (u16*)out; p.res = nullptr; p.act = act;
+    p.x_total = M * K * 2; p.w_total = Cout * K * 2; p.y_total = M * Cout * 2;
+    p.x2 = (const u16*)xp; p.w2 = (const u16*)wd; p.ratio = ratio; p.x2_total = M * K2 * 2; p.w2_total = Cout * K2 * 2; p.Cin2 = (int)K2;
+    p.Cin = (int)K; p.N = (int)Cout; p.M = (int)M;
+    p.tiles_n = (int)((Cout + 127) / 128); p.n_tiles = (int)((M + 255) / 256) * p.tiles_n;
+    hipLaunchKernelGGL((conv1x1_f16_kernel<2, 2, 4, 0, 1>), dim3(p.n_tiles), dim3(256), 0, (hipStream_t)stream, p);
     DBMM_CHECK_LAUNCH();
     return DBMM_OK;
 }

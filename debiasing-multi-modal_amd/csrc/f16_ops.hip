@@ -997,6 +997,8 @@ extern "C" int dbmm_gemm_f16_ws(const void* a, int64_t lda, const void* w, int64
 // residual added BEFORE the activation (Bottleneck.forward, clip/model.py:42-55); see include/dbmm.h
 int dbmm_conv1x1_stream_f16(const void* x, const void* w, const float* scale, const float* bias, const void* residual, void* y, int64_t M,
                             int64_t Cin, int64_t Cout, int act, void* stream);       // conv_f16.hip
+int dbmm_conv1x1_dual_stream_f16(const void* y2, const void* w3, const float* scale3, const void* xp, const void* wd, const float* ratio,
+                                 const float* bias, void* out, int64_t M, int64_t K, int64_t K2, int64_t Cout, int act, void* stream);   // conv_f16.hip
 
 extern "C" int dbmm_conv1x1_bn_act_f16(const void* x, const void* w, const float* scale, const float* bias, const void* residual, void* y,
                                        int64_t M, int64_t Cin, int64_t Cout, int act, void* stream) {
@@ -1032,10 +1034,12 @@ extern "C" int dbmm_conv1x1_dual_bn_act_f16(const void* y2, const void* w3, cons
     if (!y2 || !w3 || !scale3 || !xp || !wd || !ratio || !out) return DBMM_E_ARG;
     if (M <= 0 || K <= 0 || K2 <= 0 || Cout <= 0 || M > INT32_MAX) return DBMM_E_SHAPE;
     if (act != DBMM_ACT_NONE && act != DBMM_ACT_RELU) return DBMM_E_ARG;
-    if (!dbmm_opt(OPT_F16_8PH) || (Cout % 256) || (K % 128) || (K2 % 128) || M < 16384) return DBMM_E_UNSUPPORTED;
     if (!dbmm_aligned16(y2) || !dbmm_aligned16(w3) || !dbmm_aligned16(xp) || !dbmm_aligned16(wd) || !dbmm_aligned16(out) || !dbmm_aligned16(scale3) ||
         (bias && !dbmm_aligned16(bias)))
         return DBMM_E_ALIGN;
+    // short K (layer 1: 64 + 64 channels) or narrow shapes: the streaming kernel's dual-source mode; the rest on the eight-phase GEMM
+    if (!dbmm_opt(OPT_F16_8PH) || (Cout % 256) || (K % 128) || (K2 % 128) || M < 16384)
+        return dbmm_conv1x1_dual_stream_f16(y2, w3, scale3, xp, wd, ratio, bias, out, M, K, K2, Cout, act, stream);
     GemmHP p{};
     p.a = (const u16*)y2; p.w = (const u16*)w3; p.bias = bias; p.res = nullptr; p.c = (u16*)out; p.oscale = scale3; p.res_first = 1;
     p.lda = K; p.ldw = K; p.ldr = 0; p.ldc = Cout; p.a_total = M * K * 2; p.w_total = Cout * K * 2;

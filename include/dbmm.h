@@ -279,7 +279,8 @@ int dbmm_conv1x1_bn_act_f16(const void* x, const void* w, const float* scale, co
  * over the concatenated K -- the downsample branch's output is never written or re-read.  y2 f16 [M][K] (conv2's output), xp f16 [M][K2]
  * (the pooled block input), w3 f16 [Cout][K], wd f16 [Cout][K2], ratio[n] = scale_d[n] / scale3[n] (scale3 non-zero), bias = both
  * BatchNorm biases added.  The kernel accumulates the second pair first, multiplies the fp32 accumulators by ratio[n] and continues with
- * the first.  Cout % 256 == 0, K % 128 == 0, K2 % 128 == 0, M >= 16384; otherwise DBMM_E_UNSUPPORTED (nothing launched). */
+ * the first.  On the deep-pipelined GEMM kernel when Cout % 256 == 0, K % 128 == 0, K2 % 128 == 0 and M >= 16384, otherwise on the
+ * streaming 1x1 kernel (K % 32 == 0, K2 % 32 == 0, Cout > 64, Cout % 8 == 0: layer 1); DBMM_E_UNSUPPORTED (nothing launched) beyond that. */
 int dbmm_conv1x1_dual_bn_act_f16(const void* y2, const void* w3, const float* scale3, const void* xp, const void* wd, const float* ratio,
                                  const float* bias, void* out, int64_t M, int64_t K, int64_t K2, int64_t Cout, int act, void* stream);
 int dbmm_conv1x1_bn_act_f16_ws(const void* x, const void* w, const float* scale, const float* bias, const void* residual, void* y,

@@ -368,7 +368,9 @@ def test_fp16_conv_kernels_on_operands_over_2gib():
         del y
 
 
-@pytest.mark.parametrize("M,K,K2,N", [(28 * 28 * 24, 128, 256, 512), (14 * 14 * 90 + 12, 256, 512, 1024), (7 * 7 * 340, 512, 1024, 2048)])
+@pytest.mark.parametrize("M,K,K2,N", [(28 * 28 * 24, 128, 256, 512), (14 * 14 * 90 + 12, 256, 512, 1024), (7 * 7 * 340, 512, 1024, 2048),
+                                      # the streaming kernel's dual-source mode: layer 1 (64 + 64 channels), a small ragged problem, Cout % 128 != 0
+                                      (56 * 56 * 6, 64, 64, 256), (1000 + 77, 128, 256, 512), (56 * 56 * 2 + 5, 64, 96, 200)])
 def test_conv1x1_dual_f16(M, K, K2, N):
     """fp16 mode, first block of a stage: relu(bn3(conv3(y2)) + bn_d(conv_d(xp))) as ONE dual-source GEMM on the eight-phase kernel
     (clip/model.py:36-38, 42-55) against fp64 and against the two launches it replaces (one fp16 rounding less: the identity is never
@@ -386,4 +388,11 @@ def test_conv1x1_dual_f16(M, K, K2, N):
     ident = ops.conv1x1_f16(xp, wd, sd, bd, act=ops.ACT_NONE)
     two = ops.conv1x1_f16(y2, w3, s3, b3, residual=ident)
     assert (out.float() - two.float()).abs().max().item() <= 8e-3 * max(1.0, two.float().abs().max().item())
-    assert ops.conv1x1_dual_f16(y2[:1000], w3, s3, xp[:1000], wd, (sd / s3).contiguous(), (b3 + bd).contiguous()) is None      # M < 16384
+    # guard zone: nothing written past the (possibly ragged) output
+    buf = torch.full((M * N + 4096,), 7.0, device=DEV, dtype=torch.float16)
+    from dbmm_amd import _lib
+    ratio, bsum = (sd / s3).contiguous(), (b3 + bd).contiguous()           # (kept alive: the call takes raw pointers)
+    rc = _lib.lib().dbmm_conv1x1_dual_bn_act_f16(y2.data_ptr(), w3.data_ptr(), s3.data_ptr(), xp.data_ptr(), wd.data_ptr(), ratio.data_ptr(),
+                                                 bsum.data_ptr(), buf.data_ptr(), M, K, K2, N, ops.ACT_RELU, _lib.stream())
+    torch.cuda.synchronize()
+    assert rc == 0 and torch.equal(buf[:M * N].view(M, N), out) and (buf[M * N:] == 7.0).all()
