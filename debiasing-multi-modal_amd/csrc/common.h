@@ -18,7 +18,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 enum DbmmOpt {
     OPT_IGEMM_EPI_DIRECT, OPT_IGEMM_FAST, OPT_IGEMM_STREAMK, OPT_IGEMM_X3, OPT_IGEMM_X2, OPT_IGEMM_X2_BK, OPT_IGEMM_BK,
     OPT_IGEMM_HALO, OPT_IGEMM_HALO_POOL, OPT_IGEMM_BN256, OPT_IGEMM_BN256_KXK, OPT_GEMM_8PH, OPT_F16_8PH, OPT_F16_BN256,
-    OPT_STEM_MFMA, OPT_MHA_VALU, OPT_CONV_PATCH, OPT_MHA_X2, OPT_ADAPTER_STEP_FUSED, OPT_CONV1X1_STREAM, OPT_CONV1X1_8PH, OPT_CHAIN8, OPT_CONV1X1_BN256, OPT_TAIL_SPLIT, OPT_HALO8, OPT_DUAL_8PH, OPT_MHA_SHORT, DBMM_OPT_COUNT
+    OPT_STEM_MFMA, OPT_MHA_VALU, OPT_CONV_PATCH, OPT_MHA_X2, OPT_ADAPTER_STEP_FUSED, OPT_CONV1X1_STREAM, OPT_CONV1X1_8PH, OPT_CHAIN8, OPT_CONV1X1_BN256, OPT_TAIL_SPLIT, OPT_HALO8, OPT_DUAL_8PH, OPT_MHA_SHORT, OPT_F16_CONV_8PH, DBMM_OPT_COUNT
 };
 int dbmm_opt(int id);
 

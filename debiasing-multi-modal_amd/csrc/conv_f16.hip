@@ -564,6 +564,242 @@ __global__ __launch_bounds__(256) void avgpool2_f16_kernel(const u16* __restrict
                                          pack2(s[4] * 0.25f, s[5] * 0.25f), pack2(s[6] * 0.25f, s[7] * 0.25f)};
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The 3x3 conv for Cout % 256 == 0 (layers 3 / 4) on the eight-phase structure of gemm_f16_8ph_kernel / conv3x3_halo8_kernel: 512 threads =
+// 4 x 2 waves of 64 x 128 outputs, tile 256 pixels x 256 channels, two wave groups a barrier apart, persistent workgroups.  A tap (one
+// 32-channel K tile) is TWO phases of 8 MFMAs -- q0: both row blocks x the first 64 of the wave's 128 columns, q1: x the second 64 -- with
+// six fragment reads each (q0: four W fragments + row block 1 of the tap; q1: four W fragments + row block 0 of the NEXT tap).  Everything
+// reaches LDS by LDS-DMA: the tap's W tile (256 x 32 fp16 = 16 KB) as two half-tiles into a ring of three (first half issued at q1 three taps
+// ahead, second at the following q0), the activation strip of a (32-channel slab, kh) group (258 pixels; POOL: two strips of 130) into a
+// ring of three, issued at the first phase of the group two groups ahead; waits are counted.  A loop trip = three groups = one slab: W
+// buffer = kw, strip buffer = kh, mask bit = 3 kh + kw are compile-time.  Same arithmetic and order of accumulation as conv3x3_f16_kernel.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int E_AROWS = 384, E_ABUF = E_AROWS * 64;              // strip rows a group's three DMA instructions per thread cover; bytes
+constexpr int E_WBUF = 256 * 64, E_WHALF = 128 * 64;
+constexpr int E_OFF_A = 3 * E_WBUF;                               // W ring first: fragment reads reach buffers / blocks through ds_read immediates
+constexpr int E_LDS = E_OFF_A + 3 * E_ABUF;                       // 49,152 + 73,728 = 122,880
+constexpr int E_STRIP1 = 136, E_ZROW = 268;                       // POOL: row of the dy = 1 strip; the zero line (rows 268..271, never a strip row)
+
+template <int POOL>
+__global__ __launch_bounds__(512, 1) void conv3x3_f16_8ph_kernel(const ConvHP p) {
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[E_LDS];
+    constexpr int NLD = POOL ? 2 * E_STRIP1 : 258;                // strip rows in use (POOL: rows 130..135 of the first strip's block stay unused)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6), wr = wid >> 1, wc = wid & 1, grp = wid >> 2;
+    const int fr = lane & 31, fh = lane >> 5;
+    const int nwg = gridDim.x, xcd = blockIdx.x & 7, slot_in_xcd = blockIdx.x >> 3, wg_per_xcd = (nwg - xcd + 7) >> 3;
+    const int tq = p.n_tiles >> 3, trm = p.n_tiles & 7;
+    const int t_lo = xcd < trm ? xcd * (tq + 1) : trm * (tq + 1) + (xcd - trm) * tq, t_hi = t_lo + tq + (xcd < trm ? 1 : 0);
+    __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, 0, 0x00020000), rsW = rsA;
+    int m0 = 0, n0 = 0;
+    const int G = 3 * (p.Cin >> 5);
+
+    // W half-tile h by LDS-DMA: thread -> LDS row rl = tid >> 2 of the half (wave column rl >> 6, block j = (rl >> 5) & 1, column cc = rl & 31 <->
+    // channel 2 cc + j of the wave's h-th 64: a lane's two accumulator blocks of a half are ADJACENT channels), slot tid & 3
+    unsigned voffW[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int rl = tid >> 2, nrel = (rl >> 6) * 128 + h * 64 + 2 * (rl & 31) + ((rl >> 5) & 1);
+        voffW[h] = (unsigned)nrel * (unsigned)(9 * p.Cin * 2) + (((tid & 3) ^ ((rl >> 2) & 3)) << 4);
+    }
+    // fragment addresses: A row block 0 at tap kw (k-step 1 = ^ 32, row block 1 = + A_BLK, buffer = + E_ABUF); W block 0 of a half (+ 2048: block 1)
+    constexpr int A_BLK = POOL ? 1024 : 2048;
+    int faddr[3], boff;
+    {
+        const int r = wr * 64 + fr;
+        const int lrow = POOL ? ((r >> 1) & 1) * E_STRIP1 + (r >> 2) * 2 + (r & 1) : r;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) faddr[kw] = E_OFF_A + (lrow + kw) * 64 + ((fh ^ (((lrow + kw) >> 2) & 3)) << 4);
+        const int rw = wc * 64 + fr;
+        boff = rw * 64 + ((fh ^ ((rw >> 2) & 3)) << 4);
+    }
+    unsigned fa_off[3], fmask[2];
+    auto set_tile = [&](int tile) {
+        m0 = (tile / p.tiles_n) * 256; n0 = (tile % p.tiles_n) * 256;
+        const int pxf = POOL ? pool_corner(p, m0 >> 2) : m0;
+        const int px0 = pxf - 1 - p.W > 0 ? pxf - 1 - p.W : 0;
+        rsA = desc(p.x, p.x_total, (long long)px0 * p.Cin * 2);
+        rsW = desc(p.w, p.w_total, (long long)n0 * (9 * p.Cin) * 2);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {                             // DMA instruction k = wid + 8 i covers strip rows 16 k .. 16 k + 15
+            const int row = 16 * (wid + 8 * i) + (lane >> 2), c = (lane & 3) ^ ((row >> 2) & 3);
+            int pix = 0;
+            bool have = false;
+            if constexpr (POOL) {
+                const int dy = row >= E_STRIP1, cc = row - dy * E_STRIP1;
+                if (row < NLD && cc < 130) {
+                    const int wl = cc == 0 ? 0 : (cc == 129 ? 63 : (cc - 1) >> 1), dxo = cc == 0 ? -1 : (cc == 129 ? 2 : (cc - 1) & 1);
+                    const int mp = (m0 >> 2) + wl;
+                    if (4 * mp < p.M) { pix = pool_corner(p, mp) + dy * p.W + dxo; have = true; }
+                }
+            } else if (row < NLD) {
+                pix = m0 - 1 + row; have = true;
+            }
+            // offset of the row's kh = 0 pixel from the descriptor base; "negative" pixels wrap past the extent (zeros) until a group's shift brings them back
+            fa_off[i] = have ? (unsigned)((pix - p.W - px0) * p.Cin) * 2u + c * 16u : OOR;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int m = m0 + wr * 64 + i * 32 + fr;
+            unsigned msk = 0;
+            if (m < p.M) {
+                int ho, wo;
+                if constexpr (POOL) {
+                    const int q = m & 3, mp = m >> 2, wp2 = p.W >> 1, hwp = (p.H >> 1) * wp2;
+                    const int rem = mp % hwp, hp = rem / wp2;
+                    ho = 2 * hp + (q >> 1); wo = 2 * (rem - hp * wp2) + (q & 1);
+                } else {
+                    const int hw = p.H * p.W, rem = m % hw;
+                    ho = rem / p.W; wo = rem - ho * p.W;
+                }
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw)
+                        if (ho + kh - 1 >= 0 && ho + kh - 1 < p.H && wo + kw - 1 >= 0 && wo + kw - 1 < p.W) msk |= 1u << (kh * 3 + kw);
+            }
+            fmask[i] = msk;
+        }
+    };
+    auto dma_a = [&](int g, int buf) {                            // group g = (slab, kh) -> strip buffer `buf` (groups past the last: never multiplied)
+        const int slab = g / 3, kh = g - 3 * slab;
+        const unsigned delta = (unsigned)((kh * p.W * p.Cin + slab * 32) * 2);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) glds16(rsA, lds + E_OFF_A + buf * E_ABUF + (wid + 8 * i) * 1024, fa_off[i] + delta, 0u);
+    };
+    auto dma_w = [&](int h, int t, int buf) { glds16(rsW, lds + buf * E_WBUF + h * E_WHALF + wid * 1024, voffW[h], (unsigned)t * 64u); };
+
+    f32x16 acc[2][4];                                            // [row block][half * 2 + block]
+    u32x4 fa0[2], fa0n[2], fa1[2], fb[2][2];                     // A: [ks]; W: [block][ks] of the half in use
+    auto a_addr = [&](int i, int buf, int kw, int tapbit) -> int {
+        const bool ok = (fmask[i] >> tapbit) & 1u;
+        const int f = faddr[kw];
+        return ok ? f + buf * E_ABUF + i * A_BLK : (E_OFF_A + buf * E_ABUF + E_ZROW * 64 + (f & 255));
+    };
+    // One phase.  j = phase within the trip (static, 0..17): group gi = j / 6 (= kh), tap kw = (j % 6) / 2, q = j & 1; K tile t = t0 + 3 gi + kw.
+    //   q0: reads W half 0 + row block 1;  DMA of W half 1 two taps on;  first tap of a group: the strip of the group two on;  vmcnt retires half 1 of THIS tap
+    //   q1: reads W half 1 + row block 0 of the next tap;  DMA of W half 0 three taps on;  vmcnt retires half 0 of the NEXT tap
+    // (instructions issued after the DMA being retired: four half-tiles, + the three strip instructions unless they are older: kw = 2)
+    auto phase = [&](int j, int t0, int g0) {
+        const int gi = j / 6, kw = (j - 6 * gi) >> 1, q = j & 1, t = t0 + 3 * gi + kw;
+        const unsigned char* wb = lds + kw * E_WBUF + q * E_WHALF;
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) fb[b][ks] = *(const u32x4*)(wb + b * 2048 + (ks ? boff ^ 32 : boff));
+        if (q == 0) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) fa0[ks] = fa0n[ks];
+            const int a1 = a_addr(1, gi, kw, 3 * gi + kw);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) fa1[ks] = *(const u32x4*)(lds + (ks ? a1 ^ 32 : a1));
+            __builtin_amdgcn_sched_barrier(0);
+            if (kw == 0) dma_a(g0 + gi + 2, (gi + 2) % 3);
+            dma_w(1, t + 2, (kw + 2) % 3);
+        } else {
+            const int a0 = kw < 2 ? a_addr(0, gi, kw + 1, 3 * gi + kw + 1) : a_addr(0, (gi + 1) % 3, 0, 3 * ((gi + 1) % 3));
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) fa0n[ks] = *(const u32x4*)(lds + (ks ? a0 ^ 32 : a0));
+            __builtin_amdgcn_sched_barrier(0);
+            dma_w(0, t + 3, kw);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (kw == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+                    acc[i][2 * q + b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, i ? fa1[ks] : fa0[ks]), __builtin_bit_cast(f16x8, fb[b][ks]),
+                                                                                acc[i][2 * q + b], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+    };
+
+    // the zero line of the three strip buffers (the strip DMAs' out-of-range rows may or may not rewrite it -- with zeros)
+    if (tid < 48) *(u32x4*)(lds + E_OFF_A + (tid >> 4) * E_ABUF + E_ZROW * 64 + (tid & 15) * 16) = (u32x4){0u, 0u, 0u, 0u};
+    __syncthreads();
+
+    const int n_items = t_lo + slot_in_xcd < t_hi ? (t_hi - t_lo - slot_in_xcd + wg_per_xcd - 1) / wg_per_xcd : 0;
+    // what a tile needs before its first phases: both halves of taps 0 and 1, half 0 of tap 2; the strips of groups 0 and 1
+    auto prologue = [&]() {
+        dma_w(0, 0, 0); dma_w(1, 0, 0); dma_w(0, 1, 1); dma_w(1, 1, 1); dma_w(0, 2, 2);
+        dma_a(0, 0); dma_a(1, 1);
+    };
+    if (n_items > 0) { set_tile(t_lo + slot_in_xcd); prologue(); }
+    for (int k = 0; k < n_items; ++k) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the prologue (and the previous tile's stores)
+        __builtin_amdgcn_s_barrier();
+        {
+            const int a0 = a_addr(0, 0, 0, 0);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) fa0n[ks] = *(const u32x4*)(lds + (ks ? a0 ^ 32 : a0));
+        }
+        if (grp == 1) __builtin_amdgcn_s_barrier();               // the second wave group runs one barrier behind
+        for (int g0 = 0; g0 < G; g0 += 3) {
+#pragma unroll
+            for (int j = 0; j < 18; ++j) phase(j, 3 * g0, g0);
+        }
+        if (grp == 0) __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the look-ahead DMAs past the last tap
+        __builtin_amdgcn_s_barrier();
+        const int em0 = m0, en0 = n0;
+        if (k + 1 < n_items) { set_tile(t_lo + slot_in_xcd + (k + 1) * wg_per_xcd); prologue(); }   // in flight during the epilogue below
+
+        // epilogue: BatchNorm scale / bias, ReLU, (2x2 average), packed fp16 stores straight from the accumulators (as conv3x3_f16_kernel)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int ncol = en0 + wc * 128 + h * 64 + 2 * fr;
+            const float s0 = p.scale ? p.scale[ncol] : 1.f, s1 = p.scale ? p.scale[ncol + 1] : 1.f;
+            const float b0 = p.bias ? p.bias[ncol] : 0.f, b1 = p.bias ? p.bias[ncol + 1] : 0.f;
+            if constexpr (POOL) {
+                const __amdgpu_buffer_rsrc_t rsY = desc(p.y, p.y_total, (long long)(em0 >> 2) * p.N * 2);
+                const int wins_left = (p.M >> 2) - (em0 >> 2);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int t4 = 0; t4 < 4; ++t4) {
+                        const int wl = wr * 16 + i * 8 + 2 * t4 + fh;
+                        float v[2][4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            v[0][q] = fmaxf(fmaf(acc[i][2 * h][4 * t4 + q], s0, b0), 0.f);
+                            v[1][q] = fmaxf(fmaf(acc[i][2 * h + 1][4 * t4 + q], s1, b1), 0.f);
+                        }
+                        const float o0 = (((v[0][0] + v[0][1]) + v[0][2]) + v[0][3]) * 0.25f, o1 = (((v[1][0] + v[1][1]) + v[1][2]) + v[1][3]) * 0.25f;
+                        __builtin_amdgcn_raw_buffer_store_b32(pack2(o0, o1), rsY, wl < wins_left ? (unsigned)(wl * p.N + ncol) * 2u : OOR, 0u, 0);
+                    }
+            } else {
+                const __amdgpu_buffer_rsrc_t rsY = desc(p.y, p.y_total, (long long)em0 * p.N * 2);
+                const int rows_left = p.M - em0;
+                const int row_lim = (rows_left < 256 ? rows_left : 256) - (wr * 64 + 4 * fh);
+                const unsigned vbase = (unsigned)((wr * 64 + 4 * fh) * p.N + ncol) * 2u;
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int ru = i * 32 + (r & 3) + 8 * (r >> 2);
+                        const float v0 = fmaxf(fmaf(acc[i][2 * h][r], s0, b0), 0.f), v1 = fmaxf(fmaf(acc[i][2 * h + 1][r], s1, b1), 0.f);
+                        __builtin_amdgcn_raw_buffer_store_b32(pack2(v0, v1), rsY, ru < row_lim ? vbase : OOR, (unsigned)(ru * p.N * 2), 0);
+                    }
+            }
+        }
+    }
+}
+
 template <int WM, int WN, int TN>
 int launch_conv(ConvHP& p, int pool, hipStream_t s) {
     constexpr int BM = WM * 128, BN = WN * TN * 32;
@@ -594,6 +830,16 @@ extern "C" int dbmm_conv3x3_bn_relu_f16(const void* x, const void* w, const floa
     p.x_total = M * Cin * 2; p.w_total = wb; p.y_total = (pool ? M / 4 : M) * Cout * 2;
     p.B = (int)B; p.H = (int)H; p.W = (int)W; p.Cin = (int)Cin; p.N = (int)Cout; p.M = (int)M;
     hipStream_t s = (hipStream_t)stream;
+    // Cout % 256 == 0 (layers 3 / 4) at a size that fills the chip: the eight-phase 256 x 256 kernel (option f16_conv_8ph)
+    if (dbmm_opt(OPT_F16_CONV_8PH) && (Cout % 256) == 0 && M >= 16384) {
+        p.tiles_n = (int)(Cout / 256);
+        p.n_tiles = (int)((M + 255) / 256) * p.tiles_n;
+        const int grid = p.n_tiles < 256 ? p.n_tiles : 256;
+        if (pool) hipLaunchKernelGGL((conv3x3_f16_8ph_kernel<1>), dim3(grid), dim3(512), 0, s, p);
+        else hipLaunchKernelGGL((conv3x3_f16_8ph_kernel<0>), dim3(grid), dim3(512), 0, s, p);
+        DBMM_CHECK_LAUNCH();
+        return DBMM_OK;
+    }
     if (Cout <= 32) return launch_conv<4, 1, 1>(p, pool, s);
     if (Cout <= 64) return launch_conv<4, 1, 2>(p, pool, s);
     return launch_conv<2, 2, 2>(p, pool, s);

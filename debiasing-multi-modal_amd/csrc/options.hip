@@ -46,6 +46,7 @@ const OptDef kOpts[DBMM_OPT_COUNT] = {
     {"halo8", 1},              // parity 3x3 convs with Cout % 256 == 0 on conv3x3_halo8_kernel: 0 never / 1 where it measured ahead / 2 wherever it applies
     {"dual_8ph", 1},           // conv3 + downsample dual-source GEMM on gemm_pair_8ph_kernel: 0 never / 1 where it measured ahead / 2 wherever it applies
     {"mha_short", 1},          // attention cores: sequences of at most 64 tokens on two-wave workgroups (0: the four-wave ones, half of them idle)
+    {"f16_conv_8ph", 1},       // fp16 mode 3x3 convs with Cout % 256 == 0 on conv3x3_f16_8ph_kernel (0: conv3x3_f16_kernel)
 };
 
 std::atomic<int> g_val[DBMM_OPT_COUNT];

@@ -888,7 +888,9 @@ def conv3x3_f16(x, w, scale, bias, pool=1):
     Cout = w.shape[0]
     y = _empty((B, H // pool, W // pool, Cout), device=x.device, dtype=torch.float16)
     geo = "2, 2, 2" if Cout > 64 else ("4, 1, 2" if Cout > 32 else "4, 1, 1")
-    t = _TimedTag(f"conv3x3_f16_kernel<{geo}, {int(pool == 2)}>", 2.0 * B * H * W * Cout * 9 * Cin, 2 * (x.numel() + y.numel() + w.numel()))
+    deep = Cout % 256 == 0 and B * H * W >= 16384 and get_option("f16_conv_8ph")     # dbmm_conv3x3_bn_relu_f16's own routing rule
+    tag = f"conv3x3_f16_8ph_kernel<{int(pool == 2)}>" if deep else f"conv3x3_f16_kernel<{geo}, {int(pool == 2)}>"
+    t = _TimedTag(tag, 2.0 * B * H * W * Cout * 9 * Cin, 2 * (x.numel() + y.numel() + w.numel()))
     t.__enter__()
     rc = _lib.lib().dbmm_conv3x3_bn_relu_f16(ptr(x), ptr(w), ptr(scale), ptr(bias), ptr(y), B, H, W, Cin, Cout, 2 if pool == 2 else 0, stream())
     t.__exit__(None if rc == 0 else DbmmUnsupported, None, None)

@@ -199,6 +199,47 @@ def test_conv3x3_f16_kernel(B, H, W, Cin, Cout, pool):
     assert relerr(y.double().cpu(), ref.cpu()) < 1.5e-3            # one fp16 rounding of the result + fp32 accumulation
 
 
+@pytest.mark.parametrize("B,H,W,Cin,Cout,pool", [
+    (128, 14, 14, 256, 256, 1),          # layer 3's conv2: 98 whole tiles
+    (512, 7, 7, 512, 512, 1),            # layer 4's: two N tiles per row block, 392 tiles = two per workgroup, 7 x 7 maps
+    (131, 14, 14, 64, 256, 1),           # ragged last tile, two slabs
+    (30, 26, 30, 96, 256, 1),            # non-square maps, three slabs
+    (24, 28, 28, 256, 256, 2),           # layer 3's first conv2: pooled, window-major rows
+    (100, 14, 14, 512, 512, 2),          # layer 4's first conv2
+    (33, 26, 26, 64, 256, 2),            # pooled, ragged, windows wrap over pooled rows inside a tile
+    (700, 6, 6, 32, 256, 2),             # one slab; every tile wraps over rows and images
+    (3, 80, 72, 64, 256, 1),             # a tile inside one image row block (W > 64)
+])
+def test_conv3x3_f16_eight_phase_kernel(B, H, W, Cin, Cout, pool, option):
+    """conv3x3_f16_8ph_kernel (Cout % 256 == 0, >= 16,384 pixels): the eight-phase 256 x 256 variant keeps conv3x3_f16_kernel's arithmetic and
+    order of accumulation, so the two agree BIT FOR BIT; both against fp64 on the same fp16 values; guard zone behind the output."""
+    g = torch.Generator(device=DEV); g.manual_seed(B * 131 + H * 7 + Cin + Cout + pool)
+    x = torch.relu(torch.randn((B, H, W, Cin), device=DEV, generator=g) * 1.5).half()
+    w = (torch.randn((Cout, Cin, 3, 3), device=DEV, generator=g) * (9 * Cin) ** -0.5).half()
+    sc, b = _bn(g, Cout)
+    wp, wl = ops.pack_conv_weight(w.float(), chunk_major=32)
+    wh = wp.half().contiguous()
+    option("f16_conv_8ph", 1)
+    ops.profile_begin()
+    y8 = ops.conv3x3_f16(x, wh, sc, b, pool=pool)
+    assert list(ops.profile_end()) == [f"conv3x3_f16_8ph_kernel<{int(pool == 2)}>"]
+    option("f16_conv_8ph", 0)
+    y = ops.conv3x3_f16(x, wh, sc, b, pool=pool)
+    assert torch.equal(y8, y), ((y8 != y).sum().item(), relerr(y8.double().cpu(), y.double().cpu()))
+    ref = torch.relu(F.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), None, padding=1) * sc.double().view(1, -1, 1, 1) + b.double().view(1, -1, 1, 1))
+    if pool == 2:
+        ref = F.avg_pool2d(ref, 2)
+    assert relerr(y8.double().cpu(), ref.permute(0, 2, 3, 1).cpu()) < 1.5e-3
+    from dbmm_amd import _lib
+    n_out = y.numel()
+    buf = torch.full((n_out + 4096,), 7.0, device=DEV, dtype=torch.float16)
+    option("f16_conv_8ph", 1)
+    rc = _lib.lib().dbmm_conv3x3_bn_relu_f16(x.data_ptr(), wh.data_ptr(), sc.data_ptr(), b.data_ptr(), buf.data_ptr(), B, H, W, Cin, Cout, 2 if pool == 2 else 0,
+                                             _lib.stream())
+    torch.cuda.synchronize()
+    assert rc == 0 and torch.equal(buf[:n_out].view(y.shape), y) and (buf[n_out:] == 7.0).all()
+
+
 @pytest.mark.parametrize("M,Cin,Cout,res,act", [(56 * 56 * 3, 64, 256, True, 1), (28 * 28 * 5, 512, 128, False, 1), (14 * 14 * 90, 1024, 256, False, 1),
                                                 (14 * 14 * 90 + 12, 256, 1024, True, 1), (7 * 7 * 40, 2048, 512, False, 1), (300, 64, 64, False, 0),
                                                 (17000, 128, 512, True, 1), (256 * 3 + 77, 96, 136, True, 1), (5, 32, 8, False, 1)])
