@@ -33,6 +33,7 @@ KERNEL_SOURCES = (
     ("conv3x3_halo8", ("conv3x3_halo8.hip", "conv3x3_halo8_epilogue.inc", "common.h")),
     ("mha_pair_kernel", ("mha_pair.hip", "common.h")),
     ("gemm_f16", ("f16_ops.hip", "common.h")), ("mha_f16", ("f16_ops.hip", "common.h")), ("layernorm_f16", ("f16_ops.hip", "common.h")),
+    ("chain_f16", ("chain_f16.hip", "common.h")),
     ("conv3x3_f16", ("conv_f16.hip", "common.h")), ("conv1x1_f16", ("conv_f16.hip", "common.h")), ("stem_s2_f16", ("conv_f16.hip", "common.h")),
     ("avgpool2_f16", ("conv_f16.hip", "common.h")),
     ("stem_s2", ("resnet_ops.hip", "common.h")), ("attnpool", ("resnet_ops.hip", "common.h")),
@@ -121,6 +122,7 @@ _SIGS = {
     "dbmm_conv1x1_bn_act_f16": [_P, _P, _P, _P, _P, _P, _L, _L, _L, _I, _P],
     "dbmm_conv1x1_bn_act_f16_ws": [_P, _P, _P, _P, _P, _P, _L, _L, _L, _I, _P, _Z, _P],
     "dbmm_conv1x1_dual_bn_act_f16": [_P, _P, _P, _P, _P, _P, _P, _P, _L, _L, _L, _L, _I, _P],
+    "dbmm_bottleneck_chain_f16": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _L, _L, _L, _P],
     "dbmm_conv3x3_bn_relu_f16": [_P, _P, _P, _P, _P, _L, _L, _L, _L, _L, _I, _P],
     "dbmm_conv_stem_s2_f16": [_P, _I, _P, _P, _P, _L, _L, _L, _L, _P],
     "dbmm_avgpool2_f16": [_P, _P, _L, _L, _L, _L, _P],

@@ -332,11 +332,20 @@ class ModifiedResNet(nn.Module):
         x = ops.conv3x3_f16(x, *P["stem3"], pool=2)                     # + the stem's AvgPool2d(2)
         stages = {"stem": x}
         bi = 0
+        y1_next = None                                                  # conv1 of this block, when the previous block's chain launch made it
         for li in (1, 2, 3, 4):
-            for _ in getattr(self, f"layer{li}"):
+            nblk = len(getattr(self, f"layer{li}"))
+            for k_in_stage in range(nblk):
                 e = P["blocks"][bi]; bi += 1
-                out = ops.conv1x1_f16(x, *e["c1"])
+                out = y1_next if y1_next is not None else ops.conv1x1_f16(x, *e["c1"])
+                y1_next = None
                 out = ops.conv3x3_f16(out, *e["c2"], pool=2 if e["stride"] == 2 else 1)     # conv2 + bn2 + relu (+ avgpool)
+                if "ds" not in e and k_in_stage + 1 < nblk and _opt["fuse_chain"]:
+                    # conv3 + residual -> conv1 of the next block of the stage in one launch (layers 1 - 2; None elsewhere)
+                    r = ops.chain_f16(out, e["c3"], x, P["blocks"][bi]["c1"])
+                    if r is not None:
+                        x, y1_next = r
+                        continue
                 identity = x
                 if "ds" in e:
                     if e["stride"] == 2:

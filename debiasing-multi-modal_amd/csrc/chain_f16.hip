@@ -1,0 +1,224 @@
+// fp16 mode: conv3 + residual of one bottleneck block CHAINED with conv1 of the next block in one launch
+// (/root/reference/clip/model.py:42-55, two consecutive Bottleneck.forward bodies on the reference's GPU path):
+//
+//   x'  = relu( (y2 @ W3^T) * sc3 + b3 + x )         f16 [M][N]   written to HBM (it is the next residual)
+//   y1' = relu( (x' @ W1^T) * sc1 + b1 )             f16 [M][P]   written to HBM
+//
+// Why: in the fp16 mode the 1x1 convs of layers 1-2 are HBM-bound and conv1 of the NEXT block re-reads the 256 / 512-channel tensor
+// conv3 has just written: 1.6 of the 5.7 GB the two launches move per layer-1 block boundary at B = 1024.  As in bottleneck_chain_kernel
+// (the parity mode's chain) one workgroup owns 128 pixel rows for ALL N output channels of conv3, walks them in 64-channel slabs, and
+// every finished slab is at once the next 64-deep K chunk of conv1': the wide tensor is written once and not read back.
+//
+// Arithmetic: one fp16 MFMA per product, fp32 accumulation, BatchNorm scale / bias, residual and ReLU on the fp32 accumulator -- the
+// arithmetic of conv1x1_f16_kernel.  The slab x' is ROUNDED TO fp16 before it feeds conv1', exactly what the two launches do (conv1'
+// reads the stored fp16 x'), so the chain equals them bit for bit.
+//
+// Data movement: the y2 fragments (K <= 128) are loaded once per tile straight into registers; weights (W3 slab [64][K], W1 chunk
+// [P][64]) are prefetched one slab ahead into registers and staged in LDS; residual loads and x' / y1' stores go straight from / to the
+// accumulator layout as packed dwords (the W rows are staged interleaved: block j, column c <-> channel 2 c + j, so a lane holds two
+// ADJACENT channels and 32 lanes make a 128-B row segment); the next slab's residual is in flight during this slab's MFMAs.  Each wave
+// owns 32 rows through both GEMMs, so the fp16 slab goes through a wave-private LDS slab and needs no barrier.
+// Bound: HBM.  Algorithmic bytes per pixel row: 2 * (K + 2 N + P).
+#include <stdlib.h>
+#include "common.h"
+
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u16;
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr unsigned OOR = 0x80000000u;
+constexpr long long EXT_LIM = 0x7FFFFFF0LL;
+
+struct ChainHP {
+    const u16* a; const u16* w3; const float* sc3; const float* b3; const u16* res; u16* x;
+    const u16* w1; const float* sc1; const float* b1; u16* y1;
+    int M, N;
+};
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t desc(const void* base, long long total, long long shift) {
+    long long ext = total - shift;
+    ext = ext < 0 ? 0 : (ext > EXT_LIM ? EXT_LIM : ext);
+    return __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)base + shift), 0, (int)ext, 0x00020000);
+}
+__device__ __forceinline__ unsigned pack2(float a, float b) {
+    const f16x2 v = {(_Float16)a, (_Float16)b};
+    return __builtin_bit_cast(unsigned, v);
+}
+// LDS rows of RB bytes: XOR of the 16-B chunk index with row bits keeps the lanes of a ds_read_b128 group on distinct bank quads
+template <int RB>
+__device__ __forceinline__ int swz(int row) { return RB == 128 ? ((row >> 1) & 7) : (row & 15); }
+
+constexpr int BM = 128, BNS = 64;
+
+// (two workgroups per CU; three -- layer 1's K = P = 64 variant squeezed into 168 registers, 10 of them spilled -- measured 934 against 921 us)
+template <int K, int P>
+__global__ __launch_bounds__(256, 2) void chain_f16_kernel(const ChainHP p) {
+    static_assert(K == 64 || K == 128, "conv3 reduction depth: 64 (layer 1) or 128 (layer 2)");
+    static_assert(P == 64 || P == 128, "conv1' width");
+    constexpr int KS = K / 16, TN1 = P / 32;
+    constexpr int W3_BYTES = BNS * K * 2, W1_BYTES = P * BNS * 2, XS_BYTES = 4 * 32 * 128;
+    __shared__ __attribute__((aligned(256))) unsigned char lds[W3_BYTES + W1_BYTES + XS_BYTES];
+    unsigned char* W3b = lds;                                       // [64 rows (block j, column c)][K]
+    unsigned char* W1b = lds + W3_BYTES;                            // [P rows (block, column)][64 k]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    unsigned char* XS = lds + W3_BYTES + W1_BYTES + wave * (32 * 128);   // this wave's x' slab: [32 rows][64 k] fp16
+    const int fr = lane & 31, fh = lane >> 5;
+    const int m0 = xcd_remap(blockIdx.x, gridDim.x) * BM;
+    const int NT = p.N / BNS;
+    const long long Mll = p.M;
+    const __amdgpu_buffer_rsrc_t rsA = desc(p.a, Mll * K * 2, (long long)m0 * K * 2);
+    const __amdgpu_buffer_rsrc_t rsR = desc(p.res, Mll * p.N * 2, (long long)m0 * p.N * 2);
+    const __amdgpu_buffer_rsrc_t rsX = desc(p.x, Mll * p.N * 2, (long long)m0 * p.N * 2);
+    const __amdgpu_buffer_rsrc_t rsY = desc(p.y1, Mll * P * 2, (long long)m0 * P * 2);
+
+    // accumulator rows of this lane: u = (r & 3) + 8 (r >> 2) + 4 fh of the wave's 32; valid iff m0 + 32 wave + u < M
+    const int row_lim = p.M - m0 - wave * 32 - 4 * fh;                                  // row u is valid iff (r & 3) + 8 (r >> 2) < row_lim
+    const unsigned vx = (unsigned)((wave * 32 + 4 * fh) * p.N + 2 * fr) * 2u;           // + slab * 128 B; row step in the scalar offset
+    const unsigned vy = (unsigned)((wave * 32 + 4 * fh) * P + 2 * fr) * 2u;
+
+    // ---- weight slabs through registers: W3 slab [64 n][K], W1 chunk [P][64 k]; 16-B chunks dealt over the 256 threads ----
+    constexpr int CPR3 = K / 8, RPP3 = 256 / CPR3, W3LD = BNS * CPR3 / 256;             // chunks per row, rows per pass, loads per thread
+    constexpr int CPR1 = BNS / 8, RPP1 = 256 / CPR1, W1LD = P * CPR1 / 256;
+    const int wc3 = tid % CPR3, wr3 = tid / CPR3, wc1 = tid % CPR1, wr1 = tid / CPR1;
+    u32x4 w3r[W3LD], w1r[W1LD];
+    auto load_w = [&](int nt) {
+#pragma unroll
+        for (int j = 0; j < W3LD; ++j) {
+            const int lr = wr3 + RPP3 * j, ch = 2 * (lr & 31) + (lr >> 5);              // LDS row (block lr >> 5, column lr & 31) <-> channel
+            w3r[j] = *(const u32x4*)(p.w3 + (size_t)(nt * BNS + ch) * K + wc3 * 8);
+        }
+#pragma unroll
+        for (int j = 0; j < W1LD; ++j) {
+            const int lr = wr1 + RPP1 * j, ch = (lr >> 6) * 64 + 2 * (lr & 31) + ((lr >> 5) & 1);   // output channel of LDS row lr
+            w1r[j] = *(const u32x4*)(p.w1 + (size_t)ch * p.N + nt * BNS + wc1 * 8);
+        }
+    };
+    auto store_w = [&]() {
+#pragma unroll
+        for (int j = 0; j < W3LD; ++j) {
+            const int lr = wr3 + RPP3 * j;
+            *(u32x4*)(W3b + lr * (K * 2) + ((wc3 ^ swz<K * 2>(lr)) << 4)) = w3r[j];
+        }
+#pragma unroll
+        for (int j = 0; j < W1LD; ++j) {
+            const int lr = wr1 + RPP1 * j;
+            *(u32x4*)(W1b + lr * 128 + ((wc1 ^ swz<128>(lr)) << 4)) = w1r[j];
+        }
+    };
+    unsigned rv[16];
+    auto load_res = [&](int nt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int u = (r & 3) + 8 * (r >> 2);
+            rv[r] = __builtin_amdgcn_raw_buffer_load_b32(rsR, u < row_lim ? vx + nt * (BNS * 2) : OOR, (unsigned)(u * p.N * 2), 0);
+        }
+    };
+
+    // ---- prologue: first weight slabs and residual slab in flight; the y2 fragments of the wave's 32 rows into registers ----
+    load_w(0);
+    load_res(0);
+    u32x4 ay[KS];
+    {
+        const int m = m0 + wave * 32 + fr;
+        const unsigned va = m < p.M ? (unsigned)((wave * 32 + fr) * K + 8 * fh) * 2u : OOR;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) ay[ks] = __builtin_amdgcn_raw_buffer_load_b128(rsA, va, (unsigned)(ks * 32), 0);
+    }
+    f32x16 acc1[TN1];
+#pragma unroll
+    for (int j = 0; j < TN1; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc1[j][r] = 0.f;
+    store_w();
+    __syncthreads();
+
+    for (int nt = 0; nt < NT; ++nt) {
+        if (nt + 1 < NT) load_w(nt + 1);
+        // ---- conv3: this slab's 64 channels (two blocks: even / odd channels) of the wave's 32 rows ----
+        f32x16 acc3[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc3[j][r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int lr = j * 32 + fr;
+                const u32x4 wf = *(const u32x4*)(W3b + lr * (K * 2) + (((2 * ks + fh) ^ swz<K * 2>(lr)) << 4));
+                acc3[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ay[ks]), __builtin_bit_cast(f16x8, wf), acc3[j], 0, 0, 0);
+            }
+        // ---- x' = relu(acc * sc3 + b3 + residual): packed fp16 to HBM and to the wave's LDS slab ----
+        const int n = nt * BNS + 2 * fr;
+        const float s0 = p.sc3 ? p.sc3[n] : 1.f, s1 = p.sc3 ? p.sc3[n + 1] : 1.f, c0 = p.b3 ? p.b3[n] : 0.f, c1 = p.b3 ? p.b3[n + 1] : 0.f;
+        unsigned xv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const f16x2 rh = __builtin_bit_cast(f16x2, rv[r]);
+            const float v0 = fmaxf(fmaf(acc3[0][r], s0, c0) + (float)rh[0], 0.f), v1 = fmaxf(fmaf(acc3[1][r], s1, c1) + (float)rh[1], 0.f);
+            xv[r] = pack2(v0, v1);
+        }
+        if (nt + 1 < NT) load_res(nt + 1);                          // (rv is free: the next slab's residual flies during the stores and conv1')
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int u = (r & 3) + 8 * (r >> 2);
+            __builtin_amdgcn_raw_buffer_store_b32(xv[r], rsX, u < row_lim ? vx + nt * (BNS * 2) : OOR, (unsigned)(u * p.N * 2), 0);
+            const int row = u + 4 * fh;
+            *(unsigned*)(XS + row * 128 + (((fr >> 2) ^ swz<128>(row)) << 4) + (fr & 3) * 4) = xv[r];
+        }
+        // ---- conv1': the slab is its K chunk [64 nt, 64 nt + 64) ----
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const u32x4 af = *(const u32x4*)(XS + fr * 128 + (((2 * ks + fh) ^ swz<128>(fr)) << 4));
+#pragma unroll
+            for (int j = 0; j < TN1; ++j) {
+                const int lr = j * 32 + fr;
+                const u32x4 wf = *(const u32x4*)(W1b + lr * 128 + (((2 * ks + fh) ^ swz<128>(lr)) << 4));
+                acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af), __builtin_bit_cast(f16x8, wf), acc1[j], 0, 0, 0);
+            }
+        }
+        __syncthreads();                                            // every wave is done with this slab's weights
+        if (nt + 1 < NT) store_w();
+        __syncthreads();
+    }
+    // ---- y1' = relu(acc1 * sc1 + b1): blocks (2 h, 2 h + 1) hold the even / odd channels of the h-th 64 ----
+#pragma unroll
+    for (int h = 0; h < TN1 / 2; ++h) {
+        const int n = h * 64 + 2 * fr;
+        const float s0 = p.sc1 ? p.sc1[n] : 1.f, s1 = p.sc1 ? p.sc1[n + 1] : 1.f, c0 = p.b1 ? p.b1[n] : 0.f, c1 = p.b1 ? p.b1[n + 1] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int u = (r & 3) + 8 * (r >> 2);
+            const float v0 = fmaxf(fmaf(acc1[2 * h][r], s0, c0), 0.f), v1 = fmaxf(fmaf(acc1[2 * h + 1][r], s1, c1), 0.f);
+            __builtin_amdgcn_raw_buffer_store_b32(pack2(v0, v1), rsY, u < row_lim ? vy + h * 128 : OOR, (unsigned)(u * P * 2), 0);
+        }
+    }
+}
+
+}  // namespace
+
+// see include/dbmm.h
+extern "C" int dbmm_bottleneck_chain_f16(const void* y2, const void* w3, const float* scale3, const float* bias3, const void* residual, void* x_out,
+                                         const void* w1, const float* scale1, const float* bias1, void* y1_out, int64_t M, int64_t K, int64_t N,
+                                         int64_t P, void* stream) {
+    if (!y2 || !w3 || !residual || !x_out || !w1 || !y1_out) return DBMM_E_ARG;
+    if (M <= 0 || N <= 0 || M > INT32_MAX - 1024) return DBMM_E_SHAPE;
+    if (!(K == 64 || K == 128) || !(P == 64 || P == 128) || (N % 64) || N < 64) return DBMM_E_UNSUPPORTED;
+    if (!dbmm_aligned16(y2) || !dbmm_aligned16(w3) || !dbmm_aligned16(residual) || !dbmm_aligned16(x_out) || !dbmm_aligned16(w1) || !dbmm_aligned16(y1_out))
+        return DBMM_E_ALIGN;
+    if (128LL * N * 2 >= EXT_LIM) return DBMM_E_UNSUPPORTED;
+    ChainHP p{};
+    p.a = (const u16*)y2; p.w3 = (const u16*)w3; p.sc3 = scale3; p.b3 = bias3; p.res = (const u16*)residual; p.x = (u16*)x_out;
+    p.w1 = (const u16*)w1; p.sc1 = scale1; p.b1 = bias1; p.y1 = (u16*)y1_out; p.M = (int)M; p.N = (int)N;
+    const dim3 grid((unsigned)((M + BM - 1) / BM));
+    hipStream_t s = (hipStream_t)stream;
+    if (K == 64 && P == 64) hipLaunchKernelGGL((chain_f16_kernel<64, 64>), grid, dim3(256), 0, s, p);
+    else if (K == 64 && P == 128) hipLaunchKernelGGL((chain_f16_kernel<64, 128>), grid, dim3(256), 0, s, p);
+    else if (K == 128 && P == 64) hipLaunchKernelGGL((chain_f16_kernel<128, 64>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((chain_f16_kernel<128, 128>), grid, dim3(256), 0, s, p);
+    DBMM_CHECK_LAUNCH();
+    return DBMM_OK;
+}

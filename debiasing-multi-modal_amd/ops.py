@@ -859,6 +859,28 @@ def conv1x1_f16(x, w, scale, bias, residual=None, act=ACT_RELU):
     return y
 
 
+def chain_f16(y2, c3, residual, c1):
+    """fp16 mode: x' = relu(conv3(y2) * s3 + b3 + residual) and y1' = relu(conv1'(x') * s1 + b1) in one launch (dbmm_bottleneck_chain_f16);
+    c3 / c1 = (w f16, scale f32, bias f32).  Returns (x', y1') or None when the library has no kernel for the shape."""
+    require_cuda(y2, residual)
+    _f16c(y2); _f16c(residual)
+    (w3, s3, b3), (w1, s1, b1) = c3, c1
+    N, K = w3.shape
+    P = w1.shape[0]
+    M = y2.numel() // K
+    x = _empty(tuple(y2.shape[:-1]) + (N,), device=y2.device, dtype=torch.float16)
+    y1 = _empty(tuple(y2.shape[:-1]) + (P,), device=y2.device, dtype=torch.float16)
+    t = _TimedTag(f"chain_f16_kernel<{K}, {P}>", 2.0 * M * N * (K + P), 2 * (M * (K + 2 * N + P) + N * (K + P)))
+    t.__enter__()
+    rc = _lib.lib().dbmm_bottleneck_chain_f16(ptr(y2), ptr(w3), ptr(s3), ptr(b3), ptr(residual), ptr(x), ptr(w1), ptr(s1), ptr(b1), ptr(y1),
+                                              M, K, N, P, stream())
+    t.__exit__(None if rc == 0 else DbmmUnsupported, None, None)
+    if rc == _lib.E_UNSUPPORTED:
+        return None
+    check(rc, "bottleneck_chain_f16")
+    return x, y1
+
+
 def conv1x1_dual_f16(y2, w3, scale3, xp, wd, ratio, bias, act=ACT_RELU):
     """fp16 mode: act(conv3(y2) * scale3 + conv_d(xp) * scale_d + bias) as one dual-source GEMM (dbmm_conv1x1_dual_bn_act_f16);
     ratio = scale_d / scale3, bias = both BatchNorm biases.  None when the library has no kernel for the shape."""

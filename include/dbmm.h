@@ -283,6 +283,14 @@ int dbmm_conv1x1_bn_act_f16(const void* x, const void* w, const float* scale, co
  * streaming 1x1 kernel (K % 32 == 0, K2 % 32 == 0, Cout > 64, Cout % 8 == 0: layer 1); DBMM_E_UNSUPPORTED (nothing launched) beyond that. */
 int dbmm_conv1x1_dual_bn_act_f16(const void* y2, const void* w3, const float* scale3, const void* xp, const void* wd, const float* ratio,
                                  const float* bias, void* out, int64_t M, int64_t K, int64_t K2, int64_t Cout, int act, void* stream);
+/* fp16 mode: conv3 + residual of one bottleneck block chained with conv1 of the NEXT block (clip/model.py:42-55 twice) in one launch:
+ *   x_out  = relu((y2 @ w3^T) * scale3 + bias3 + residual)   f16 [M][N]      y1_out = relu((x_out @ w1^T) * scale1 + bias1)   f16 [M][P]
+ * The wide tensor x_out is written once and not read back for conv1; x_out is rounded to fp16 before it feeds conv1, so the results equal
+ * the two launches bit for bit.  y2 f16 [M][K], w3 f16 [N][K], w1 f16 [P][N].  K, P in {64, 128}, N % 64 == 0 (layers 1 - 2);
+ * DBMM_E_UNSUPPORTED (nothing launched) otherwise -- the caller then issues the two convs. */
+int dbmm_bottleneck_chain_f16(const void* y2, const void* w3, const float* scale3, const float* bias3, const void* residual, void* x_out,
+                              const void* w1, const float* scale1, const float* bias1, void* y1_out, int64_t M, int64_t K, int64_t N,
+                              int64_t P, void* stream);
 int dbmm_conv1x1_bn_act_f16_ws(const void* x, const void* w, const float* scale, const float* bias, const void* residual, void* y,
                                int64_t M, int64_t Cin, int64_t Cout, int act, void* workspace, size_t workspace_bytes,
                                void* stream);          /* with a workspace, as dbmm_gemm_f16_ws */

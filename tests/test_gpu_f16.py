@@ -437,3 +437,33 @@ def test_conv1x1_dual_f16(M, K, K2, N):
                                                  bsum.data_ptr(), buf.data_ptr(), M, K, K2, N, ops.ACT_RELU, _lib.stream())
     torch.cuda.synchronize()
     assert rc == 0 and torch.equal(buf[:M * N].view(M, N), out) and (buf[M * N:] == 7.0).all()
+
+
+@pytest.mark.parametrize("M,K,N,P", [(56 * 56 * 3, 64, 256, 64), (28 * 28 * 9 + 5, 128, 512, 128), (1000, 64, 192, 128), (130, 128, 64, 64), (7, 64, 64, 64)])
+def test_bottleneck_chain_f16(M, K, N, P):
+    """fp16 mode: conv3 + BatchNorm + residual + ReLU of a block and conv1 + BatchNorm + ReLU of the next block as one launch
+    (clip/model.py:42-55 twice): equal BIT FOR BIT to the two launches it replaces (x' is rounded to fp16 before it feeds conv1'), against
+    fp64 on sample rows, ragged tiles, guard zones behind both outputs; other shapes answer None"""
+    g = torch.Generator(device=DEV); g.manual_seed(M + K + N + P)
+    y2 = torch.relu(torch.randn((M, K), device=DEV, generator=g)).half(); res = torch.relu(torch.randn((M, N), device=DEV, generator=g) * 2.0).half()
+    w3 = (torch.randn((N, K), device=DEV, generator=g) * K ** -0.5).half(); w1 = (torch.randn((P, N), device=DEV, generator=g) * N ** -0.5).half()
+    s3, b3 = _bn(g, N); s1, b1 = _bn(g, P)
+    r = ops.chain_f16(y2, (w3, s3, b3), res, (w1, s1, b1))
+    assert r is not None
+    x, y1 = r
+    x_two = ops.conv1x1_f16(y2, w3, s3, b3, residual=res)
+    y1_two = ops.conv1x1_f16(x_two, w1, s1, b1)
+    assert torch.equal(x, x_two), (x != x_two).sum().item()
+    assert torch.equal(y1, y1_two), (y1 != y1_two).sum().item()
+    xr = torch.relu(y2.double() @ w3.double().t() * s3.double() + b3.double() + res.double())
+    assert torch.allclose(x.double(), xr, rtol=2e-3, atol=2e-3)
+    y1r = torch.relu(x.double() @ w1.double().t() * s1.double() + b1.double())           # from the fp16 x', like the reference's next conv
+    assert torch.allclose(y1.double(), y1r, rtol=2e-3, atol=2e-3)
+    from dbmm_amd import _lib
+    bx = torch.full((M * N + 4096,), 7.0, device=DEV, dtype=torch.float16); by = torch.full((M * P + 4096,), 7.0, device=DEV, dtype=torch.float16)
+    rc = _lib.lib().dbmm_bottleneck_chain_f16(y2.data_ptr(), w3.data_ptr(), s3.data_ptr(), b3.data_ptr(), res.data_ptr(), bx.data_ptr(), w1.data_ptr(),
+                                              s1.data_ptr(), b1.data_ptr(), by.data_ptr(), M, K, N, P, _lib.stream())
+    torch.cuda.synchronize()
+    assert rc == 0 and torch.equal(bx[:M * N].view(M, N), x) and torch.equal(by[:M * P].view(M, P), y1)
+    assert (bx[M * N:] == 7.0).all() and (by[M * P:] == 7.0).all()
+    assert ops.chain_f16(torch.zeros((M, 256), device=DEV, dtype=torch.float16), (torch.zeros((N, 256), device=DEV, dtype=torch.float16), s3, b3), res, (w1, s1, b1)) is None
