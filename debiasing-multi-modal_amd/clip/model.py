@@ -340,8 +340,9 @@ class ModifiedResNet(nn.Module):
                 out = y1_next if y1_next is not None else ops.conv1x1_f16(x, *e["c1"])
                 y1_next = None
                 out = ops.conv3x3_f16(out, *e["c2"], pool=2 if e["stride"] == 2 else 1)     # conv2 + bn2 + relu (+ avgpool)
-                if "ds" not in e and k_in_stage + 1 < nblk and _opt["fuse_chain"]:
-                    # conv3 + residual -> conv1 of the next block of the stage in one launch (layers 1 - 2; None elsewhere)
+                if "ds" not in e and bi < len(P["blocks"]) and _opt["fuse_chain"]:
+                    # conv3 + residual -> conv1 of the NEXT block (of this stage, or the first block of the next stage: its conv1 runs on
+                    # the un-pooled map too) in one launch (layers 1 - 2 and the 1 -> 2 seam; None elsewhere)
                     r = ops.chain_f16(out, e["c3"], x, P["blocks"][bi]["c1"])
                     if r is not None:
                         x, y1_next = r
