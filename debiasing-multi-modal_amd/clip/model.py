@@ -352,6 +352,12 @@ class ModifiedResNet(nn.Module):
                     if e["stride"] == 2:
                         identity = ops.avgpool2_f16(x)
                     fused = None
+                    if "dual" in e and _opt["fuse_ds"] and _opt["fuse_chain"] and bi < len(P["blocks"]):
+                        # ... and conv1 of the next block chained on (layer 1's first block; None elsewhere)
+                        r = ops.chain_dual_f16(out, e["c3"][0], e["c3"][1], identity, e["ds"][0], *e["dual"], P["blocks"][bi]["c1"])
+                        if r is not None:
+                            x, y1_next = r
+                            continue
                     if "dual" in e and _opt["fuse_ds"]:                     # conv3 + downsample branch in one launch where the library has the shape
                         fused = ops.conv1x1_dual_f16(out, e["c3"][0], e["c3"][1], identity, e["ds"][0], *e["dual"])
                     if fused is not None:

@@ -35,6 +35,7 @@ constexpr long long EXT_LIM = 0x7FFFFFF0LL;
 struct ChainHP {
     const u16* a; const u16* w3; const float* sc3; const float* b3; const u16* res; u16* x;
     const u16* w1; const float* sc1; const float* b1; u16* y1;
+    const u16* a2; const u16* w2; const float* ratio;              // DUAL: the block's downsample branch (64 channels deep) instead of a residual
     int M, N;
 };
 
@@ -54,15 +55,19 @@ __device__ __forceinline__ int swz(int row) { return RB == 128 ? ((row >> 1) & 7
 constexpr int BM = 128, BNS = 64;
 
 // (two workgroups per CU; three -- layer 1's K = P = 64 variant squeezed into 168 registers, 10 of them spilled -- measured 934 against 921 us)
-template <int K, int P>
+// DUAL (the first block of layer 1): x' = relu((y2 @ W3^T + ((xp @ Wd^T) * ratio)) * sc3 + b) -- the downsample branch's 64-deep GEMM
+// runs first, its sums are multiplied per output channel by ratio = sc_d / sc3 and conv3 continues on the same accumulators: the
+// order and arithmetic of conv1x1_f16_kernel<.., TWO = 1> (dbmm_conv1x1_dual_stream_f16), so again bit-equal to the two launches.
+template <int K, int P, int DUAL = 0>
 __global__ __launch_bounds__(256, 2) void chain_f16_kernel(const ChainHP p) {
     static_assert(K == 64 || K == 128, "conv3 reduction depth: 64 (layer 1) or 128 (layer 2)");
     static_assert(P == 64 || P == 128, "conv1' width");
     constexpr int KS = K / 16, TN1 = P / 32;
-    constexpr int W3_BYTES = BNS * K * 2, W1_BYTES = P * BNS * 2, XS_BYTES = 4 * 32 * 128;
-    __shared__ __attribute__((aligned(256))) unsigned char lds[W3_BYTES + W1_BYTES + XS_BYTES];
+    constexpr int W3_BYTES = BNS * K * 2, W1_BYTES = P * BNS * 2, XS_BYTES = 4 * 32 * 128, W2_BYTES = DUAL ? BNS * 64 * 2 : 0;
+    __shared__ __attribute__((aligned(256))) unsigned char lds[W3_BYTES + W1_BYTES + XS_BYTES + W2_BYTES];
     unsigned char* W3b = lds;                                       // [64 rows (block j, column c)][K]
     unsigned char* W1b = lds + W3_BYTES;                            // [P rows (block, column)][64 k]
+    unsigned char* W2b = lds + W3_BYTES + W1_BYTES + XS_BYTES;      // DUAL: [64 rows (block j, column c)][64]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     unsigned char* XS = lds + W3_BYTES + W1_BYTES + wave * (32 * 128);   // this wave's x' slab: [32 rows][64 k] fp16
     const int fr = lane & 31, fh = lane >> 5;
@@ -70,7 +75,7 @@ __global__ __launch_bounds__(256, 2) void chain_f16_kernel(const ChainHP p) {
     const int NT = p.N / BNS;
     const long long Mll = p.M;
     const __amdgpu_buffer_rsrc_t rsA = desc(p.a, Mll * K * 2, (long long)m0 * K * 2);
-    const __amdgpu_buffer_rsrc_t rsR = desc(p.res, Mll * p.N * 2, (long long)m0 * p.N * 2);
+    const __amdgpu_buffer_rsrc_t rsR = DUAL ? desc(p.a2, Mll * 64 * 2, (long long)m0 * 64 * 2) : desc(p.res, Mll * p.N * 2, (long long)m0 * p.N * 2);
     const __amdgpu_buffer_rsrc_t rsX = desc(p.x, Mll * p.N * 2, (long long)m0 * p.N * 2);
     const __amdgpu_buffer_rsrc_t rsY = desc(p.y1, Mll * P * 2, (long long)m0 * P * 2);
 
@@ -83,8 +88,15 @@ __global__ __launch_bounds__(256, 2) void chain_f16_kernel(const ChainHP p) {
     constexpr int CPR3 = K / 8, RPP3 = 256 / CPR3, W3LD = BNS * CPR3 / 256;             // chunks per row, rows per pass, loads per thread
     constexpr int CPR1 = BNS / 8, RPP1 = 256 / CPR1, W1LD = P * CPR1 / 256;
     const int wc3 = tid % CPR3, wr3 = tid / CPR3, wc1 = tid % CPR1, wr1 = tid / CPR1;
-    u32x4 w3r[W3LD], w1r[W1LD];
+    u32x4 w3r[W3LD], w1r[W1LD], w2r[DUAL ? 2 : 1];
     auto load_w = [&](int nt) {
+        if (DUAL) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int lr = wr1 + RPP1 * j, ch = 2 * (lr & 31) + (lr >> 5);
+                w2r[j] = *(const u32x4*)(p.w2 + (size_t)(nt * BNS + ch) * 64 + wc1 * 8);
+            }
+        }
 #pragma unroll
         for (int j = 0; j < W3LD; ++j) {
             const int lr = wr3 + RPP3 * j, ch = 2 * (lr & 31) + (lr >> 5);              // LDS row (block lr >> 5, column lr & 31) <-> channel
@@ -97,6 +109,13 @@ __global__ __launch_bounds__(256, 2) void chain_f16_kernel(const ChainHP p) {
         }
     };
     auto store_w = [&]() {
+        if (DUAL) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int lr = wr1 + RPP1 * j;
+                *(u32x4*)(W2b + lr * 128 + ((wc1 ^ swz<128>(lr)) << 4)) = w2r[j];
+            }
+        }
 #pragma unroll
         for (int j = 0; j < W3LD; ++j) {
             const int lr = wr3 + RPP3 * j;
@@ -110,6 +129,7 @@ __global__ __launch_bounds__(256, 2) void chain_f16_kernel(const ChainHP p) {
     };
     unsigned rv[16];
     auto load_res = [&](int nt) {
+        if (DUAL) return;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int u = (r & 3) + 8 * (r >> 2);
@@ -120,12 +140,17 @@ __global__ __launch_bounds__(256, 2) void chain_f16_kernel(const ChainHP p) {
     // ---- prologue: first weight slabs and residual slab in flight; the y2 fragments of the wave's 32 rows into registers ----
     load_w(0);
     load_res(0);
-    u32x4 ay[KS];
+    u32x4 ay[KS], ay2[DUAL ? 4 : 1];
     {
         const int m = m0 + wave * 32 + fr;
         const unsigned va = m < p.M ? (unsigned)((wave * 32 + fr) * K + 8 * fh) * 2u : OOR;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) ay[ks] = __builtin_amdgcn_raw_buffer_load_b128(rsA, va, (unsigned)(ks * 32), 0);
+        if (DUAL) {
+            const unsigned va2 = m < p.M ? (unsigned)((wave * 32 + fr) * 64 + 8 * fh) * 2u : OOR;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) ay2[ks] = __builtin_amdgcn_raw_buffer_load_b128(rsR, va2, (unsigned)(ks * 32), 0);
+        }
     }
     f32x16 acc1[TN1];
 #pragma unroll
@@ -143,6 +168,20 @@ __global__ __launch_bounds__(256, 2) void chain_f16_kernel(const ChainHP p) {
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc3[j][r] = 0.f;
+        const int n = nt * BNS + 2 * fr;
+        if (DUAL) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int lr = j * 32 + fr;
+                    const u32x4 wf = *(const u32x4*)(W2b + lr * 128 + (((2 * ks + fh) ^ swz<128>(lr)) << 4));
+                    acc3[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ay2[ks]), __builtin_bit_cast(f16x8, wf), acc3[j], 0, 0, 0);
+                }
+            const float r0 = p.ratio[n], r1 = p.ratio[n + 1];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc3[0][r] *= r0; acc3[1][r] *= r1; }
+        }
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
@@ -152,14 +191,16 @@ __global__ __launch_bounds__(256, 2) void chain_f16_kernel(const ChainHP p) {
                 acc3[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ay[ks]), __builtin_bit_cast(f16x8, wf), acc3[j], 0, 0, 0);
             }
         // ---- x' = relu(acc * sc3 + b3 + residual): packed fp16 to HBM and to the wave's LDS slab ----
-        const int n = nt * BNS + 2 * fr;
         const float s0 = p.sc3 ? p.sc3[n] : 1.f, s1 = p.sc3 ? p.sc3[n + 1] : 1.f, c0 = p.b3 ? p.b3[n] : 0.f, c1 = p.b3 ? p.b3[n + 1] : 0.f;
         unsigned xv[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const f16x2 rh = __builtin_bit_cast(f16x2, rv[r]);
-            const float v0 = fmaxf(fmaf(acc3[0][r], s0, c0) + (float)rh[0], 0.f), v1 = fmaxf(fmaf(acc3[1][r], s1, c1) + (float)rh[1], 0.f);
-            xv[r] = pack2(v0, v1);
+            float v0 = fmaf(acc3[0][r], s0, c0), v1 = fmaf(acc3[1][r], s1, c1);
+            if (!DUAL) {
+                const f16x2 rh = __builtin_bit_cast(f16x2, rv[r]);
+                v0 += (float)rh[0]; v1 += (float)rh[1];
+            }
+            xv[r] = pack2(fmaxf(v0, 0.f), fmaxf(v1, 0.f));
         }
         if (nt + 1 < NT) load_res(nt + 1);                          // (rv is free: the next slab's residual flies during the stores and conv1')
 #pragma unroll
@@ -200,25 +241,44 @@ __global__ __launch_bounds__(256, 2) void chain_f16_kernel(const ChainHP p) {
 
 }  // namespace
 
-// see include/dbmm.h
-extern "C" int dbmm_bottleneck_chain_f16(const void* y2, const void* w3, const float* scale3, const float* bias3, const void* residual, void* x_out,
-                                         const void* w1, const float* scale1, const float* bias1, void* y1_out, int64_t M, int64_t K, int64_t N,
-                                         int64_t P, void* stream) {
-    if (!y2 || !w3 || !residual || !x_out || !w1 || !y1_out) return DBMM_E_ARG;
+static int chain_launch(const void* y2, const void* w3, const float* scale3, const float* bias3, const void* residual, const void* downsample_in,
+                        const void* wd, const float* ratio, void* x_out, const void* w1, const float* scale1, const float* bias1, void* y1_out,
+                        int64_t M, int64_t K, int64_t K2, int64_t N, int64_t P, void* stream) {
+    const void* second = downsample_in ? downsample_in : residual;
+    if (!y2 || !w3 || !second || !x_out || !w1 || !y1_out || (downsample_in && (!wd || !ratio))) return DBMM_E_ARG;
     if (M <= 0 || N <= 0 || M > INT32_MAX - 1024) return DBMM_E_SHAPE;
     if (!(K == 64 || K == 128) || !(P == 64 || P == 128) || (N % 64) || N < 64) return DBMM_E_UNSUPPORTED;
-    if (!dbmm_aligned16(y2) || !dbmm_aligned16(w3) || !dbmm_aligned16(residual) || !dbmm_aligned16(x_out) || !dbmm_aligned16(w1) || !dbmm_aligned16(y1_out))
+    if (downsample_in && (K != 64 || P != 64 || K2 != 64)) return DBMM_E_UNSUPPORTED;
+    if (!dbmm_aligned16(y2) || !dbmm_aligned16(w3) || !dbmm_aligned16(second) || !dbmm_aligned16(x_out) || !dbmm_aligned16(w1) || !dbmm_aligned16(y1_out) ||
+        (wd && !dbmm_aligned16(wd)))
         return DBMM_E_ALIGN;
     if (128LL * N * 2 >= EXT_LIM) return DBMM_E_UNSUPPORTED;
     ChainHP p{};
     p.a = (const u16*)y2; p.w3 = (const u16*)w3; p.sc3 = scale3; p.b3 = bias3; p.res = (const u16*)residual; p.x = (u16*)x_out;
     p.w1 = (const u16*)w1; p.sc1 = scale1; p.b1 = bias1; p.y1 = (u16*)y1_out; p.M = (int)M; p.N = (int)N;
+    p.a2 = (const u16*)downsample_in; p.w2 = (const u16*)wd; p.ratio = ratio;
     const dim3 grid((unsigned)((M + BM - 1) / BM));
     hipStream_t s = (hipStream_t)stream;
-    if (K == 64 && P == 64) hipLaunchKernelGGL((chain_f16_kernel<64, 64>), grid, dim3(256), 0, s, p);
+    if (downsample_in) hipLaunchKernelGGL((chain_f16_kernel<64, 64, 1>), grid, dim3(256), 0, s, p);
+    else if (K == 64 && P == 64) hipLaunchKernelGGL((chain_f16_kernel<64, 64>), grid, dim3(256), 0, s, p);
     else if (K == 64 && P == 128) hipLaunchKernelGGL((chain_f16_kernel<64, 128>), grid, dim3(256), 0, s, p);
     else if (K == 128 && P == 64) hipLaunchKernelGGL((chain_f16_kernel<128, 64>), grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL((chain_f16_kernel<128, 128>), grid, dim3(256), 0, s, p);
     DBMM_CHECK_LAUNCH();
     return DBMM_OK;
+}
+
+// see include/dbmm.h
+extern "C" int dbmm_bottleneck_chain_f16(const void* y2, const void* w3, const float* scale3, const float* bias3, const void* residual, void* x_out,
+                                         const void* w1, const float* scale1, const float* bias1, void* y1_out, int64_t M, int64_t K, int64_t N,
+                                         int64_t P, void* stream) {
+    return chain_launch(y2, w3, scale3, bias3, residual, nullptr, nullptr, nullptr, x_out, w1, scale1, bias1, y1_out, M, K, 0, N, P, stream);
+}
+
+// see include/dbmm.h
+extern "C" int dbmm_bottleneck_chain_dual_f16(const void* y2, const void* w3, const float* scale3, const void* xp, const void* wd, const float* ratio,
+                                              const float* bias, void* x_out, const void* w1, const float* scale1, const float* bias1, void* y1_out,
+                                              int64_t M, int64_t K, int64_t K2, int64_t N, int64_t P, void* stream) {
+    if (!xp) return DBMM_E_ARG;
+    return chain_launch(y2, w3, scale3, bias, nullptr, xp, wd, ratio, x_out, w1, scale1, bias1, y1_out, M, K, K2, N, P, stream);
 }

@@ -881,6 +881,29 @@ def chain_f16(y2, c3, residual, c1):
     return x, y1
 
 
+def chain_dual_f16(y2, w3, scale3, xp, wd, ratio, bias, c1):
+    """fp16 mode: the first block of a stage -- x' = relu(conv3(y2) * scale3 + conv_d(xp) * scale_d + bias) (conv1x1_dual_f16's arguments) and
+    y1' = relu(conv1'(x') * s1 + b1) in one launch (dbmm_bottleneck_chain_dual_f16).  Returns (x', y1') or None."""
+    require_cuda(y2, xp)
+    _f16c(y2); _f16c(xp); _f16c(w3); _f16c(wd)
+    w1, s1, b1 = c1
+    N, K = w3.shape
+    K2 = wd.shape[1]
+    P = w1.shape[0]
+    M = y2.numel() // K
+    x = _empty(tuple(y2.shape[:-1]) + (N,), device=y2.device, dtype=torch.float16)
+    y1 = _empty(tuple(y2.shape[:-1]) + (P,), device=y2.device, dtype=torch.float16)
+    t = _TimedTag(f"chain_f16_kernel<{K}, {P}, 1>", 2.0 * M * N * (K + K2 + P), 2 * (M * (K + K2 + N + P) + N * (K + K2 + P)))
+    t.__enter__()
+    rc = _lib.lib().dbmm_bottleneck_chain_dual_f16(ptr(y2), ptr(w3), ptr(scale3), ptr(xp), ptr(wd), ptr(ratio), ptr(bias), ptr(x), ptr(w1), ptr(s1),
+                                                   ptr(b1), ptr(y1), M, K, K2, N, P, stream())
+    t.__exit__(None if rc == 0 else DbmmUnsupported, None, None)
+    if rc == _lib.E_UNSUPPORTED:
+        return None
+    check(rc, "bottleneck_chain_dual_f16")
+    return x, y1
+
+
 def conv1x1_dual_f16(y2, w3, scale3, xp, wd, ratio, bias, act=ACT_RELU):
     """fp16 mode: act(conv3(y2) * scale3 + conv_d(xp) * scale_d + bias) as one dual-source GEMM (dbmm_conv1x1_dual_bn_act_f16);
     ratio = scale_d / scale3, bias = both BatchNorm biases.  None when the library has no kernel for the shape."""

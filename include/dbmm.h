@@ -291,6 +291,12 @@ int dbmm_conv1x1_dual_bn_act_f16(const void* y2, const void* w3, const float* sc
 int dbmm_bottleneck_chain_f16(const void* y2, const void* w3, const float* scale3, const float* bias3, const void* residual, void* x_out,
                               const void* w1, const float* scale1, const float* bias1, void* y1_out, int64_t M, int64_t K, int64_t N,
                               int64_t P, void* stream);
+/* the same chain for the FIRST block of a stage, whose shortcut is the downsample conv instead of a residual (dbmm_conv1x1_dual_bn_act_f16's
+ * arguments and arithmetic, then conv1 of the next block): x_out = relu((y2 @ w3^T + (xp @ wd^T) * ratio) * scale3 + bias).
+ * K = K2 = P = 64 (layer 1's first block); DBMM_E_UNSUPPORTED (nothing launched) otherwise. */
+int dbmm_bottleneck_chain_dual_f16(const void* y2, const void* w3, const float* scale3, const void* xp, const void* wd, const float* ratio,
+                                   const float* bias, void* x_out, const void* w1, const float* scale1, const float* bias1, void* y1_out,
+                                   int64_t M, int64_t K, int64_t K2, int64_t N, int64_t P, void* stream);
 int dbmm_conv1x1_bn_act_f16_ws(const void* x, const void* w, const float* scale, const float* bias, const void* residual, void* y,
                                int64_t M, int64_t Cin, int64_t Cout, int act, void* workspace, size_t workspace_bytes,
                                void* stream);          /* with a workspace, as dbmm_gemm_f16_ws */

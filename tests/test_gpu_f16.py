@@ -467,3 +467,41 @@ def test_bottleneck_chain_f16(M, K, N, P):
     assert rc == 0 and torch.equal(bx[:M * N].view(M, N), x) and torch.equal(by[:M * P].view(M, P), y1)
     assert (bx[M * N:] == 7.0).all() and (by[M * P:] == 7.0).all()
     assert ops.chain_f16(torch.zeros((M, 256), device=DEV, dtype=torch.float16), (torch.zeros((N, 256), device=DEV, dtype=torch.float16), s3, b3), res, (w1, s1, b1)) is None
+
+
+@pytest.mark.parametrize("M,N", [(56 * 56 * 3, 256), (1000 + 37, 192), (7, 128)])
+def test_bottleneck_chain_dual_f16(M, N):
+    """fp16 mode, layer 1's first block: conv3 + downsample branch + ReLU and conv1 of the next block as one launch (clip/model.py:36-38,
+    42-55, then 42 of the next block): equal BIT FOR BIT to the dual launch + conv1 launch it replaces, against fp64, ragged tiles, guard
+    zones behind both outputs; other depths answer None"""
+    K = K2 = P = 64
+    g = torch.Generator(device=DEV); g.manual_seed(M + N)
+    y2 = torch.relu(torch.randn((M, K), device=DEV, generator=g)).half(); xp = torch.relu(torch.randn((M, K2), device=DEV, generator=g) * 2.0).half()
+    w3 = (torch.randn((N, K), device=DEV, generator=g) * K ** -0.5).half(); wd = (torch.randn((N, K2), device=DEV, generator=g) * K2 ** -0.5).half()
+    w1 = (torch.randn((P, N), device=DEV, generator=g) * N ** -0.5).half()
+    s3 = 0.5 + torch.rand((N,), device=DEV, generator=g); sd = 0.5 + torch.rand((N,), device=DEV, generator=g)
+    b3 = torch.randn((N,), device=DEV, generator=g) * 0.1; bd = torch.randn((N,), device=DEV, generator=g) * 0.1
+    s1, b1 = _bn(g, P)
+    ratio, bsum = (sd / s3).contiguous(), (b3 + bd).contiguous()
+    r = ops.chain_dual_f16(y2, w3, s3, xp, wd, ratio, bsum, (w1, s1, b1))
+    assert r is not None
+    x, y1 = r
+    x_two = ops.conv1x1_dual_f16(y2, w3, s3, xp, wd, ratio, bsum)
+    assert x_two is not None
+    y1_two = ops.conv1x1_f16(x_two, w1, s1, b1)
+    assert torch.equal(x, x_two), (x != x_two).sum().item()
+    assert torch.equal(y1, y1_two), (y1 != y1_two).sum().item()
+    xr = torch.relu(y2.double() @ w3.double().t() * s3.double() + xp.double() @ wd.double().t() * sd.double() + bsum.double())
+    assert torch.allclose(x.double(), xr, rtol=2e-3, atol=2e-3)
+    y1r = torch.relu(x.double() @ w1.double().t() * s1.double() + b1.double())
+    assert torch.allclose(y1.double(), y1r, rtol=2e-3, atol=2e-3)
+    from dbmm_amd import _lib
+    bx = torch.full((M * N + 4096,), 7.0, device=DEV, dtype=torch.float16); by = torch.full((M * P + 4096,), 7.0, device=DEV, dtype=torch.float16)
+    rc = _lib.lib().dbmm_bottleneck_chain_dual_f16(y2.data_ptr(), w3.data_ptr(), s3.data_ptr(), xp.data_ptr(), wd.data_ptr(), ratio.data_ptr(),
+                                                   bsum.data_ptr(), bx.data_ptr(), w1.data_ptr(), s1.data_ptr(), b1.data_ptr(), by.data_ptr(),
+                                                   M, K, K2, N, P, _lib.stream())
+    torch.cuda.synchronize()
+    assert rc == 0 and torch.equal(bx[:M * N].view(M, N), x) and torch.equal(by[:M * P].view(M, P), y1)
+    assert (bx[M * N:] == 7.0).all() and (by[M * P:] == 7.0).all()
+    w3b = (torch.randn((N, 128), device=DEV, generator=g) * 0.1).half()
+    assert ops.chain_dual_f16(torch.zeros((M, 128), device=DEV, dtype=torch.float16), w3b, s3, xp, wd, ratio, bsum, (w1, s1, b1)) is None
