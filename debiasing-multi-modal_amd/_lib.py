@@ -123,6 +123,7 @@ _SIGS = {
     "dbmm_conv1x1_bn_act_f16_ws": [_P, _P, _P, _P, _P, _P, _L, _L, _L, _I, _P, _Z, _P],
     "dbmm_conv1x1_dual_bn_act_f16": [_P, _P, _P, _P, _P, _P, _P, _P, _L, _L, _L, _L, _I, _P],
     "dbmm_bottleneck_chain_f16": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _L, _L, _L, _P],
+    "dbmm_bottleneck_chain_pool_f16": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _L, _L, _L, _L, _L, _P],
     "dbmm_bottleneck_chain_dual_f16": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _L, _L, _L, _L, _P],
     "dbmm_conv3x3_bn_relu_f16": [_P, _P, _P, _P, _P, _L, _L, _L, _L, _L, _I, _P],
     "dbmm_conv_stem_s2_f16": [_P, _I, _P, _P, _P, _L, _L, _L, _L, _P],

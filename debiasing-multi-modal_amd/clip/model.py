@@ -138,8 +138,11 @@ def _conv_bn(conv, bn):
 #   fuse_ds     conv3 + downsample branch of a stage's first block as one dual-source GEMM (0: two launches)
 #   fuse_chain  conv3 + residual chained with the next block's conv1 in one launch (0: separate launches)
 #   fuse_conv2  ... and the block's own 3x3 conv2 inside that launch too (0: conv2 as its own launch)
+#   seam_pool   the chain launch at a stage seam also writes AvgPool2d(2) of the stage output for the next stage's downsample branch:
+#               2 (default) = and ONLY that, not the un-pooled tensor nobody else reads (the stage outputs of return_stages=True are
+#               always written); 1 = both; 0 = fp16 mode: neither, a separate pooling launch (the fp32-accurate plan: as 1)
 _PLAN_OPTIONS = {"conv_split": ("f16", ("f16", "bf16", "off")), "conv_k_order": ("chunk32", ("chunk32", "tap")),
-                 "fuse_ds": (1, (0, 1)), "fuse_chain": (1, (0, 1)), "fuse_conv2": (1, (0, 1))}
+                 "fuse_ds": (1, (0, 1)), "fuse_chain": (1, (0, 1)), "fuse_conv2": (1, (0, 1)), "seam_pool": (2, (0, 1, 2))}
 _opt = {}
 _opt_version = [0]
 
@@ -333,6 +336,7 @@ class ModifiedResNet(nn.Module):
         stages = {"stem": x}
         bi = 0
         y1_next = None                                                  # conv1 of this block, when the previous block's chain launch made it
+        x_pooled = None                                                 # AvgPool2d(2) of x, when that launch made it too
         for li in (1, 2, 3, 4):
             nblk = len(getattr(self, f"layer{li}"))
             for k_in_stage in range(nblk):
@@ -343,14 +347,18 @@ class ModifiedResNet(nn.Module):
                 if "ds" not in e and bi < len(P["blocks"]) and _opt["fuse_chain"]:
                     # conv3 + residual -> conv1 of the NEXT block (of this stage, or the first block of the next stage: its conv1 runs on
                     # the un-pooled map too) in one launch (layers 1 - 2 and the 1 -> 2 seam; None elsewhere)
-                    r = ops.chain_f16(out, e["c3"], x, P["blocks"][bi]["c1"])
+                    nxt = P["blocks"][bi]
+                    # ... and AvgPool2d(2) of x for the next stage's downsample branch; the un-pooled x only when the caller wants the stages
+                    seam = "ds" in nxt and nxt["stride"] == 2 and _opt["seam_pool"] > 0
+                    r = ops.chain_f16(out, e["c3"], x, nxt["c1"], pooled=seam, keep_full=return_stages or _opt["seam_pool"] < 2)
                     if r is not None:
-                        x, y1_next = r
+                        x, x_pooled, y1_next = r if seam else (r[0], None, r[1])
                         continue
                 identity = x
                 if "ds" in e:
                     if e["stride"] == 2:
-                        identity = ops.avgpool2_f16(x)
+                        identity = x_pooled if x_pooled is not None else ops.avgpool2_f16(x)
+                        x_pooled = None
                     fused = None
                     if "dual" in e and _opt["fuse_ds"] and _opt["fuse_chain"] and bi < len(P["blocks"]):
                         # ... and conv1 of the next block chained on (layer 1's first block; None elsewhere)
@@ -465,14 +473,15 @@ class ModifiedResNet(nn.Module):
                 # block downsamples, the same launch also writes AvgPool2d(2) of its output for that
                 # block's downsample branch
                 nxt = blocks[bi] if bi < len(blocks) else None
-                want_pool = nxt is not None and nxt["stride"] == 2 and "ds" in nxt and x.shape[1] % 2 == 0 and x.shape[2] % 2 == 0 \
-                    and identity.shape[1] % 2 == 0 and identity.shape[2] % 2 == 0
+                want_pool = nxt is not None and nxt["stride"] == 2 and "ds" in nxt and identity.shape[1] % 2 == 0 and identity.shape[2] % 2 == 0
                 if (nxt is not None and track and _opt["fuse_chain"] and e["c3"]["sc"] is not None and nxt["c1"]["sc"] is not None
                         and e["c3"]["ph"] is not None and nxt["c1"]["ph"] is not None
                         and (want_pool or not (nxt["stride"] == 2 and "ds" in nxt))):
                     # the same launch continues into the next block's conv1: x is written once, not re-read
                     x_am, y1_am = amax[slot[0]:slot[0] + 1], amax[slot[0] + 1:slot[0] + 2]
-                    r = ops.bottleneck_chain(out, oam, e["c3"], identity, nxt["c1"], x_am, y1_am, pooled=want_pool)
+                    # (at a seam the un-pooled x is read by nobody else: it is only written when the caller wants the stage outputs)
+                    r = ops.bottleneck_chain(out, oam, e["c3"], identity, nxt["c1"], x_am, y1_am, pooled=want_pool,
+                                             keep_full=return_stages or _opt["seam_pool"] < 2)
                     if r is not None:
                         slot[0] += 2                      # this conv3's slot and the next conv1's
                         if want_pool:

@@ -2,7 +2,8 @@
 //
 //   x' = relu( (y2 @ W3^T) * sc3 + b3 + x )          [M][N]   written to HBM (it is the next residual)
 //   y1' = relu( (x' @ W1^T) * sc1 + b1 )             [M][P]   written to HBM
-//   (POOL: also avgpool2x2(x') [M/4][N] for the downsample branch of the next stage's first block)
+//   (POOL: also avgpool2x2(x') [M/4][N] for the downsample branch of the next stage's first block; POOL = 2: ONLY the pooled
+//    copy -- at a stage seam nothing else reads the un-pooled x', conv1' has just consumed it here)
 //
 // Why: at the headline batch the 1x1 convs of layers 1-2 are HBM-bound and conv1 of the NEXT block re-reads
 // the 256/512-channel tensor conv3 has just written (clip/model.py:42-55 back to back): 3.3 GB of the 13 GB a
@@ -159,7 +160,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck_chain_kernel(const ChainP p
     const __amdgpu_buffer_rsrc_t rsA = desc(p.a, Mll * K * 4, (long long)g0 * K * 4);
     const __amdgpu_buffer_rsrc_t rsR = DUAL ? desc(p.a2, Mll * 64 * 4, (long long)g0 * 64 * 4)      // DUAL: the branch input
                                             : desc(p.res, Mll * p.N * 4, (long long)g0 * p.N * 4);
-    const __amdgpu_buffer_rsrc_t rsX = desc(p.x, Mll * p.N * 4, (long long)g0 * p.N * 4);
+    const __amdgpu_buffer_rsrc_t rsX = desc(p.x, POOL == 2 ? 0 : Mll * p.N * 4, (long long)g0 * p.N * 4);
     const __amdgpu_buffer_rsrc_t rsY = desc(p.y1, Mll * P * 4, (long long)g0 * P * 4);
     __amdgpu_buffer_rsrc_t rsXP = rsX;
     if constexpr (POOL) rsXP = desc(p.xp, (Mll >> 2) * p.N * 4, (long long)(m0 >> 2) * p.N * 4);
@@ -512,8 +513,9 @@ __global__ __launch_bounds__(256, 2) void bottleneck_chain_kernel(const ChainP p
                 if (gx[r >> 2] == OOR) v = 0.f;          // rows past M: keep the slab clean (their stores are dropped)
                 acc3[j][r] = v;
                 tmax = fmaxf(tmax, v);
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsX, gx[r >> 2],
-                                                      (unsigned)((n0 + j * 32) * 4 + qpix(r & 3) * p.N * 4), 0);
+                if constexpr (POOL != 2)
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsX, gx[r >> 2],
+                                                          (unsigned)((n0 + j * 32) * 4 + qpix(r & 3) * p.N * 4), 0);
                 Ls[((r & 3) + 8 * (r >> 2) + 4 * fh) * SLROW + j * 32 + fr] = v;
             }
             if constexpr (POOL) {
@@ -685,9 +687,9 @@ extern "C" int dbmm_bottleneck_chain_x2(const float* y2, const float* y2_absmax,
                                         float* x_pooled, float* x_absmax, const void* w1_plane_f16, int w1_exp,
                                         const float* scale1, const float* bias1, float* y1_out, float* y1_absmax,
                                         int64_t B, int64_t Ho, int64_t Wo, int64_t K, int64_t N, int64_t P, void* stream) {
-    if (!y2 || !y2_absmax || !w3_plane_f16 || !scale3 || !bias3 || !residual || !x_out || !w1_plane_f16 || !scale1 || !bias1 ||
-        !y1_out)
+    if (!y2 || !y2_absmax || !w3_plane_f16 || !scale3 || !bias3 || !residual || !w1_plane_f16 || !scale1 || !bias1 || !y1_out)
         return DBMM_E_ARG;
+    if (!x_out && !x_pooled) return DBMM_E_ARG;         // x_out may be NULL only when the pooled copy is what the caller keeps
     if (B <= 0 || Ho <= 0 || Wo <= 0 || K <= 0 || N <= 0 || P <= 0) return DBMM_E_SHAPE;
     const int64_t M = B * Ho * Wo;
     if (M > (INT32_MAX >> 1)) return DBMM_E_SHAPE;
@@ -704,7 +706,7 @@ extern "C" int dbmm_bottleneck_chain_x2(const float* y2, const float* y2_absmax,
     if (w3_exp < -40 || w3_exp > 40 || w1_exp < -40 || w1_exp > 40) return DBMM_E_UNSUPPORTED;
     if (x_pooled && ((Ho & 1) || (Wo & 1))) return DBMM_E_UNSUPPORTED;
     if (!dbmm_aligned16(y2) || !dbmm_aligned16(w3_plane_f16) || !dbmm_aligned16(w1_plane_f16) || !dbmm_aligned16(residual) ||
-        !dbmm_aligned16(x_out) || !dbmm_aligned16(y1_out) || (x_pooled && !dbmm_aligned16(x_pooled)))
+        (x_out && !dbmm_aligned16(x_out)) || !dbmm_aligned16(y1_out) || (x_pooled && !dbmm_aligned16(x_pooled)))
         return DBMM_E_ALIGN;
     ChainP p{};
     p.a = y2; p.a_absmax = y2_absmax;
@@ -717,11 +719,13 @@ extern "C" int dbmm_bottleneck_chain_x2(const float* y2, const float* y2_absmax,
     hipStream_t s = (hipStream_t)stream;
 #define CHAIN_LAUNCH(KK, PP, PL) hipLaunchKernelGGL((bottleneck_chain_kernel<KK, PP, PL>), grid, dim3(256), 0, s, p)
     if (K == 64) {
-        if (x_pooled) { if (P == 64) CHAIN_LAUNCH(64, 64, 1); else CHAIN_LAUNCH(64, 128, 1); }
-        else          { if (P == 64) CHAIN_LAUNCH(64, 64, 0); else CHAIN_LAUNCH(64, 128, 0); }
+        if (!x_out)        { if (P == 64) CHAIN_LAUNCH(64, 64, 2); else CHAIN_LAUNCH(64, 128, 2); }
+        else if (x_pooled) { if (P == 64) CHAIN_LAUNCH(64, 64, 1); else CHAIN_LAUNCH(64, 128, 1); }
+        else               { if (P == 64) CHAIN_LAUNCH(64, 64, 0); else CHAIN_LAUNCH(64, 128, 0); }
     } else {
-        if (x_pooled) { if (P == 64) CHAIN_LAUNCH(128, 64, 1); else CHAIN_LAUNCH(128, 128, 1); }
-        else          { if (P == 64) CHAIN_LAUNCH(128, 64, 0); else CHAIN_LAUNCH(128, 128, 0); }
+        if (!x_out)        { if (P == 64) CHAIN_LAUNCH(128, 64, 2); else CHAIN_LAUNCH(128, 128, 2); }
+        else if (x_pooled) { if (P == 64) CHAIN_LAUNCH(128, 64, 1); else CHAIN_LAUNCH(128, 128, 1); }
+        else               { if (P == 64) CHAIN_LAUNCH(128, 64, 0); else CHAIN_LAUNCH(128, 128, 0); }
     }
 #undef CHAIN_LAUNCH
     DBMM_CHECK_LAUNCH();

@@ -36,8 +36,18 @@ struct ChainHP {
     const u16* a; const u16* w3; const float* sc3; const float* b3; const u16* res; u16* x;
     const u16* w1; const float* sc1; const float* b1; u16* y1;
     const u16* a2; const u16* w2; const float* ratio;              // DUAL: the block's downsample branch (64 channels deep) instead of a residual
+    u16* xp; int Ho, Wo;                                            // POOL: AvgPool2d(2) of x' [M / 4][N]; M = B * Ho * Wo pixels
     int M, N;
 };
+
+// pixel (standard order) of tile row m: identity, or 2x2-window-major (m = 4 * pooled pixel + dy * 2 + dx)
+template <int POOL>
+__device__ __forceinline__ int row_pixel(const ChainHP& p, int m) {
+    if constexpr (!POOL) return m;
+    const int mp = m >> 2, q = m & 3, wp2 = p.Wo >> 1, hwp = (p.Ho >> 1) * wp2;
+    const int n = mp / hwp, rem = mp - n * hwp, hp = rem / wp2;
+    return (n * p.Ho + 2 * hp + (q >> 1)) * p.Wo + 2 * (rem - hp * wp2) + (q & 1);
+}
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t desc(const void* base, long long total, long long shift) {
     long long ext = total - shift;
@@ -58,8 +68,13 @@ constexpr int BM = 128, BNS = 64;
 // DUAL (the first block of layer 1): x' = relu((y2 @ W3^T + ((xp @ Wd^T) * ratio)) * sc3 + b) -- the downsample branch's 64-deep GEMM
 // runs first, its sums are multiplied per output channel by ratio = sc_d / sc3 and conv3 continues on the same accumulators: the
 // order and arithmetic of conv1x1_f16_kernel<.., TWO = 1> (dbmm_conv1x1_dual_stream_f16), so again bit-equal to the two launches.
-template <int K, int P, int DUAL = 0>
+// POOL (a stage seam): the tile's rows walk the pixels in 2x2-window-major order, so the four registers (r & 3) of an accumulator group are
+// one pooling window and AvgPool2d(2) of x' -- the next stage's downsample input -- is a sum inside the lane (fp32 sum of the ROUNDED fp16
+// values in (dy, dx) order, times 0.25: avgpool2_f16_kernel's arithmetic, bit-equal).  POOL = 2: only the pooled copy is written; conv1' has
+// consumed the un-pooled x' here and nobody else reads it.  M % 4 == 0, Ho and Wo even.
+template <int K, int P, int DUAL = 0, int POOL = 0>
 __global__ __launch_bounds__(256, 2) void chain_f16_kernel(const ChainHP p) {
+    static_assert(!(DUAL && POOL), "a stage's first block is not its last");
     static_assert(K == 64 || K == 128, "conv3 reduction depth: 64 (layer 1) or 128 (layer 2)");
     static_assert(P == 64 || P == 128, "conv1' width");
     constexpr int KS = K / 16, TN1 = P / 32;
@@ -74,15 +89,27 @@ __global__ __launch_bounds__(256, 2) void chain_f16_kernel(const ChainHP p) {
     const int m0 = xcd_remap(blockIdx.x, gridDim.x) * BM;
     const int NT = p.N / BNS;
     const long long Mll = p.M;
-    const __amdgpu_buffer_rsrc_t rsA = desc(p.a, Mll * K * 2, (long long)m0 * K * 2);
-    const __amdgpu_buffer_rsrc_t rsR = DUAL ? desc(p.a2, Mll * 64 * 2, (long long)m0 * 64 * 2) : desc(p.res, Mll * p.N * 2, (long long)m0 * p.N * 2);
-    const __amdgpu_buffer_rsrc_t rsX = desc(p.x, Mll * p.N * 2, (long long)m0 * p.N * 2);
-    const __amdgpu_buffer_rsrc_t rsY = desc(p.y1, Mll * P * 2, (long long)m0 * P * 2);
+    const int g0 = row_pixel<POOL>(p, m0);                                              // descriptors rebased to the tile's first pixel
+    const __amdgpu_buffer_rsrc_t rsA = desc(p.a, Mll * K * 2, (long long)g0 * K * 2);
+    const __amdgpu_buffer_rsrc_t rsR = DUAL ? desc(p.a2, Mll * 64 * 2, (long long)g0 * 64 * 2) : desc(p.res, Mll * p.N * 2, (long long)g0 * p.N * 2);
+    const __amdgpu_buffer_rsrc_t rsX = desc(p.x, POOL == 2 ? 0 : Mll * p.N * 2, (long long)g0 * p.N * 2);
+    const __amdgpu_buffer_rsrc_t rsY = desc(p.y1, Mll * P * 2, (long long)g0 * P * 2);
+    __amdgpu_buffer_rsrc_t rsXP = rsX;
+    if constexpr (POOL) rsXP = desc(p.xp, (Mll >> 2) * p.N * 2, (long long)(m0 >> 2) * p.N * 2);
 
-    // accumulator rows of this lane: u = (r & 3) + 8 (r >> 2) + 4 fh of the wave's 32; valid iff m0 + 32 wave + u < M
+    // accumulator rows of this lane: u = (r & 3) + 8 (r >> 2) + 4 fh of the wave's 32; valid iff m0 + 32 wave + u < M.  The 16 rows are
+    // 4 groups (t = r >> 2) of 4 consecutive tile rows: the group's first pixel goes into the vector offset, the step inside the group
+    // (wave-uniform: q, or (dy Wo + dx) of a 2x2 window) into the scalar offset.
     const int row_lim = p.M - m0 - wave * 32 - 4 * fh;                                  // row u is valid iff (r & 3) + 8 (r >> 2) < row_lim
-    const unsigned vx = (unsigned)((wave * 32 + 4 * fh) * p.N + 2 * fr) * 2u;           // + slab * 128 B; row step in the scalar offset
-    const unsigned vy = (unsigned)((wave * 32 + 4 * fh) * P + 2 * fr) * 2u;
+    unsigned gx[POOL ? 4 : 1], gy[POOL ? 4 : 1];                                        // (standard order: one offset, all steps scalar)
+#pragma unroll
+    for (int t = 0; t < (POOL ? 4 : 1); ++t) {
+        const int dp = row_pixel<POOL>(p, m0 + wave * 32 + 8 * t + 4 * fh) - g0;
+        gx[t] = (unsigned)(dp * p.N + 2 * fr) * 2u;                                     // + slab * 128 B
+        gy[t] = (unsigned)(dp * P + 2 * fr) * 2u;
+    }
+    auto vrow = [&](const unsigned (&g)[POOL ? 4 : 1], int r) { return g[POOL ? (r >> 2) : 0]; };
+    auto srow = [&](int r) { return POOL ? (r >> 1 & 1) * p.Wo + (r & 1) : (r & 3) + 8 * (r >> 2); };     // pixel step of register r's row
 
     // ---- weight slabs through registers: W3 slab [64 n][K], W1 chunk [P][64 k]; 16-B chunks dealt over the 256 threads ----
     constexpr int CPR3 = K / 8, RPP3 = 256 / CPR3, W3LD = BNS * CPR3 / 256;             // chunks per row, rows per pass, loads per thread
@@ -133,7 +160,7 @@ __global__ __launch_bounds__(256, 2) void chain_f16_kernel(const ChainHP p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int u = (r & 3) + 8 * (r >> 2);
-            rv[r] = __builtin_amdgcn_raw_buffer_load_b32(rsR, u < row_lim ? vx + nt * (BNS * 2) : OOR, (unsigned)(u * p.N * 2), 0);
+            rv[r] = __builtin_amdgcn_raw_buffer_load_b32(rsR, u < row_lim ? vrow(gx, r) + nt * (BNS * 2) : OOR, (unsigned)(srow(r) * p.N * 2), 0);
         }
     };
 
@@ -143,11 +170,11 @@ __global__ __launch_bounds__(256, 2) void chain_f16_kernel(const ChainHP p) {
     u32x4 ay[KS], ay2[DUAL ? 4 : 1];
     {
         const int m = m0 + wave * 32 + fr;
-        const unsigned va = m < p.M ? (unsigned)((wave * 32 + fr) * K + 8 * fh) * 2u : OOR;
+        const unsigned va = m < p.M ? (unsigned)((row_pixel<POOL>(p, m) - g0) * K + 8 * fh) * 2u : OOR;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) ay[ks] = __builtin_amdgcn_raw_buffer_load_b128(rsA, va, (unsigned)(ks * 32), 0);
         if (DUAL) {
-            const unsigned va2 = m < p.M ? (unsigned)((wave * 32 + fr) * 64 + 8 * fh) * 2u : OOR;
+            const unsigned va2 = m < p.M ? (unsigned)((row_pixel<POOL>(p, m) - g0) * 64 + 8 * fh) * 2u : OOR;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) ay2[ks] = __builtin_amdgcn_raw_buffer_load_b128(rsR, va2, (unsigned)(ks * 32), 0);
         }
@@ -206,9 +233,25 @@ __global__ __launch_bounds__(256, 2) void chain_f16_kernel(const ChainHP p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int u = (r & 3) + 8 * (r >> 2);
-            __builtin_amdgcn_raw_buffer_store_b32(xv[r], rsX, u < row_lim ? vx + nt * (BNS * 2) : OOR, (unsigned)(u * p.N * 2), 0);
+            if constexpr (POOL != 2)
+                __builtin_amdgcn_raw_buffer_store_b32(xv[r], rsX, u < row_lim ? vrow(gx, r) + nt * (BNS * 2) : OOR, (unsigned)(srow(r) * p.N * 2), 0);
             const int row = u + 4 * fh;
             *(unsigned*)(XS + row * 128 + (((fr >> 2) ^ swz<128>(row)) << 4) + (fr & 3) * 4) = xv[r];
+        }
+        if constexpr (POOL) {
+            // rows 4 i .. 4 i + 3 of the wave are one 2x2 window = registers 4 t .. 4 t + 3 of this lane (i = 2 t + fh)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f16x2 h = __builtin_bit_cast(f16x2, xv[4 * t + q]);
+                    s0 += (float)h[0]; s1 += (float)h[1];
+                }
+                const int mp = wave * 8 + 2 * t + fh;                               // pooled row within the tile
+                __builtin_amdgcn_raw_buffer_store_b32(pack2(s0 * 0.25f, s1 * 0.25f), rsXP,
+                                                      8 * t < row_lim ? (unsigned)(mp * p.N + 2 * fr) * 2u + nt * (BNS * 2) : OOR, 0, 0);
+            }
         }
         // ---- conv1': the slab is its K chunk [64 nt, 64 nt + 64) ----
 #pragma unroll
@@ -234,7 +277,7 @@ __global__ __launch_bounds__(256, 2) void chain_f16_kernel(const ChainHP p) {
         for (int r = 0; r < 16; ++r) {
             const int u = (r & 3) + 8 * (r >> 2);
             const float v0 = fmaxf(fmaf(acc1[2 * h][r], s0, c0), 0.f), v1 = fmaxf(fmaf(acc1[2 * h + 1][r], s1, c1), 0.f);
-            __builtin_amdgcn_raw_buffer_store_b32(pack2(v0, v1), rsY, u < row_lim ? vy + h * 128 : OOR, (unsigned)(u * P * 2), 0);
+            __builtin_amdgcn_raw_buffer_store_b32(pack2(v0, v1), rsY, u < row_lim ? vrow(gy, r) + h * 128 : OOR, (unsigned)(srow(r) * P * 2), 0);
         }
     }
 }
@@ -242,28 +285,39 @@ __global__ __launch_bounds__(256, 2) void chain_f16_kernel(const ChainHP p) {
 }  // namespace
 
 static int chain_launch(const void* y2, const void* w3, const float* scale3, const float* bias3, const void* residual, const void* downsample_in,
-                        const void* wd, const float* ratio, void* x_out, const void* w1, const float* scale1, const float* bias1, void* y1_out,
-                        int64_t M, int64_t K, int64_t K2, int64_t N, int64_t P, void* stream) {
+                        const void* wd, const float* ratio, void* x_out, void* x_pooled, int64_t Ho, int64_t Wo, const void* w1, const float* scale1,
+                        const float* bias1, void* y1_out, int64_t M, int64_t K, int64_t K2, int64_t N, int64_t P, void* stream) {
     const void* second = downsample_in ? downsample_in : residual;
-    if (!y2 || !w3 || !second || !x_out || !w1 || !y1_out || (downsample_in && (!wd || !ratio))) return DBMM_E_ARG;
+    if (!y2 || !w3 || !second || (!x_out && !x_pooled) || !w1 || !y1_out || (downsample_in && (!wd || !ratio))) return DBMM_E_ARG;
     if (M <= 0 || N <= 0 || M > INT32_MAX - 1024) return DBMM_E_SHAPE;
     if (!(K == 64 || K == 128) || !(P == 64 || P == 128) || (N % 64) || N < 64) return DBMM_E_UNSUPPORTED;
-    if (downsample_in && (K != 64 || P != 64 || K2 != 64)) return DBMM_E_UNSUPPORTED;
-    if (!dbmm_aligned16(y2) || !dbmm_aligned16(w3) || !dbmm_aligned16(second) || !dbmm_aligned16(x_out) || !dbmm_aligned16(w1) || !dbmm_aligned16(y1_out) ||
-        (wd && !dbmm_aligned16(wd)))
+    if (downsample_in && (K != 64 || P != 64 || K2 != 64 || x_pooled)) return DBMM_E_UNSUPPORTED;
+    if (x_pooled && ((Ho & 1) || (Wo & 1) || (M & 3) || M > (INT32_MAX >> 1))) return DBMM_E_UNSUPPORTED;
+    if (!dbmm_aligned16(y2) || !dbmm_aligned16(w3) || !dbmm_aligned16(second) || (x_out && !dbmm_aligned16(x_out)) || !dbmm_aligned16(w1) ||
+        !dbmm_aligned16(y1_out) || (wd && !dbmm_aligned16(wd)) || (x_pooled && !dbmm_aligned16(x_pooled)))
         return DBMM_E_ALIGN;
-    if (128LL * N * 2 >= EXT_LIM) return DBMM_E_UNSUPPORTED;
+    if ((132LL + (x_pooled ? 2 * Wo : 0)) * N * 2 >= EXT_LIM) return DBMM_E_UNSUPPORTED;      // a tile's pixel span under its rebased descriptors
     ChainHP p{};
     p.a = (const u16*)y2; p.w3 = (const u16*)w3; p.sc3 = scale3; p.b3 = bias3; p.res = (const u16*)residual; p.x = (u16*)x_out;
     p.w1 = (const u16*)w1; p.sc1 = scale1; p.b1 = bias1; p.y1 = (u16*)y1_out; p.M = (int)M; p.N = (int)N;
     p.a2 = (const u16*)downsample_in; p.w2 = (const u16*)wd; p.ratio = ratio;
+    p.xp = (u16*)x_pooled; p.Ho = (int)Ho; p.Wo = (int)Wo;
     const dim3 grid((unsigned)((M + BM - 1) / BM));
     hipStream_t s = (hipStream_t)stream;
-    if (downsample_in) hipLaunchKernelGGL((chain_f16_kernel<64, 64, 1>), grid, dim3(256), 0, s, p);
-    else if (K == 64 && P == 64) hipLaunchKernelGGL((chain_f16_kernel<64, 64>), grid, dim3(256), 0, s, p);
-    else if (K == 64 && P == 128) hipLaunchKernelGGL((chain_f16_kernel<64, 128>), grid, dim3(256), 0, s, p);
-    else if (K == 128 && P == 64) hipLaunchKernelGGL((chain_f16_kernel<128, 64>), grid, dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((chain_f16_kernel<128, 128>), grid, dim3(256), 0, s, p);
+#define CHAIN_LAUNCH(KK, PP, DD, PL) hipLaunchKernelGGL((chain_f16_kernel<KK, PP, DD, PL>), grid, dim3(256), 0, s, p)
+#define CHAIN_SHAPES(PL)                                   \
+    do {                                                   \
+        if (K == 64 && P == 64) CHAIN_LAUNCH(64, 64, 0, PL);        \
+        else if (K == 64 && P == 128) CHAIN_LAUNCH(64, 128, 0, PL); \
+        else if (K == 128 && P == 64) CHAIN_LAUNCH(128, 64, 0, PL); \
+        else CHAIN_LAUNCH(128, 128, 0, PL);                         \
+    } while (0)
+    if (downsample_in) CHAIN_LAUNCH(64, 64, 1, 0);
+    else if (!x_pooled) CHAIN_SHAPES(0);
+    else if (x_out) CHAIN_SHAPES(1);
+    else CHAIN_SHAPES(2);
+#undef CHAIN_SHAPES
+#undef CHAIN_LAUNCH
     DBMM_CHECK_LAUNCH();
     return DBMM_OK;
 }
@@ -272,13 +326,25 @@ static int chain_launch(const void* y2, const void* w3, const float* scale3, con
 extern "C" int dbmm_bottleneck_chain_f16(const void* y2, const void* w3, const float* scale3, const float* bias3, const void* residual, void* x_out,
                                          const void* w1, const float* scale1, const float* bias1, void* y1_out, int64_t M, int64_t K, int64_t N,
                                          int64_t P, void* stream) {
-    return chain_launch(y2, w3, scale3, bias3, residual, nullptr, nullptr, nullptr, x_out, w1, scale1, bias1, y1_out, M, K, 0, N, P, stream);
+    if (!x_out) return DBMM_E_ARG;
+    return chain_launch(y2, w3, scale3, bias3, residual, nullptr, nullptr, nullptr, x_out, nullptr, 0, 0, w1, scale1, bias1, y1_out, M, K, 0, N, P,
+                        stream);
+}
+
+// see include/dbmm.h
+extern "C" int dbmm_bottleneck_chain_pool_f16(const void* y2, const void* w3, const float* scale3, const float* bias3, const void* residual,
+                                              void* x_out, void* x_pooled, const void* w1, const float* scale1, const float* bias1, void* y1_out,
+                                              int64_t B, int64_t Ho, int64_t Wo, int64_t K, int64_t N, int64_t P, void* stream) {
+    if (!x_pooled) return DBMM_E_ARG;
+    if (B <= 0 || Ho <= 0 || Wo <= 0) return DBMM_E_SHAPE;
+    return chain_launch(y2, w3, scale3, bias3, residual, nullptr, nullptr, nullptr, x_out, x_pooled, Ho, Wo, w1, scale1, bias1, y1_out, B * Ho * Wo,
+                        K, 0, N, P, stream);
 }
 
 // see include/dbmm.h
 extern "C" int dbmm_bottleneck_chain_dual_f16(const void* y2, const void* w3, const float* scale3, const void* xp, const void* wd, const float* ratio,
                                               const float* bias, void* x_out, const void* w1, const float* scale1, const float* bias1, void* y1_out,
                                               int64_t M, int64_t K, int64_t K2, int64_t N, int64_t P, void* stream) {
-    if (!xp) return DBMM_E_ARG;
-    return chain_launch(y2, w3, scale3, bias, nullptr, xp, wd, ratio, x_out, w1, scale1, bias1, y1_out, M, K, K2, N, P, stream);
+    if (!xp || !x_out) return DBMM_E_ARG;
+    return chain_launch(y2, w3, scale3, bias, nullptr, xp, wd, ratio, x_out, nullptr, 0, 0, w1, scale1, bias1, y1_out, M, K, K2, N, P, stream);
 }

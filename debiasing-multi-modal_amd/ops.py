@@ -102,6 +102,10 @@ class _Timed:
             self.e0.record()
 
     def __exit__(self, *exc):
+        if _TRACE_LAUNCHES:
+            torch.cuda.synchronize()
+            with open(_TRACE_LAUNCHES, "a") as f:
+                f.write("ok\n")
         if self.on and _prof is not None and exc[0] is None:
             M, N, K, amode, wmode = self.args
             e1 = torch.cuda.Event(enable_timing=True)
@@ -339,11 +343,11 @@ def gemm_dual(a, a_absmax, w_plane, w_exp, out_scale, a2, a2_absmax, w2_plane, r
     return c
 
 
-def bottleneck_chain(y2, y2_absmax, c3, residual, c1, x_absmax=None, y1_absmax=None, pooled=False):
+def bottleneck_chain(y2, y2_absmax, c3, residual, c1, x_absmax=None, y1_absmax=None, pooled=False, keep_full=True):
     """x' = relu(bn3(conv3(y2)) + residual); y1' = relu(bn1'(conv1'(x'))) in ONE launch (dbmm_bottleneck_chain_x2);
     c3 / c1 = plan entries of the two 1x1 convs (single exact fp16 plane `ph`, `we`, `sc`, `b`).  y2 NHWC [B,H,W,K].
-    Returns (x', y1') or (x', x'_pooled, y1') with pooled=True; None when the library has no kernel for the shape
-    (the caller then runs the two convs)."""
+    Returns (x', y1') or (x', x'_pooled, y1') with pooled=True -- x' is None with keep_full=False (pooled only: the un-pooled
+    tensor is not written); None when the library has no kernel for the shape (the caller then runs the two convs)."""
     require_cuda(y2, residual)
     _f32c(y2); _f32c(residual)
     B, H, W, K = y2.shape
@@ -356,14 +360,15 @@ def bottleneck_chain(y2, y2_absmax, c3, residual, c1, x_absmax=None, y1_absmax=N
     if N % 64 or (pooled and (H % 2 or W % 2)):
         return None
     dev = y2.device
-    x = _empty((B, H, W, N), device=dev, dtype=torch.float32)
+    full = keep_full or not pooled
+    x = _empty((B, H, W, N), device=dev, dtype=torch.float32) if full else None
     y1 = _empty((B, H, W, P), device=dev, dtype=torch.float32)
     xp = _empty((B, H // 2, W // 2, N), device=dev, dtype=torch.float32) if pooled else None
     M = B * H * W
     # tagged like an igemm launch for bench.py's per-kernel table: FLOPs of both GEMMs, algorithmic bytes
     global _chain_tag
-    _chain_tag = "bottleneck_chain8_kernel" if chain8 else f"bottleneck_chain_kernel<{K}, {P}, {int(pooled)}, 0>"
-    t = _Timed(M, N, K + P, -1, 0, 4 * (M * K + 2 * M * N + M * P + (M // 4 * N if pooled else 0)) + 2 * (N * K + P * N))
+    _chain_tag = "bottleneck_chain8_kernel" if chain8 else f"bottleneck_chain_kernel<{K}, {P}, {int(pooled) + int(not full)}, 0>"
+    t = _Timed(M, N, K + P, -1, 0, 4 * (M * K + (2 if full else 1) * M * N + M * P + (M // 4 * N if pooled else 0)) + 2 * (N * K + P * N))
     t.__enter__()
     rc = _lib.lib().dbmm_bottleneck_chain_x2(ptr(y2), ptr(y2_absmax), ptr(c3["ph"]), int(c3["we"]), ptr(c3["sc"]), ptr(c3["b"]),
                                             ptr(residual), ptr(x), ptr(xp), ptr(x_absmax), ptr(c1["ph"]), int(c1["we"]),
@@ -859,26 +864,37 @@ def conv1x1_f16(x, w, scale, bias, residual=None, act=ACT_RELU):
     return y
 
 
-def chain_f16(y2, c3, residual, c1):
+def chain_f16(y2, c3, residual, c1, pooled=False, keep_full=True):
     """fp16 mode: x' = relu(conv3(y2) * s3 + b3 + residual) and y1' = relu(conv1'(x') * s1 + b1) in one launch (dbmm_bottleneck_chain_f16);
-    c3 / c1 = (w f16, scale f32, bias f32).  Returns (x', y1') or None when the library has no kernel for the shape."""
+    c3 / c1 = (w f16, scale f32, bias f32).  Returns (x', y1'), or with pooled=True (y2 NHWC [B,H,W,K], a stage seam) (x', AvgPool2d(2) of x',
+    y1') where x' is None with keep_full=False (not written); None when the library has no kernel for the shape."""
     require_cuda(y2, residual)
     _f16c(y2); _f16c(residual)
     (w3, s3, b3), (w1, s1, b1) = c3, c1
     N, K = w3.shape
     P = w1.shape[0]
     M = y2.numel() // K
-    x = _empty(tuple(y2.shape[:-1]) + (N,), device=y2.device, dtype=torch.float16)
+    full = keep_full or not pooled
+    if pooled and (y2.dim() != 4 or y2.shape[1] % 2 or y2.shape[2] % 2):
+        return None
+    x = _empty(tuple(y2.shape[:-1]) + (N,), device=y2.device, dtype=torch.float16) if full else None
     y1 = _empty(tuple(y2.shape[:-1]) + (P,), device=y2.device, dtype=torch.float16)
-    t = _TimedTag(f"chain_f16_kernel<{K}, {P}>", 2.0 * M * N * (K + P), 2 * (M * (K + 2 * N + P) + N * (K + P)))
+    xp = _empty((y2.shape[0], y2.shape[1] // 2, y2.shape[2] // 2, N), device=y2.device, dtype=torch.float16) if pooled else None
+    tag = f"chain_f16_kernel<{K}, {P}, 0, {int(pooled) + int(not full)}>" if pooled else f"chain_f16_kernel<{K}, {P}>"
+    t = _TimedTag(tag, 2.0 * M * N * (K + P), 2 * (M * (K + (2 if full else 1) * N + P) + (M // 4 * N if pooled else 0) + N * (K + P)))
     t.__enter__()
-    rc = _lib.lib().dbmm_bottleneck_chain_f16(ptr(y2), ptr(w3), ptr(s3), ptr(b3), ptr(residual), ptr(x), ptr(w1), ptr(s1), ptr(b1), ptr(y1),
-                                              M, K, N, P, stream())
+    if pooled:
+        B, H, W = y2.shape[:3]
+        rc = _lib.lib().dbmm_bottleneck_chain_pool_f16(ptr(y2), ptr(w3), ptr(s3), ptr(b3), ptr(residual), ptr(x), ptr(xp), ptr(w1), ptr(s1), ptr(b1),
+                                                       ptr(y1), B, H, W, K, N, P, stream())
+    else:
+        rc = _lib.lib().dbmm_bottleneck_chain_f16(ptr(y2), ptr(w3), ptr(s3), ptr(b3), ptr(residual), ptr(x), ptr(w1), ptr(s1), ptr(b1), ptr(y1),
+                                                  M, K, N, P, stream())
     t.__exit__(None if rc == 0 else DbmmUnsupported, None, None)
     if rc == _lib.E_UNSUPPORTED:
         return None
     check(rc, "bottleneck_chain_f16")
-    return x, y1
+    return (x, xp, y1) if pooled else (x, y1)
 
 
 def chain_dual_f16(y2, w3, scale3, xp, wd, ratio, bias, c1):
@@ -971,18 +987,28 @@ def avgpool2_f16(x):
     return y
 
 
+_TRACE_LAUNCHES = os.environ.get("DBMM_TRACE_LAUNCHES")
+
+
 class _TimedTag:
     """profile hook for kernels outside the igemm family: fixed tag, caller-supplied FLOPs and algorithmic bytes"""
     def __init__(self, tag, flops, nbytes):
         self.tag, self.flops, self.nbytes = tag, float(flops), float(nbytes)
 
     def __enter__(self):
+        if _TRACE_LAUNCHES:                 # developer aid (DBMM_TRACE_LAUNCHES=<file>): tag before the launch, "ok" after a device sync
+            with open(_TRACE_LAUNCHES, "a") as f:
+                f.write(self.tag + " ... ")
         self.on = _prof is not None and not _prof_paused and not _prof_conv_only
         if self.on:
             self.e0 = torch.cuda.Event(enable_timing=True)
             self.e0.record()
 
     def __exit__(self, *exc):
+        if _TRACE_LAUNCHES:
+            torch.cuda.synchronize()
+            with open(_TRACE_LAUNCHES, "a") as f:
+                f.write("ok\n")
         if self.on and _prof is not None and exc[0] is None:
             e1 = torch.cuda.Event(enable_timing=True)
             e1.record()

@@ -200,6 +200,8 @@ int dbmm_conv3x3_c32_bn_relu_x2(const float* x, const float* x_absmax, const voi
  *   x_out  = relu((y2 @ w3^T) * scale3 + bias3 + residual)        [B*Ho*Wo][N]
  *   y1_out = relu((x_out @ w1^T) * scale1 + bias1)                [B*Ho*Wo][P]
  *   x_pooled (optional) = AvgPool2d(2) of x_out                   [B*Ho/2*Wo/2][N]  (next stage's downsample input)
+ * With x_pooled given, x_out may be NULL: the un-pooled tensor is then not written at all (at a stage seam its only other reader is
+ * conv1 of the next block, which this launch has already computed).
  * The wide tensor x_out is written once and not read back for conv1.  y2 [B*Ho*Wo][K] fp32 with its device scalar
  * y2_absmax >= max|y2|; w3_plane_f16 [N][K] / w1_plane_f16 [P][N] = the stored (fp16-exact) weights times
  * 2^w3_exp / 2^w1_exp as single fp16 planes; scale / bias = eval-mode BatchNorm per channel.  x_absmax / y1_absmax
@@ -291,6 +293,13 @@ int dbmm_conv1x1_dual_bn_act_f16(const void* y2, const void* w3, const float* sc
 int dbmm_bottleneck_chain_f16(const void* y2, const void* w3, const float* scale3, const float* bias3, const void* residual, void* x_out,
                               const void* w1, const float* scale1, const float* bias1, void* y1_out, int64_t M, int64_t K, int64_t N,
                               int64_t P, void* stream);
+/* the same chain at a stage seam (the block is the LAST of its stage, the next block downsamples): also x_pooled = AvgPool2d(2) of x_out
+ * f16 [B*Ho/2*Wo/2][N], the next stage's downsample input (fp32 sum of the fp16 values in (dy, dx) order, times 0.25: equal to
+ * dbmm_avgpool2_f16 of x_out bit for bit).  x_out may be NULL: the un-pooled tensor is then not written -- conv1 of the next block is
+ * computed here and nothing else reads it.  Ho, Wo even, B*Ho*Wo % 4 == 0. */
+int dbmm_bottleneck_chain_pool_f16(const void* y2, const void* w3, const float* scale3, const float* bias3, const void* residual, void* x_out,
+                                   void* x_pooled, const void* w1, const float* scale1, const float* bias1, void* y1_out, int64_t B, int64_t Ho,
+                                   int64_t Wo, int64_t K, int64_t N, int64_t P, void* stream);
 /* the same chain for the FIRST block of a stage, whose shortcut is the downsample conv instead of a residual (dbmm_conv1x1_dual_bn_act_f16's
  * arguments and arithmetic, then conv1 of the next block): x_out = relu((y2 @ w3^T + (xp @ wd^T) * ratio) * scale3 + bias).
  * K = K2 = P = 64 (layer 1's first block); DBMM_E_UNSUPPORTED (nothing launched) otherwise. */

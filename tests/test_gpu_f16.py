@@ -505,3 +505,37 @@ def test_bottleneck_chain_dual_f16(M, N):
     assert (bx[M * N:] == 7.0).all() and (by[M * P:] == 7.0).all()
     w3b = (torch.randn((N, 128), device=DEV, generator=g) * 0.1).half()
     assert ops.chain_dual_f16(torch.zeros((M, 128), device=DEV, dtype=torch.float16), w3b, s3, xp, wd, ratio, bsum, (w1, s1, b1)) is None
+
+
+@pytest.mark.parametrize("B,H,W,K,N,P", [(3, 56, 56, 64, 256, 128), (5, 6, 10, 64, 192, 64), (1, 2, 2, 64, 64, 64), (9, 28, 28, 128, 512, 128),
+                                         (7, 14, 6, 128, 128, 64)])
+def test_bottleneck_chain_f16_at_a_stage_seam(B, H, W, K, N, P):
+    """fp16 mode, the last block of a stage: the chain launch also writes AvgPool2d(2) of x' for the next stage's downsample branch
+    (clip/model.py:36-38, 52) -- window-major tile rows; x', y1' equal the plain chain launch and the pooled copy equals avgpool2_f16 of x',
+    bit for bit; pooled-only (x' not written) gives the same pooled copy and y1'; ragged tiles, windows wrapping over pooled rows and images,
+    guard zones"""
+    g = torch.Generator(device=DEV); g.manual_seed(B + H + K + N + P)
+    y2 = torch.relu(torch.randn((B, H, W, K), device=DEV, generator=g)).half(); res = torch.relu(torch.randn((B, H, W, N), device=DEV, generator=g) * 2.0).half()
+    w3 = (torch.randn((N, K), device=DEV, generator=g) * K ** -0.5).half(); w1 = (torch.randn((P, N), device=DEV, generator=g) * N ** -0.5).half()
+    s3, b3 = _bn(g, N); s1, b1 = _bn(g, P)
+    x0, y0 = ops.chain_f16(y2, (w3, s3, b3), res, (w1, s1, b1))
+    r = ops.chain_f16(y2, (w3, s3, b3), res, (w1, s1, b1), pooled=True)
+    assert r is not None
+    x, xp, y1 = r
+    assert torch.equal(x, x0) and torch.equal(y1, y0)
+    assert tuple(xp.shape) == (B, H // 2, W // 2, N) and torch.equal(xp, ops.avgpool2_f16(x))
+    ref_p = F.avg_pool2d(x.float().permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1)
+    assert torch.allclose(xp.float(), ref_p, rtol=1e-3, atol=1e-3)
+    x2, xp2, y12 = ops.chain_f16(y2, (w3, s3, b3), res, (w1, s1, b1), pooled=True, keep_full=False)
+    assert x2 is None and torch.equal(xp2, xp) and torch.equal(y12, y1)
+    from dbmm_amd import _lib
+    M = B * H * W
+    bx = torch.full((M * N + 4096,), 7.0, device=DEV, dtype=torch.float16); by = torch.full((M * P + 4096,), 7.0, device=DEV, dtype=torch.float16)
+    bp = torch.full((M // 4 * N + 4096,), 7.0, device=DEV, dtype=torch.float16)
+    rc = _lib.lib().dbmm_bottleneck_chain_pool_f16(y2.data_ptr(), w3.data_ptr(), s3.data_ptr(), b3.data_ptr(), res.data_ptr(), bx.data_ptr(), bp.data_ptr(),
+                                                   w1.data_ptr(), s1.data_ptr(), b1.data_ptr(), by.data_ptr(), B, H, W, K, N, P, _lib.stream())
+    torch.cuda.synchronize()
+    assert rc == 0 and torch.equal(bx[:M * N].view_as(x), x) and torch.equal(by[:M * P].view_as(y1), y1) and torch.equal(bp[:M // 4 * N].view_as(xp), xp)
+    assert (bx[M * N:] == 7.0).all() and (by[M * P:] == 7.0).all() and (bp[M // 4 * N:] == 7.0).all()
+    # odd map sides: no kernel
+    assert ops.chain_f16(y2[:, :H - 1].contiguous(), (w3, s3, b3), res[:, :H - 1].contiguous(), (w1, s1, b1), pooled=True) is None

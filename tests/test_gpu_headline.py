@@ -51,7 +51,7 @@ def test_rn50_bs1024_one_call_rows_vs_golden_and_small_batch(golden):
     assert eg < 5e-5
     # the launches that make the headline number were the ones checked
     tags = set(prof)
-    for want in ("bottleneck_chain_kernel<64, 64, 0, 1, 1>", "bottleneck_chain_kernel<64, 64, 0, 0, 1>", "bottleneck_chain_kernel<64, 128, 1, 0>",
+    for want in ("bottleneck_chain_kernel<64, 64, 0, 1, 1>", "bottleneck_chain_kernel<64, 64, 0, 0, 1>", "bottleneck_chain_kernel<64, 128, 2, 0>",
                  "bottleneck_chain_kernel<128, 128, 0, 0, 1>", "conv3x3_c32_kernel<32, 0>", "conv3x3_c32_kernel<64, 1>"):
         assert want in tags, (want, sorted(tags))
     assert "conv3x3_halo8n_kernel<1>" in tags, sorted(tags)                                                # layer 2's pooled 3x3

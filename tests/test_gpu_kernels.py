@@ -980,6 +980,11 @@ def test_bottleneck_chain_conv3_residual_then_next_conv1(B, H, W, K, N, P, poole
     if pooled:
         ref_p = F.avg_pool2d(x.permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1)
         assert tuple(r[1].shape) == (B, H // 2, W // 2, N) and relerr(r[1].cpu(), ref_p.cpu()) < 2e-6
+        # pooled only (a stage seam: nobody reads the un-pooled tensor): same pooled copy, conv1 output and maxima, bit for bit
+        xam2, yam2 = torch.zeros(1, device=DEV), torch.zeros(1, device=DEV)
+        r2 = ops.bottleneck_chain(y2, ya, c3, res, c1, xam2, yam2, pooled=True, keep_full=False)
+        assert r2 is not None and r2[0] is None and ops._chain_tag == f"bottleneck_chain_kernel<{K}, {P}, 2, 0>"
+        assert torch.equal(r2[1], r[1]) and torch.equal(r2[2], y1) and xam2.item() == xam.item() and yam2.item() == yam.item()
     # the two separate launches
     xu = ops.conv_bn_act(y2, w3, b3, res, 1, 1, 1, 0, ops.ACT_RELU, w_planes_f16=p3, w_exp=e3, x_absmax=ya, out_scale=s3)
     yu = ops.conv_bn_act(xu, w1, b1, None, 1, 1, 1, 0, ops.ACT_RELU, w_planes_f16=p1, w_exp=e1,
