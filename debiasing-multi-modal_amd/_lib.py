@@ -127,6 +127,7 @@ _SIGS = {
     "dbmm_bottleneck_chain_dual_f16": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _L, _L, _L, _L, _P],
     "dbmm_conv3x3_bn_relu_f16": [_P, _P, _P, _P, _P, _L, _L, _L, _L, _L, _I, _P],
     "dbmm_conv_stem_s2_f16": [_P, _I, _P, _P, _P, _L, _L, _L, _L, _P],
+    "dbmm_conv_stem_s2_bn_f16": [_P, _I, _P, _P, _P, _P, _L, _L, _L, _L, _P],
     "dbmm_avgpool2_f16": [_P, _P, _L, _L, _L, _L, _P],
     "dbmm_im2col_patch_f16": [_P, _I, _P, _L, _L, _L, _L, _P],
     "dbmm_vit_tokens_f16": [_P, _P, _P, _P, _L, _L, _L, _P],

@@ -283,7 +283,7 @@ class ModifiedResNet(nn.Module):
     def _compile_f16(self):
         """fp16 mode (clip/model.py:146, 375-396): conv weights as the checkpoint's fp16 values ([Cout][Cin] for 1x1,
         [Cout][(cin/32, kh, kw, 32)] for 3x3), eval-mode BatchNorm as fp32 per-channel scale / bias for the conv epilogues;
-        the 3-channel stem conv keeps BatchNorm folded into fp32 weights (it runs on the vector ALUs)."""
+        the 3-channel stem conv likewise (fp32 container of the fp16 values, [kh][kw][cin][cout]: its MFMA gather kernel packs them)."""
         def bn_sb(bn):
             sc = bn.weight.detach().double() / torch.sqrt(bn.running_var.detach().double() + bn.eps)
             return sc.float().contiguous(), (bn.bias.detach().double() - bn.running_mean.detach().double() * sc).float().contiguous()
@@ -296,8 +296,8 @@ class ModifiedResNet(nn.Module):
             w, _ = ops.pack_conv_weight(conv.weight.detach().float(), chunk_major=32)
             return (w.to(torch.float16).contiguous(),) + bn_sb(bn)
         P = {}
-        w, b = _fold_bn(self.conv1.weight.float(), self.bn1)
-        P["stem1"] = (w.permute(2, 3, 1, 0).contiguous().float(), b.float().contiguous())
+        sc1, b1 = bn_sb(self.bn1)
+        P["stem1"] = (self.conv1.weight.detach().float().permute(2, 3, 1, 0).contiguous(), b1, sc1)      # (w, bias, scale)
         P["stem2"], P["stem3"] = c3x3(self.conv2, self.bn2), c3x3(self.conv3, self.bn3)
         blocks = []
         for li in (1, 2, 3, 4):

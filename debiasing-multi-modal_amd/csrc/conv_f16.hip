@@ -487,13 +487,13 @@ __global__ __launch_bounds__(256, 2) void conv1x1_f16_kernel(const ConvHP p) {
 // reference's `x.type(self.conv1.weight.dtype)` does (clip/model.py:146).
 // ---------------------------------------------------------------------------------------------------------------
 template <int COUT, typename TIN>
-__global__ __launch_bounds__(256) void stem_s2_f16_kernel(const TIN* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
-                                                          u16* __restrict__ y, int B, int H, int W, int Ho, int Wo) {
+__global__ __launch_bounds__(256) void stem_s2_f16_kernel(const TIN* __restrict__ x, const float* __restrict__ w, const float* __restrict__ scale,
+                                                          const float* __restrict__ bias, u16* __restrict__ y, int B, int H, int W, int Ho, int Wo) {
     constexpr int PITCH = COUT + 8;                             // staging row pitch in halves (16-B aligned rows, shifted banks)
-    __shared__ __attribute__((aligned(16))) float sw[28 * COUT];
+    __shared__ __attribute__((aligned(16))) float sw[29 * COUT];
     __shared__ __attribute__((aligned(16))) u16 stage[256 * PITCH];
     for (int i = threadIdx.x; i < 27 * COUT; i += 256) sw[i] = w[i];
-    for (int i = threadIdx.x; i < COUT; i += 256) sw[27 * COUT + i] = bias ? bias[i] : 0.f;
+    for (int i = threadIdx.x; i < COUT; i += 256) { sw[27 * COUT + i] = bias ? bias[i] : 0.f; sw[28 * COUT + i] = scale ? scale[i] : 1.f; }
     __syncthreads();
     const long long m0 = (long long)blockIdx.x * 256, m = m0 + threadIdx.x;
     const long long M = (long long)B * Ho * Wo;
@@ -527,7 +527,7 @@ __global__ __launch_bounds__(256) void stem_s2_f16_kernel(const TIN* __restrict_
             }
             float o[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] = fmaxf(acc[j] + sw[27 * COUT + c0 + j], 0.f);
+            for (int j = 0; j < 8; ++j) o[j] = fmaxf(fmaf(acc[j], sw[28 * COUT + c0 + j], sw[27 * COUT + c0 + j]), 0.f);
             *(u32x4*)(so + c0) = (u32x4){pack2(o[0], o[1]), pack2(o[2], o[3]), pack2(o[4], o[5]), pack2(o[6], o[7])};
         }
     }
@@ -538,6 +538,127 @@ __global__ __launch_bounds__(256) void stem_s2_f16_kernel(const TIN* __restrict_
 #pragma unroll 2
     for (int q = threadIdx.x; q < 256 * QPP; q += 256)
         if (q < run) yo[q] = *(const u32x4*)(stage + (q / QPP) * PITCH + (q % QPP) * 8);
+}
+
+// The same conv as an MFMA gather (resnet_ops.hip's stem_s2_mfma_kernel at one fp16 product): a wave owns blocks of 32 output pixels; lane
+// (pixel fr, K half fh) gathers its 16 of the 32 K slots (27 taps + 5 zeros) straight from the NCHW image through a bounds-checked
+// descriptor, rounds them to fp16 (the reference's cast) and two 32x32x16 MFMAs per 32 channels replace 864 FMAs per pixel; the weights
+// are B fragments held in registers for the whole launch.  The block's 32 x Cout fp16 outputs go through a wave-private LDS tile and
+// leave as one contiguous run of 16-B lane stores.  The next block's taps are in flight during the MFMAs and stores.
+// The weights are rounded to fp16 here -- exact for a model whose conv1 is stored in fp16, which is what fp16 mode means -- so BatchNorm
+// comes as a separate per-channel scale / bias on the fp32 accumulator (dbmm_conv_stem_s2_bn_f16), not folded into the weights.
+// fp32 accumulation inside the MFMA instead of 27 sequential FMAs: another order of summation of the same exact products.
+// Bound: HBM (0.6 MB in as fp32 + 0.8 MB out per image at 224 px).
+template <int NB, typename TIN>                                       // NB = Cout / 32
+__global__ __launch_bounds__(256, 3) void stem_s2_f16_mfma_kernel(const TIN* __restrict__ x, const float* __restrict__ w, const float* __restrict__ scale,
+                                                                  const float* __restrict__ bias, u16* __restrict__ y, int B, int H, int W, int Ho, int Wo,
+                                                                  int n_blocks) {
+    constexpr int Cout = NB * 32, PITCH = Cout + 8, ES = (int)sizeof(TIN);
+    __shared__ __attribute__((aligned(16))) u16 stage_all[4 * 32 * PITCH];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    u16* stage = stage_all + wave * (32 * PITCH);
+    const int fr = lane & 31, fh = lane >> 5;
+    const long long M = (long long)B * Ho * Wo, img = 3LL * H * W;
+    // K slot (fh, t = ks * 8 + i) -> tap: t < 9: (kw, c) = (t / 3, t % 3), kh = fh;  t >= 9: kh = 2, (kw, c) pair t - 9 (fh = 0) or t - 2 (fh = 1: t = 9, 10)
+    auto slot_tap = [](int f, int t, int& kh, int& kw, int& c) -> bool {
+        int pr;
+        if (t < 9) { kh = f; pr = t; }
+        else { kh = 2; pr = f ? t - 2 : t - 9; if (pr > 8) { kh = kw = c = 0; return false; } }
+        kw = pr / 3; c = pr - kw * 3;
+        return true;
+    };
+    unsigned wq[NB][2][4];
+    float bv[NB], sv[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        float wv[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            int kh0, kw0, c0, kh1, kw1, c1;
+            const bool v0 = slot_tap(0, t, kh0, kw0, c0), v1 = slot_tap(1, t, kh1, kw1, c1);
+            const int k = fh ? (kh1 * 3 + kw1) * 3 + c1 : (kh0 * 3 + kw0) * 3 + c0;
+            wv[t] = (fh ? v1 : v0) ? w[k * Cout + j * 32 + fr] : 0.f;
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) wq[j][ks][q] = pack2(wv[ks * 8 + 2 * q], wv[ks * 8 + 2 * q + 1]);
+        bv[j] = bias ? bias[j * 32 + fr] : 0.f;
+        sv[j] = scale ? scale[j * 32 + fr] : 1.f;
+    }
+    const int n_waves = gridDim.x * 4;
+    float xv[16];
+    auto gather = [&](int blk) {
+        const long long mb = (long long)blk * 32, m = mb + fr;
+        const long long img0 = mb / ((long long)Ho * Wo);                 // image of the block's first pixel (descriptor base)
+        const long long left = (long long)B - img0;
+        const long long ext = (left < 2 ? left : 2) * img * ES;           // 32 pixels touch at most two images
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(x + img0 * img), 0, (int)ext, 0x00020000);
+        unsigned base = OOR;
+        int mask = 0;
+        if (m < M) {
+            const int wo = (int)(m % Wo), ho = (int)((m / Wo) % Ho);
+            const int n = (int)(m / ((long long)Wo * Ho) - img0);
+            const int hi0 = 2 * ho - 1, wi0 = 2 * wo - 1;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                if (hi0 + d >= 0 && hi0 + d < H) mask |= 1 << d;
+                if (wi0 + d >= 0 && wi0 + d < W) mask |= 8 << d;
+            }
+            base = (unsigned)((long long)n * img + (long long)hi0 * W + wi0);      // may wrap below zero: only used with valid taps
+        }
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            int kh0, kw0, c0, kh1, kw1, c1;
+            const bool v0 = slot_tap(0, t, kh0, kw0, c0), v1 = slot_tap(1, t, kh1, kw1, c1);
+            const int off0 = (c0 * H + kh0) * W + kw0, off1 = (c1 * H + kh1) * W + kw1;          // uniform
+            const int bit0 = v0 ? (1 << kh0) | (8 << kw0) : 64, bit1 = v1 ? (1 << kh1) | (8 << kw1) : 64;   // bit 6 is never in a mask
+            const int bit = fh ? bit1 : bit0;
+            const bool ok = (mask & bit) == bit;
+            const unsigned off = ok ? (base + (unsigned)(fh ? off1 : off0)) * (unsigned)ES : OOR;
+            if constexpr (ES == 4) xv[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, off, 0, 0));
+            else xv[t] = (float)__builtin_bit_cast(_Float16, __builtin_amdgcn_raw_buffer_load_b16(rs, off, 0, 0));
+        }
+    };
+    int blk = blockIdx.x * 4 + wave;
+    if (blk < n_blocks) gather(blk);
+    for (; blk < n_blocks; blk += n_waves) {
+        unsigned a[2][4];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) a[ks][q] = pack2(xv[ks * 8 + 2 * q], xv[ks * 8 + 2 * q + 1]);     // the image rounded to fp16
+        const long long mb = (long long)blk * 32;
+        if (blk + n_waves < n_blocks) gather(blk + n_waves);          // in flight during the MFMAs and stores
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, (u32x4){a[ks][0], a[ks][1], a[ks][2], a[ks][3]}),
+                                                             __builtin_bit_cast(f16x8, (u32x4){wq[j][ks][0], wq[j][ks][1], wq[j][ks][2], wq[j][ks][3]}), acc, 0, 0, 0);
+            // accumulator register r = pixel row (r & 3) + 8 (r >> 2) + 4 fh, column = channel j * 32 + fr
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * fh;
+                const _Float16 hv = (_Float16)fmaxf(fmaf(acc[r], sv[j], bv[j]), 0.f);
+                stage[row * PITCH + j * 32 + fr] = __builtin_bit_cast(u16, hv);
+            }
+        }
+        // the block's 32 x Cout outputs are one contiguous run: 16-B chunks lane by lane (rows past M are cut by the descriptor)
+        const long long rows_left = M - mb;
+        const long long bytes = (rows_left < 32 ? rows_left : 32) * Cout * 2;
+        const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)(y + mb * Cout), 0, (int)bytes, 0x00020000);
+        constexpr int QPP = Cout / 8;
+#pragma unroll
+        for (int i = 0; i < 32 * QPP / 64; ++i) {
+            const int c = lane + 64 * i;
+            const u32x4 v = *(const u32x4*)(stage + (c / QPP) * PITCH + (c % QPP) * 8);
+            __builtin_amdgcn_raw_buffer_store_b128(v, ry, (unsigned)c * 16u, 0, 0);
+        }
+    }
 }
 
 // AvgPool2d(2) on fp16 NHWC: a thread owns 8 channels of one output pixel
@@ -889,8 +1010,8 @@ int dbmm_conv1x1_dual_stream_f16(const void* y2, const void* w3, const float* sc
     return DBMM_OK;
 }
 
-extern "C" int dbmm_conv_stem_s2_f16(const void* x_nchw, int x_is_f16, const float* w, const float* bias, void* y_nhwc, int64_t B, int64_t H,
-                                     int64_t W, int64_t Cout, void* stream) {
+static int stem_f16_launch(const void* x_nchw, int x_is_f16, const float* w, const float* scale, const float* bias, void* y_nhwc, int64_t B,
+                           int64_t H, int64_t W, int64_t Cout, bool mfma, void* stream) {
     if (!x_nchw || !w || !y_nhwc) return DBMM_E_ARG;
     if (B <= 0 || H <= 0 || W <= 0) return DBMM_E_SHAPE;
     if (Cout != 32 && Cout != 64) return DBMM_E_UNSUPPORTED;
@@ -899,12 +1020,35 @@ extern "C" int dbmm_conv_stem_s2_f16(const void* x_nchw, int x_is_f16, const flo
     const long long M = (long long)B * Ho * Wo;
     const dim3 g((unsigned)((M + 255) / 256));
     hipStream_t s = (hipStream_t)stream;
-#define DBMM_STEMH(C, T) hipLaunchKernelGGL((stem_s2_f16_kernel<C, T>), g, dim3(256), 0, s, (const T*)x_nchw, w, bias, (u16*)y_nhwc, (int)B, (int)H, (int)W, Ho, Wo)
+    if (mfma && 3 * H * W * 8 < 0x7FFFFFF0LL && (M + 31) / 32 <= INT32_MAX) {
+        const int n_blocks = (int)((M + 31) / 32);
+        const int wgs = (n_blocks + 3) / 4 < 256 * 8 ? (n_blocks + 3) / 4 : 256 * 8;
+#define DBMM_STEMM(NB, T) hipLaunchKernelGGL((stem_s2_f16_mfma_kernel<NB, T>), dim3(wgs), dim3(256), 0, s, (const T*)x_nchw, w, scale, bias, (u16*)y_nhwc, (int)B, (int)H, (int)W, Ho, Wo, n_blocks)
+        if (Cout == 32) { if (x_is_f16) DBMM_STEMM(1, _Float16); else DBMM_STEMM(1, float); }
+        else { if (x_is_f16) DBMM_STEMM(2, _Float16); else DBMM_STEMM(2, float); }
+#undef DBMM_STEMM
+        DBMM_CHECK_LAUNCH();
+        return DBMM_OK;
+    }
+#define DBMM_STEMH(C, T) hipLaunchKernelGGL((stem_s2_f16_kernel<C, T>), g, dim3(256), 0, s, (const T*)x_nchw, w, scale, bias, (u16*)y_nhwc, (int)B, (int)H, (int)W, Ho, Wo)
     if (Cout == 32) { if (x_is_f16) DBMM_STEMH(32, _Float16); else DBMM_STEMH(32, float); }
     else { if (x_is_f16) DBMM_STEMH(64, _Float16); else DBMM_STEMH(64, float); }
 #undef DBMM_STEMH
     DBMM_CHECK_LAUNCH();
     return DBMM_OK;
+}
+
+// see include/dbmm.h: fp32 weights (e.g. with BatchNorm folded in) used as they are -- the FMA kernel
+extern "C" int dbmm_conv_stem_s2_f16(const void* x_nchw, int x_is_f16, const float* w, const float* bias, void* y_nhwc, int64_t B, int64_t H,
+                                     int64_t W, int64_t Cout, void* stream) {
+    return stem_f16_launch(x_nchw, x_is_f16, w, nullptr, bias, y_nhwc, B, H, W, Cout, false, stream);
+}
+
+// see include/dbmm.h: fp16-exact weights + BatchNorm scale / bias -- the MFMA gather kernel (option stem_mfma = 0: the FMA kernel)
+extern "C" int dbmm_conv_stem_s2_bn_f16(const void* x_nchw, int x_is_f16, const float* w, const float* scale, const float* bias, void* y_nhwc,
+                                        int64_t B, int64_t H, int64_t W, int64_t Cout, void* stream) {
+    if (!scale) return DBMM_E_ARG;
+    return stem_f16_launch(x_nchw, x_is_f16, w, scale, bias, y_nhwc, B, H, W, Cout, dbmm_opt(OPT_STEM_MFMA) != 0, stream);
 }
 
 extern "C" int dbmm_avgpool2_f16(const void* x, void* y, int64_t B, int64_t H, int64_t W, int64_t C, void* stream) {

@@ -961,8 +961,10 @@ def conv3x3_f16(x, w, scale, bias, pool=1):
     return y
 
 
-def conv_stem_s2_f16(x_nchw, w, bias):
-    """stem conv1 (3x3, stride 2, folded BatchNorm, ReLU): NCHW f32 / f16 image -> f16 NHWC"""
+def conv_stem_s2_f16(x_nchw, w, bias, scale=None):
+    """stem conv1 (3x3, stride 2, BatchNorm, ReLU): NCHW f32 / f16 image -> f16 NHWC.  w fp32 [kh][kw][cin][cout].  Without `scale`: w carries
+    the folded BatchNorm and is used as it is (FMA kernel); with it: w = the model's fp16 conv weights, BatchNorm = scale / bias on the fp32
+    accumulator (dbmm_conv_stem_s2_bn_f16, MFMA gather kernel)."""
     require_cuda(x_nchw, w)
     if x_nchw.dtype not in (torch.float16, torch.float32) or not x_nchw.is_contiguous():
         raise _lib.DbmmError("conv_stem_s2_f16 needs a contiguous float16 / float32 image batch")
@@ -971,9 +973,15 @@ def conv_stem_s2_f16(x_nchw, w, bias):
         raise _lib.DbmmError("stem conv expects 3 input channels")
     Cout = w.shape[-1]
     y = _empty((B, (H - 1) // 2 + 1, (W - 1) // 2 + 1, Cout), device=x_nchw.device, dtype=torch.float16)
-    with _TimedTag("stem_s2_f16_kernel", 2.0 * y.numel() * 27, x_nchw.numel() * x_nchw.element_size() + 2 * y.numel()):
-        check(_lib.lib().dbmm_conv_stem_s2_f16(ptr(x_nchw), int(x_nchw.dtype == torch.float16), ptr(w), ptr(bias), ptr(y), B, H, W, Cout,
-                                               stream()), "conv_stem_s2_f16")
+    mfma = scale is not None and get_option("stem_mfma")
+    with _TimedTag("stem_s2_f16_mfma_kernel" if mfma else "stem_s2_f16_kernel", 2.0 * y.numel() * 27,
+                   x_nchw.numel() * x_nchw.element_size() + 2 * y.numel()):
+        if scale is None:
+            check(_lib.lib().dbmm_conv_stem_s2_f16(ptr(x_nchw), int(x_nchw.dtype == torch.float16), ptr(w), ptr(bias), ptr(y), B, H, W, Cout,
+                                                   stream()), "conv_stem_s2_f16")
+        else:
+            check(_lib.lib().dbmm_conv_stem_s2_bn_f16(ptr(x_nchw), int(x_nchw.dtype == torch.float16), ptr(w), ptr(scale), ptr(bias), ptr(y), B, H, W,
+                                                      Cout, stream()), "conv_stem_s2_bn_f16")
     return y
 
 

@@ -313,6 +313,11 @@ int dbmm_conv3x3_bn_relu_f16(const void* x, const void* w, const float* scale, c
                              int64_t W, int64_t Cin, int64_t Cout, int pool, void* stream);
 int dbmm_conv_stem_s2_f16(const void* x_nchw, int x_is_f16, const float* w, const float* bias, void* y_nhwc, int64_t B, int64_t H,
                           int64_t W, int64_t Cout, void* stream);
+/* the same conv with BatchNorm as a separate per-channel scale / bias: y = relu(conv(fp16(x), fp16(w)) * scale + bias).  w fp32
+ * [kh][kw][cin][cout] holding the model's fp16 conv1 weights (rounded to fp16 here: exact for an fp16-stored model, clip/model.py:146-148
+ * under convert_weights); runs on the MFMA gather kernel (option stem_mfma; 0: the FMA kernel). */
+int dbmm_conv_stem_s2_bn_f16(const void* x_nchw, int x_is_f16, const float* w, const float* scale, const float* bias, void* y_nhwc,
+                             int64_t B, int64_t H, int64_t W, int64_t Cout, void* stream);
 int dbmm_avgpool2_f16(const void* x, void* y, int64_t B, int64_t H, int64_t W, int64_t C, void* stream);
 /* softmax(q k^T / sqrt(64)) v per (image, head), head_dim 64; qkv f16 [B*L][3E] (q | k | v), out f16 [B*L][E]. */
 int dbmm_mha_core_f16(const void* qkv, void* out, int64_t B, int64_t L, int64_t E, int64_t heads, int causal, void* stream);

@@ -278,6 +278,34 @@ def test_stem_and_avgpool_f16(B, R, Cout, half_in):
         assert relerr(p.double().cpu(), F.avg_pool2d(y.double().permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1).cpu()) < 1e-3
 
 
+@pytest.mark.parametrize("B,R,Cout,half_in", [(3, 64, 32, False), (2, 224, 32, True), (5, 38, 64, False), (1, 18, 32, True), (130, 32, 32, False)])
+def test_stem_f16_mfma_gather_kernel(B, R, Cout, half_in, option):
+    """stem conv1 + BatchNorm + ReLU in fp16 mode on the MFMA gather kernel (clip/model.py:146-148 with fp16 weights): against fp64 of the
+    fp16-rounded image x fp16 weights, and against the FMA kernel given the same operands (same exact products, another order of the fp32
+    sums); odd output sides (R = 38, 18), blocks of 32 pixels straddling images, a ragged last block, guard zone behind the output"""
+    g = torch.Generator(device=DEV); g.manual_seed(R + Cout + B)
+    x = torch.randn((B, 3, R, R), device=DEV, generator=g)
+    w = (torch.randn((3, 3, 3, Cout), device=DEV, generator=g) * 0.2).half().float()
+    sc = 0.5 + torch.rand((Cout,), device=DEV, generator=g); b = torch.randn((Cout,), device=DEV, generator=g) * 0.1
+    xin = x.half() if half_in else x
+    y = ops.conv_stem_s2_f16(xin, w, b, sc)
+    ref = F.conv2d(x.half().double(), w.permute(3, 2, 0, 1).double(), None, stride=2, padding=1) * sc.double().view(1, -1, 1, 1) + b.double().view(1, -1, 1, 1)
+    ref = torch.relu(ref).permute(0, 2, 3, 1)
+    assert y.dtype == torch.float16 and tuple(y.shape) == tuple(ref.shape) and relerr(y.double().cpu(), ref.cpu()) < 5e-4
+    assert (y.double() - ref).abs().max().item() <= 2e-3 * max(1.0, ref.abs().max().item())
+    option("stem_mfma", 0)
+    y0 = ops.conv_stem_s2_f16(xin, w, b, sc)
+    assert (y.float() - y0.float()).abs().max().item() <= 2e-3 * max(1.0, y0.float().abs().max().item())     # one fp16 ulp apart at most
+    assert (y != y0).float().mean().item() < 0.02
+    option("stem_mfma", 1)
+    from dbmm_amd import _lib
+    n = y.numel()
+    buf = torch.full((n + 4096,), 7.0, device=DEV, dtype=torch.float16)
+    rc = _lib.lib().dbmm_conv_stem_s2_bn_f16(xin.data_ptr(), int(half_in), w.data_ptr(), sc.data_ptr(), b.data_ptr(), buf.data_ptr(), B, R, R, Cout, _lib.stream())
+    torch.cuda.synchronize()
+    assert rc == 0 and torch.equal(buf[:n].view_as(y), y) and (buf[n:] == 7.0).all()
+
+
 def test_fp16_mode_rn50_vs_reference_fp16_path(golden):
     """the whole RN50 tower in fp16 mode (fp16 NHWC activations, the fp16 conv / GEMM kernels) against the reference's OWN
     fp16 path run on CPU: per-stage samples and the embedding within 3 x the reference's fp16-vs-fp32 distance"""
@@ -306,7 +334,7 @@ def test_fp16_mode_rn50_vs_reference_fp16_path(golden):
     ops.profile_begin()
     model.encode_image(img)
     tags = set(ops.profile_end())
-    assert any(t.startswith("conv3x3_f16_kernel<") for t in tags) and "stem_s2_f16_kernel" in tags, sorted(tags)
+    assert any(t.startswith("conv3x3_f16_kernel<") for t in tags) and "stem_s2_f16_mfma_kernel" in tags, sorted(tags)
 
 
 @pytest.mark.parametrize("B", [1, 3])
