@@ -921,6 +921,163 @@ __global__ __launch_bounds__(512, 1) void conv3x3_f16_8ph_kernel(const ConvHP p)
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The two 32-channel stem convs (conv2 32 -> 32, conv3 32 -> 64 + AvgPool2d(2) on 112 x 112 maps) as in the parity mode's conv3x3_c32_kernel
+// (conv_patch.hip), at one fp16 product: persistent workgroups, the whole weight (N x 288 fp16) in LDS once, a tile = 4 rows x 28 columns of
+// output whose 6 x 30-pixel input patch is fetched ONCE (16-B chunks through registers, the next tile's in flight during this tile's MFMAs)
+// and serves all nine taps by shifted LDS reads.  With K = 288 the generic kernel's tiles are a nine-step loop whose latencies nothing hides
+// (0.55 + 0.67 ms for 1.6 + 1.2 GB at B = 1024).  Outputs: BatchNorm scale / bias, ReLU, (2x2 average: the four registers (r & 3) of a lane
+// are one window) on the fp32 accumulator, rounded to fp16 into an LDS tile, then whole rows as 16-B lane stores.
+// Same products and K order (kh, kw, 32 channels) as conv3x3_f16_kernel.  Bound: HBM.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int C_TR = 4, C_TC = 28, C_PR = 6, C_PC = 30, C_PPX = C_PR * C_PC, C_KTOT = 288, C_WROW = C_KTOT + 8;
+struct C32P {
+    const u16* x; const u16* w; const float* scale; const float* bias; u16* y;
+    int B, H, W, tiles_w, tiles_h, n_tiles;
+};
+
+template <int N, int POOL>
+__global__ __launch_bounds__(256, N == 32 ? 4 : 2) void conv3x3_c32_f16_kernel(const C32P p) {
+    constexpr int TN = N / 32, NLD = (C_PPX * 4 + 255) / 256;      // 3 patch loads (16 B = 8 channels) per thread
+    constexpr int PCL = POOL ? 40 : C_PC, PLN = C_PR * PCL * 32;    // patch row pitch (conv_patch.hip: pooled lanes of a read group stay on distinct rows mod 16)
+    constexpr int SPITCH = N + 8, SROWS = POOL ? 28 : C_TR * C_TC;    // output staging: [pooled window | tile pixel][N]
+    // N = 64: the lane's 36 weight fragments live in REGISTERS for the whole launch (144 of them; two workgroups per CU either way) -- from
+    // LDS three fragment reads fed two MFMAs and the LDS pipe, not the matrix pipe, set the pace.  N = 32: in LDS (four workgroups per CU).
+    constexpr bool WREG = N == 64;
+    constexpr int WL_HALVES = WREG ? 0 : N * C_WROW;
+    __shared__ __attribute__((aligned(16))) u16 lds[WL_HALVES + PLN + SROWS * SPITCH];
+    u16* Wl = lds;                                                 // [N][C_WROW]
+    u16* Pl = lds + WL_HALVES;                                     // [6 x PCL][32]
+    u16* St = Pl + PLN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 31, fh = lane >> 5;
+    u32x4 wreg[WREG ? 18 : 1][TN];
+    if constexpr (WREG) {
+#pragma unroll
+        for (int t = 0; t < 18; ++t)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) wreg[t][j] = *(const u32x4*)(p.w + (size_t)(j * 32 + fr) * C_KTOT + (t >> 1) * 32 + (2 * (t & 1) + fh) * 8);
+    } else {
+        for (int i = tid; i < N * (C_KTOT / 8); i += 256) {
+            const int n = i / (C_KTOT / 8), c = i - n * (C_KTOT / 8);
+            *(u32x4*)(Wl + n * C_WROW + c * 8) = *(const u32x4*)(p.w + (size_t)n * C_KTOT + c * 8);
+        }
+    }
+    float sv[TN], bv[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) { sv[j] = p.scale ? p.scale[j * 32 + fr] : 1.f; bv[j] = p.bias ? p.bias[j * 32 + fr] : 0.f; }
+    // this lane's MFMA row (A operand): tile pixel (dy, c) -> patch row of tap (0, 0); rows >= 112 are padding
+    const int ml = wave * 32 + fr;
+    int a_dy, a_c;
+    bool a_ok;
+    if (POOL) { const int o = ml >> 2, q = ml & 3; a_dy = 2 * (o / 14) + (q >> 1); a_c = 2 * (o % 14) + (q & 1); a_ok = ml < C_TR * C_TC; }
+    else { a_dy = wave; a_c = fr; a_ok = fr < C_TC; }
+    const int a_row0 = a_ok ? a_dy * PCL + a_c : 0;
+    const long long img_bytes = (long long)p.H * p.W * 64;
+    u32x4 pre[NLD];
+    auto tile_coords = [&](int tile, int& b, int& h0, int& w0) {
+        const int tw = tile % p.tiles_w, r = tile / p.tiles_w;
+        b = r / p.tiles_h; h0 = (r - b * p.tiles_h) * C_TR; w0 = tw * C_TC;
+    };
+    auto load_patch = [&](int tile) {
+        int b, h0, w0;
+        tile_coords(tile, b, h0, w0);
+        const __amdgpu_buffer_rsrc_t rs = desc(p.x, (long long)p.B * img_bytes, (long long)b * img_bytes);
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int idx = tid + 256 * k, i = idx >> 2, chunk = idx & 3;
+            const int py = i / C_PC, px = i - py * C_PC, h = h0 - 1 + py, w = w0 - 1 + px;
+            const bool ok = i < C_PPX && h >= 0 && h < p.H && w >= 0 && w < p.W;
+            pre[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? (unsigned)((h * p.W + w) * 64 + chunk * 16) : OOR, 0, 0);
+        }
+    };
+    auto store_patch = [&]() {
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int idx = tid + 256 * k, i = idx >> 2, chunk = idx & 3;
+            if (i < C_PPX) {
+                const int py = i / C_PC, row = py * PCL + (i - py * C_PC);
+                *(u32x4*)(Pl + row * 32 + ((chunk ^ ((row >> 2) & 3)) << 3)) = pre[k];
+            }
+        }
+    };
+    int tile = blockIdx.x;
+    if (tile < p.n_tiles) load_patch(tile);
+    for (; tile < p.n_tiles; tile += gridDim.x) {
+        store_patch();
+        __syncthreads();                                           // patch (and, the first time, the weights) visible; the previous tile's staged outputs are out
+        if (tile + (int)gridDim.x < p.n_tiles) load_patch(tile + gridDim.x);
+        f32x16 acc[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int row = a_row0 + (tap / 3) * PCL + (tap % 3);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const u32x4 af = *(const u32x4*)(Pl + row * 32 + (((2 * ks + fh) ^ ((row >> 2) & 3)) << 3));
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    u32x4 wf;
+                    if constexpr (WREG) wf = wreg[2 * tap + ks][j];
+                    else wf = *(const u32x4*)(Wl + (j * 32 + fr) * C_WROW + tap * 32 + (2 * ks + fh) * 8);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af), __builtin_bit_cast(f16x8, wf), acc[j], 0, 0, 0);
+                }
+            }
+        }
+        // ---- BatchNorm scale / bias, ReLU, (2x2 average) -> fp16 staging tile ----
+        if constexpr (POOL) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {                          // window o = registers 4 t .. 4 t + 3 of this lane
+                const int o = wave * 8 + 2 * t + fh;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    float v[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] = fmaxf(fmaf(acc[j][4 * t + q], sv[j], bv[j]), 0.f);
+                    const _Float16 hv = (_Float16)((((v[0] + v[1]) + v[2]) + v[3]) * 0.25f);
+                    if (o < 28) St[o * SPITCH + j * 32 + fr] = __builtin_bit_cast(u16, hv);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int c = (r & 3) + 8 * (r >> 2) + 4 * fh;     // accumulator row = the wave's tile row, column c
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const _Float16 hv = (_Float16)fmaxf(fmaf(acc[j][r], sv[j], bv[j]), 0.f);
+                    if (c < C_TC) St[(wave * C_TC + c) * SPITCH + j * 32 + fr] = __builtin_bit_cast(u16, hv);
+                }
+            }
+        }
+        __syncthreads();                                           // every wave is done reading this patch; the staged tile is complete
+        // ---- whole output rows as 16-B lane stores ----
+        int b, h0, w0;
+        tile_coords(tile, b, h0, w0);
+        constexpr int QPP = N / 8;                                 // 16-B chunks per pixel
+        if constexpr (POOL) {
+            const int Hp = p.H >> 1, Wp = p.W >> 1;
+            const long long base_px = ((long long)b * Hp + (h0 >> 1)) * Wp + (w0 >> 1);
+            const __amdgpu_buffer_rsrc_t rs = desc(p.y, (long long)p.B * Hp * Wp * N * 2, base_px * N * 2);
+            for (int q = tid; q < 28 * QPP; q += 256) {
+                const int o = q / QPP, ch = q - o * QPP;
+                const u32x4 v = *(const u32x4*)(St + o * SPITCH + ch * 8);
+                __builtin_amdgcn_raw_buffer_store_b128(v, rs, (unsigned)(((o / 14) * Wp + (o % 14)) * (N * 2) + ch * 16), 0, 0);
+            }
+        } else {
+            const long long base_px = ((long long)b * p.H + h0) * p.W + w0;
+            const __amdgpu_buffer_rsrc_t rs = desc(p.y, (long long)p.B * p.H * p.W * N * 2, base_px * N * 2);
+            for (int q = tid; q < 4 * C_TC * QPP; q += 256) {
+                const int pix = q / QPP, ch = q - pix * QPP, dy = pix / C_TC, c = pix - dy * C_TC;
+                const u32x4 v = *(const u32x4*)(St + pix * SPITCH + ch * 8);
+                __builtin_amdgcn_raw_buffer_store_b128(v, rs, (unsigned)((dy * p.W + c) * (N * 2) + ch * 16), 0, 0);
+            }
+        }
+    }
+}
+
 template <int WM, int WN, int TN>
 int launch_conv(ConvHP& p, int pool, hipStream_t s) {
     constexpr int BM = WM * 128, BN = WN * TN * 32;
@@ -951,6 +1108,24 @@ extern "C" int dbmm_conv3x3_bn_relu_f16(const void* x, const void* w, const floa
     p.x_total = M * Cin * 2; p.w_total = wb; p.y_total = (pool ? M / 4 : M) * Cout * 2;
     p.B = (int)B; p.H = (int)H; p.W = (int)W; p.Cin = (int)Cin; p.N = (int)Cout; p.M = (int)M;
     hipStream_t s = (hipStream_t)stream;
+    // the 32-channel stem convs on 4 x 28 output tiles: the persistent patch kernel (option conv_patch)
+    if (dbmm_opt(OPT_CONV_PATCH) && Cin == 32 && (Cout == 32 || Cout == 64) && (H % C_TR) == 0 && (W % C_TC) == 0 && H * W * 64 < EXT_LIM &&
+        B * (H / C_TR) * (W / C_TC) <= INT32_MAX) {
+        C32P q{};
+        q.x = (const u16*)x; q.w = (const u16*)w; q.scale = scale; q.bias = bias; q.y = (u16*)y; q.B = (int)B; q.H = (int)H; q.W = (int)W;
+        q.tiles_w = (int)(W / C_TC); q.tiles_h = (int)(H / C_TR); q.n_tiles = (int)(B * q.tiles_h * q.tiles_w);
+        const int per_cu = Cout == 32 ? 4 : 2;
+        const int grid = q.n_tiles < 256 * per_cu ? q.n_tiles : 256 * per_cu;
+        if (Cout == 32) {
+            if (pool) hipLaunchKernelGGL((conv3x3_c32_f16_kernel<32, 1>), dim3(grid), dim3(256), 0, s, q);
+            else hipLaunchKernelGGL((conv3x3_c32_f16_kernel<32, 0>), dim3(grid), dim3(256), 0, s, q);
+        } else {
+            if (pool) hipLaunchKernelGGL((conv3x3_c32_f16_kernel<64, 1>), dim3(grid), dim3(256), 0, s, q);
+            else hipLaunchKernelGGL((conv3x3_c32_f16_kernel<64, 0>), dim3(grid), dim3(256), 0, s, q);
+        }
+        DBMM_CHECK_LAUNCH();
+        return DBMM_OK;
+    }
     // Cout % 256 == 0 (layers 3 / 4) at a size that fills the chip: the eight-phase 256 x 256 kernel (option f16_conv_8ph)
     if (dbmm_opt(OPT_F16_CONV_8PH) && (Cout % 256) == 0 && M >= 16384) {
         p.tiles_n = (int)(Cout / 256);

@@ -951,6 +951,8 @@ def conv3x3_f16(x, w, scale, bias, pool=1):
     geo = "2, 2, 2" if Cout > 64 else ("4, 1, 2" if Cout > 32 else "4, 1, 1")
     deep = Cout % 256 == 0 and B * H * W >= 16384 and get_option("f16_conv_8ph")     # dbmm_conv3x3_bn_relu_f16's own routing rule
     tag = f"conv3x3_f16_8ph_kernel<{int(pool == 2)}>" if deep else f"conv3x3_f16_kernel<{geo}, {int(pool == 2)}>"
+    if Cin == 32 and Cout in (32, 64) and H % 4 == 0 and W % 28 == 0 and get_option("conv_patch"):      # the stem convs: persistent patch kernel
+        tag = f"conv3x3_c32_f16_kernel<{Cout}, {int(pool == 2)}>"
     t = _TimedTag(tag, 2.0 * B * H * W * Cout * 9 * Cin, 2 * (x.numel() + y.numel() + w.numel()))
     t.__enter__()
     rc = _lib.lib().dbmm_conv3x3_bn_relu_f16(ptr(x), ptr(w), ptr(scale), ptr(bias), ptr(y), B, H, W, Cin, Cout, 2 if pool == 2 else 0, stream())

@@ -240,6 +240,40 @@ def test_conv3x3_f16_eight_phase_kernel(B, H, W, Cin, Cout, pool, option):
     assert rc == 0 and torch.equal(buf[:n_out].view(y.shape), y) and (buf[n_out:] == 7.0).all()
 
 
+@pytest.mark.parametrize("B,H,W,Cout,pool", [(3, 112, 112, 32, 1), (3, 112, 112, 64, 2), (2, 8, 28, 32, 2), (5, 4, 56, 64, 1), (1, 4, 28, 32, 1),
+                                             (40, 20, 84, 64, 2), (300, 12, 28, 32, 1)])
+def test_conv3x3_c32_f16_patch_kernel(B, H, W, Cout, pool, option):
+    """the 32-channel stem convs (clip/model.py:108-116, 141-143: conv2 / conv3 + bn + relu, conv3 followed by AvgPool2d(2)) on the persistent
+    patch kernel: same products and K order as conv3x3_f16_kernel, so the two agree BIT FOR BIT; both against fp64 on the same fp16 values;
+    one tile per image row block ... more tiles than workgroup slots (B = 300: 900 tiles over 1024 slots; B = 40 x 15 = 600), image borders on
+    every side of a tile, guard zone behind the output"""
+    Cin = 32
+    g = torch.Generator(device=DEV); g.manual_seed(B * 131 + H * 7 + W + Cout + pool)
+    x = torch.relu(torch.randn((B, H, W, Cin), device=DEV, generator=g) * 1.5).half()
+    w = (torch.randn((Cout, Cin, 3, 3), device=DEV, generator=g) * (9 * Cin) ** -0.5).half()
+    sc, b = _bn(g, Cout)
+    wp, wl = ops.pack_conv_weight(w.float(), chunk_major=32)
+    wh = wp.half().contiguous()
+    ops.profile_begin()
+    yp = ops.conv3x3_f16(x, wh, sc, b, pool=pool)
+    assert list(ops.profile_end()) == [f"conv3x3_c32_f16_kernel<{Cout}, {int(pool == 2)}>"]
+    option("conv_patch", 0)
+    y = ops.conv3x3_f16(x, wh, sc, b, pool=pool)
+    assert torch.equal(yp, y), ((yp != y).sum().item(), relerr(yp.double().cpu(), y.double().cpu()))
+    ref = torch.relu(F.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), None, padding=1) * sc.double().view(1, -1, 1, 1) + b.double().view(1, -1, 1, 1))
+    if pool == 2:
+        ref = F.avg_pool2d(ref, 2)
+    assert relerr(yp.double().cpu(), ref.permute(0, 2, 3, 1).cpu()) < 1.5e-3
+    option("conv_patch", 1)
+    from dbmm_amd import _lib
+    n_out = y.numel()
+    buf = torch.full((n_out + 4096,), 7.0, device=DEV, dtype=torch.float16)
+    rc = _lib.lib().dbmm_conv3x3_bn_relu_f16(x.data_ptr(), wh.data_ptr(), sc.data_ptr(), b.data_ptr(), buf.data_ptr(), B, H, W, Cin, Cout, 2 if pool == 2 else 0,
+                                             _lib.stream())
+    torch.cuda.synchronize()
+    assert rc == 0 and torch.equal(buf[:n_out].view(y.shape), y) and (buf[n_out:] == 7.0).all()
+
+
 @pytest.mark.parametrize("M,Cin,Cout,res,act", [(56 * 56 * 3, 64, 256, True, 1), (28 * 28 * 5, 512, 128, False, 1), (14 * 14 * 90, 1024, 256, False, 1),
                                                 (14 * 14 * 90 + 12, 256, 1024, True, 1), (7 * 7 * 40, 2048, 512, False, 1), (300, 64, 64, False, 0),
                                                 (17000, 128, 512, True, 1), (256 * 3 + 77, 96, 136, True, 1), (5, 32, 8, False, 1)])
