@@ -225,3 +225,57 @@ def test_attention_and_layernorm_outputs_stay_inside_their_buffers(guarded):
         assert relerr(y32.double().cpu(), ref.cpu()) < 1e-5 and relerr(y16.double().cpu(), F.layer_norm(x.half().double(), (E,), ga.double(), be.double(), 1e-5).cpu()) < 1e-3
     torch.cuda.synchronize()
     guarded.check()
+
+
+def test_fp16_resnet_kernels_on_tensors_over_2gib():
+    """the fp16 ModifiedResNet kernels of round 4 where a tensor passes 2 GiB (fp16 RN50 from B = 1338 at layer 1, from B = 2675 at the
+    stem): every tile rebases its descriptors on a 64-bit base, so the images around byte 2^31 and the last one must match fp64 --
+    chain_f16_kernel (plain, and the seam mode whose pooled copy is written from window-major tiles), conv3x3_c32_f16_kernel,
+    stem_s2_f16_mfma_kernel (clip/model.py:42-55, 108-116, 141-148)."""
+    g = torch.Generator(device=DEV); g.manual_seed(77)
+    bn = lambda n: (0.5 + torch.rand((n,), device=DEV, generator=g), torch.randn((n,), device=DEV, generator=g) * 0.1)
+    # ---- conv3 + residual -> next conv1: the 256-channel layer-1 map, 1,605,632 B per image ----
+    B, H, K, N, P = 1400, 56, 64, 256, 128
+    y2 = torch.relu(torch.randn((B, H, H, K), device=DEV, generator=g)).half()
+    res = torch.relu(torch.randn((B, H, H, N), device=DEV, generator=g, dtype=torch.float16))
+    assert res.numel() * 2 > 2 ** 31
+    w3 = (torch.randn((N, K), device=DEV, generator=g) * K ** -0.5).half(); w1 = (torch.randn((P, N), device=DEV, generator=g) * N ** -0.5).half()
+    (s3, b3), (s1, b1) = bn(N), bn(P)
+    x, y1 = ops.chain_f16(y2, (w3, s3, b3), res, (w1, s1, b1))
+    xs, xp, y1s = ops.chain_f16(y2, (w3, s3, b3), res, (w1, s1, b1), pooled=True)
+    s = 2 ** 31 // (H * H * N * 2)
+    for i in (0, s - 1, s, s + 1, B - 1):
+        xr = torch.relu(y2[i].double().view(-1, K) @ w3.double().t() * s3.double() + b3.double() + res[i].double().view(-1, N))
+        assert torch.allclose(x[i].double().view(-1, N), xr, rtol=2e-3, atol=2e-3), i
+        y1r = torch.relu(x[i].double().view(-1, N) @ w1.double().t() * s1.double() + b1.double())
+        assert torch.allclose(y1[i].double().view(-1, P), y1r, rtol=2e-3, atol=2e-3), i
+        assert torch.equal(xs[i], x[i]) and torch.equal(y1s[i], y1[i]) and torch.equal(xp[i], ops.avgpool2_f16(x[i:i + 1])[0]), i
+    del y2, res, x, y1, xs, xp, y1s
+    # ---- the 32-channel stem convs: 802,816 B per image in, the same out (plain) ----
+    B, R = 2800, 112
+    xin = torch.relu(torch.randn((B, R, R, 32), device=DEV, generator=g, dtype=torch.float16))
+    assert xin.numel() * 2 > 2 ** 31
+    w = (torch.randn((32, 32, 3, 3), device=DEV, generator=g) * 288 ** -0.5).half()
+    wp, _ = ops.pack_conv_weight(w.float(), chunk_major=32)
+    sc, b = bn(32)
+    ops.profile_begin()
+    y = ops.conv3x3_f16(xin, wp.half().contiguous(), sc, b)
+    yp = ops.conv3x3_f16(xin, wp.half().contiguous(), sc, b, pool=2)
+    assert list(ops.profile_end()) == ["conv3x3_c32_f16_kernel<32, 0>", "conv3x3_c32_f16_kernel<32, 1>"]
+    s = 2 ** 31 // (R * R * 32 * 2)
+    for i in (0, s - 1, s, s + 1, B - 1):
+        ref = torch.relu(F.conv2d(xin[i].permute(2, 0, 1)[None].double(), w.double(), None, padding=1) * sc.double().view(1, -1, 1, 1) + b.double().view(1, -1, 1, 1))
+        assert relerr(y[i].double().cpu(), ref[0].permute(1, 2, 0).cpu()) < 1.5e-3, i
+        assert relerr(yp[i].double().cpu(), F.avg_pool2d(ref, 2)[0].permute(1, 2, 0).cpu()) < 1.5e-3, i
+    del xin, y, yp
+    # ---- stem conv1: the fp32 NCHW image batch itself passes 2 GiB (602,112 B per image) ----
+    B, R = 3600, 224
+    img = torch.randn((B, 3, R, R), device=DEV, generator=g)
+    assert img.numel() * 4 > 2 ** 31
+    w = (torch.randn((3, 3, 3, 32), device=DEV, generator=g) * 0.2).half().float()
+    sc, b = bn(32)
+    y = ops.conv_stem_s2_f16(img, w, b, sc)
+    s = 2 ** 31 // (3 * R * R * 4)
+    for i in (0, s - 1, s, s + 1, B - 1):
+        ref = F.conv2d(img[i:i + 1].half().double(), w.permute(3, 2, 0, 1).double(), None, stride=2, padding=1) * sc.double().view(1, -1, 1, 1) + b.double().view(1, -1, 1, 1)
+        assert relerr(y[i].double().cpu(), torch.relu(ref)[0].permute(1, 2, 0).cpu()) < 5e-4, i
