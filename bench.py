@@ -122,7 +122,8 @@ def kernel_products(tag):
         return 3                                                  # activation pair x activation pair
     if tag.startswith("mha_mfma_kernel"):
         return 1
-    if tag.startswith(("igemm_halo_kernel<", "conv3x3_halo8_kernel<", "conv3x3_halo8n_kernel<", "bottleneck_chain_kernel<", "bottleneck_chain8_kernel", "conv3x3_c32_kernel<")):
+    if tag.startswith(("igemm_halo_kernel<", "conv3x3_halo8_kernel<", "conv3x3_halo8n_kernel<", "bottleneck_chain_kernel<", "bottleneck_chain8_kernel", "conv3x3_c32_kernel<",
+                       "conv1x1_res_stream_kernel<")):
         return 2                                                  # fp16 pair x one exact weight plane
     if tag.startswith("igemm_x3_kernel<"):
         a = [v.strip() for v in tag[tag.index("<") + 1:tag.rindex(">")].split(",")]

@@ -34,6 +34,7 @@ KERNEL_SOURCES = (
     ("mha_pair_kernel", ("mha_pair.hip", "common.h")),
     ("gemm_f16", ("f16_ops.hip", "common.h")), ("mha_f16", ("f16_ops.hip", "common.h")), ("layernorm_f16", ("f16_ops.hip", "common.h")),
     ("chain_f16", ("chain_f16.hip", "common.h")),
+    ("conv1x1_res_stream", ("conv1x1_res_stream.hip", "common.h")),
     ("conv3x3_f16", ("conv_f16.hip", "common.h")), ("conv1x1_f16", ("conv_f16.hip", "common.h")), ("stem_s2_f16", ("conv_f16.hip", "common.h")),
     ("avgpool2_f16", ("conv_f16.hip", "common.h")),
     ("stem_s2", ("resnet_ops.hip", "common.h")), ("attnpool", ("resnet_ops.hip", "common.h")),

@@ -18,7 +18,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 enum DbmmOpt {
     OPT_IGEMM_EPI_DIRECT, OPT_IGEMM_FAST, OPT_IGEMM_STREAMK, OPT_IGEMM_X3, OPT_IGEMM_X2, OPT_IGEMM_X2_BK, OPT_IGEMM_BK,
     OPT_IGEMM_HALO, OPT_IGEMM_HALO_POOL, OPT_IGEMM_BN256, OPT_IGEMM_BN256_KXK, OPT_GEMM_8PH, OPT_F16_8PH, OPT_F16_BN256,
-    OPT_STEM_MFMA, OPT_MHA_VALU, OPT_CONV_PATCH, OPT_MHA_X2, OPT_ADAPTER_STEP_FUSED, OPT_CONV1X1_STREAM, OPT_CONV1X1_8PH, OPT_CHAIN8, OPT_CONV1X1_BN256, OPT_TAIL_SPLIT, OPT_HALO8, OPT_DUAL_8PH, OPT_MHA_SHORT, OPT_F16_CONV_8PH, DBMM_OPT_COUNT
+    OPT_STEM_MFMA, OPT_MHA_VALU, OPT_CONV_PATCH, OPT_MHA_X2, OPT_ADAPTER_STEP_FUSED, OPT_CONV1X1_STREAM, OPT_CONV1X1_8PH, OPT_CHAIN8, OPT_CONV1X1_BN256, OPT_TAIL_SPLIT, OPT_HALO8, OPT_DUAL_8PH, OPT_MHA_SHORT, OPT_F16_CONV_8PH, OPT_CONV1X1_RES_STREAM, DBMM_OPT_COUNT
 };
 int dbmm_opt(int id);
 
@@ -50,6 +50,10 @@ static inline int dbmm_cut_slices(int rem, int trips) {
     S = S < 16 ? S : 16;
     return S >= 2 ? S : 0;
 }
+
+// conv1x1_res_stream.hip: y = relu((a @ W^T) * scale + bias + residual), K = 256, N % 32 == 0, M % 4 == 0 (fp16-pair arithmetic)
+int dbmm_conv1x1_res_stream(const float* a, const float* a_absmax, const void* w_plane_f16, int w_exp, const float* scale, const float* bias,
+                            const float* residual, float* y, float* y_absmax, int64_t M, int64_t K, int64_t N, void* stream);
 
 static inline bool dbmm_aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
 

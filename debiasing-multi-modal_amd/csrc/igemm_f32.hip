@@ -1727,6 +1727,17 @@ int conv_impl(const float* x, const float* w, const float* bias, const float* re
     }
     hipStream_t s = (hipStream_t)stream;
     if (KH == 1 && KW == 1 && stride == 1 && pad == 0) {                                           // plain GEMM
+        // conv3 + residual + ReLU with a short reduction into many channels (layer 3: 256 -> 1024): rows owned by one workgroup for a range
+        // of 32-channel slabs, A fragments in registers, residual two slabs ahead (conv1x1_res_stream.hip)
+        if (dbmm_opt(OPT_CONV1X1_RES_STREAM) && residual && act == DBMM_ACT_RELU && p.wh && p.nw == 1 && p.a_absmax && !p.pool2 && sx.oscale &&
+            Cin == 256 && Cout >= 4 * Cin && M >= 131072 && p.wh_bytes) {        // (level with the tile kernel below that size and for K = 128)
+            const int rc = dbmm_conv1x1_res_stream(x, sx.a_absmax, p.wh, p.w_exp, sx.oscale, bias, residual, y, sx.absmax_out, M, Cin, Cout, stream);
+            if (rc == DBMM_OK) {
+                const int cfg[11] = {(int)Cin, 32, 4, 1, 0, 0, 32, 2, 9, 0, 1};       // [8] = 9: conv1x1_res_stream_kernel<K>
+                for (int i = 0; i < 11; ++i) g_last_cfg[i] = cfg[i];
+            }
+            if (rc != DBMM_E_UNSUPPORTED) return rc;
+        }
         // (the 128 x 256 tile of gemm_impl was measured here too, on RN50 layers 3-4 at B = 1024: neutral, not kept)
         // Also measured and not kept (round 3, profiles/r03_pair_stream_ab_layers.log): an LDS-DMA streaming variant (fp32 A tile by
         // DMA into a 3-slot ring, split into (hi, lo) when the fragments are read): 7 - 34 % SLOWER on every layer-2/3/4 shape

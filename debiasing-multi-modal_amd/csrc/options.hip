@@ -47,6 +47,7 @@ const OptDef kOpts[DBMM_OPT_COUNT] = {
     {"dual_8ph", 1},           // conv3 + downsample dual-source GEMM on gemm_pair_8ph_kernel: 0 never / 1 where it measured ahead / 2 wherever it applies
     {"mha_short", 1},          // attention cores: sequences of at most 64 tokens on two-wave workgroups (0: the four-wave ones, half of them idle)
     {"f16_conv_8ph", 1},       // fp16 mode 3x3 convs with Cout % 256 == 0 on conv3x3_f16_8ph_kernel (0: conv3x3_f16_kernel)
+    {"conv1x1_res_stream", 1}, // conv3 + residual with K = 256 and >= 131,072 rows on conv1x1_res_stream_kernel (0: the 128 x 128 tiles)
 };
 
 std::atomic<int> g_val[DBMM_OPT_COUNT];

@@ -1146,3 +1146,45 @@ def test_bottleneck_block_chain_conv2_conv3_next_conv1(B, H, W, K, N, P, dual):
         xu = ops.conv_bn_act(y2, w3, b3, res, 1, 1, 1, 0, ops.ACT_RELU, w_planes_f16=p3, w_exp=e3, x_absmax=y2.abs().max().reshape(1), out_scale=s3)
         assert relerr(x.cpu(), xu.cpu()) < 3e-6
 
+
+
+@pytest.mark.parametrize("B,H,W,K,N", [(1024, 14, 14, 256, 1024), (671, 14, 14, 256, 1024), (700, 14, 14, 256, 1056), (170, 28, 28, 256, 1024)])
+def test_conv1x1_res_stream_kernel(B, H, W, K, N, option):
+    """conv3 + BatchNorm + residual + ReLU with a short reduction into many channels (clip/model.py:50-54; layer 3: 256 -> 1024) on
+    conv1x1_res_stream_kernel, through the same C-ABI entry as every conv (dbmm_conv_bn_act_x2, option conv1x1_res_stream): against fp64 and
+    against the 128 x 128-tile kernel it replaces; same output maximum; ragged last tile (B = 671: 131,516 rows), slab counts that do not
+    divide over the workgroups (N = 1056: 33 slabs), guard zones around the output; smaller problems, K = 128 and other epilogues keep the
+    tile kernels"""
+    g = torch.Generator(device=DEV); g.manual_seed(B + K + N)
+    x = torch.relu(torch.randn((B, H, W, K), device=DEV, generator=g))
+    res = torch.relu(torch.randn((B, H, W, N), device=DEV, generator=g) * 2.0)
+    w = (torch.randn((N, K, 1, 1), device=DEV, generator=g) * K ** -0.5).half().float()
+    sc = 0.5 + torch.rand((N,), device=DEV, generator=g); b = torch.randn((N,), device=DEV, generator=g) * 0.1
+    wp, wl = ops.pack_conv_weight(w, chunk_major=32)
+    ph, we, n = ops.split_planes_f16(wp, allow_single=True)
+    assert n == 1
+    xam = (x.abs().max() * 1.2).reshape(1)
+    kw = dict(w_planes_f16=ph, w_exp=we, x_absmax=xam, out_scale=sc)
+    am, am0 = torch.zeros(1, device=DEV), torch.zeros(1, device=DEV)
+    y = ops.conv_bn_act(x, wp, b, res, 1, 1, 1, 0, ops.ACT_RELU, wl, y_absmax=am, **kw)
+    assert ops._last_igemm_tag() == f"conv1x1_res_stream_kernel<{K}>", ops._last_igemm_tag()
+    option("conv1x1_res_stream", 0)
+    y0 = ops.conv_bn_act(x, wp, b, res, 1, 1, 1, 0, ops.ACT_RELU, wl, y_absmax=am0, **kw)
+    assert not ops._last_igemm_tag().startswith("conv1x1_res_stream"), ops._last_igemm_tag()
+    M = B * H * W
+    ref = torch.relu(x.view(M, K).double() @ w.view(N, K).double().t() * sc.double() + b.double() + res.view(M, N).double())
+    assert relerr(y.view(M, N).double().cpu(), ref.cpu()) < 5e-6 and relerr(y.cpu(), y0.cpu()) < 2e-6
+    assert am.item() == y.abs().max().item() and am0.item() == y0.abs().max().item()
+    # no residual / fewer rows keep the tile kernels
+    ops.conv_bn_act(x, wp, b, None, 1, 1, 1, 0, ops.ACT_RELU, wl, **kw)
+    assert not ops._last_igemm_tag().startswith("conv1x1_res_stream")
+    ops.conv_bn_act(x[:100].contiguous(), wp, b, res[:100].contiguous(), 1, 1, 1, 0, ops.ACT_RELU, wl, **kw)
+    assert not ops._last_igemm_tag().startswith("conv1x1_res_stream")
+    option("conv1x1_res_stream", 1)
+    guard = 4096
+    buf = torch.full((M * N + 2 * guard,), 777.0, device=DEV)
+    out = buf[guard:guard + M * N].view(B, H, W, N)
+    rc = ops._conv_x2(x, wp, b, res, out, 1, 1, 1, 0, ops.ACT_RELU, wl, ph, we, xam, None, sc, 0, None)
+    assert rc == 0 and ops._last_igemm_tag().startswith("conv1x1_res_stream"), (rc, ops._last_igemm_tag())
+    torch.cuda.synchronize()
+    assert (buf[:guard] == 777.0).all() and (buf[guard + M * N:] == 777.0).all() and torch.equal(out, y)
