@@ -51,9 +51,10 @@ static inline int dbmm_cut_slices(int rem, int trips) {
     return S >= 2 ? S : 0;
 }
 
-// conv1x1_res_stream.hip: y = relu((a @ W^T) * scale + bias + residual), K = 256, N % 32 == 0, M % 4 == 0 (fp16-pair arithmetic)
+// conv1x1_res_stream.hip: y = relu((a @ W^T) * scale + bias + residual) (+ y_pooled = AvgPool2d(2) of y), K = 256, N % 32 == 0, M % 4 == 0
 int dbmm_conv1x1_res_stream(const float* a, const float* a_absmax, const void* w_plane_f16, int w_exp, const float* scale, const float* bias,
-                            const float* residual, float* y, float* y_absmax, int64_t M, int64_t K, int64_t N, void* stream);
+                            const float* residual, float* y, float* y_pooled, float* y_absmax, int64_t M, int64_t Ho, int64_t Wo, int64_t K,
+                            int64_t N, void* stream);
 
 static inline bool dbmm_aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
 

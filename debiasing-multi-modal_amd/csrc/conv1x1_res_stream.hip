@@ -40,7 +40,17 @@ struct ResStreamP {
     const u16* w; int w_exp; const float* sc; const float* b;
     const float* res; float* y; float* y_absmax;
     int M, N, n_tiles;
+    float* yp; int Ho, Wo;                                 // POOL: AvgPool2d(2) of y [M / 4][N]; M = B * Ho * Wo pixels
 };
+
+// pixel (standard order) of tile row m: identity, or 2x2-window-major (m = 4 * pooled pixel + dy * 2 + dx)
+template <int POOL>
+__device__ __forceinline__ int row_pixel(const ResStreamP& p, int m) {
+    if constexpr (!POOL) return m;
+    const int mp = m >> 2, q = m & 3, wp2 = p.Wo >> 1, hwp = (p.Ho >> 1) * wp2;
+    const int n = mp / hwp, rem = mp - n * hwp, hp = rem / wp2;
+    return (n * p.Ho + 2 * hp + (q >> 1)) * p.Wo + 2 * (rem - hp * wp2) + (q & 1);
+}
 
 __device__ __forceinline__ int scale_exp(float amax) {      // s with amax * 2^s in [2^13, 2^14)
     const unsigned b = __float_as_uint(amax) & 0x7fffffffu;
@@ -71,7 +81,10 @@ __device__ __forceinline__ int swz(int row) { return RH == 64 ? ((row >> 1) & 7)
 
 constexpr int BM = 128, BNS = 32;
 
-template <int K>
+// POOL (the last block of a stage): the tile's rows walk the pixels in 2x2-window-major order, the four registers (r & 3) of an accumulator
+// group are one pooling window, and the launch also writes AvgPool2d(2) of y (summed in (dy, dx) order like avgpool_kernel) for the next
+// stage's downsample branch -- dbmm_conv_bn_act_x2 with pool = 2 and y_full.
+template <int K, int POOL = 0>
 __global__ __launch_bounds__(256, 2) void conv1x1_res_stream_kernel(const ResStreamP p) {
     static_assert(K == 256, "reduction depth (K = 128 compiles and is correct, but measured level with the tile kernel at M = 802,816 and 4 % behind it at 200,704: not instantiated)");
     constexpr int KS = K / 16;
@@ -100,16 +113,21 @@ __global__ __launch_bounds__(256, 2) void conv1x1_res_stream_kernel(const ResStr
         const int nt1 = (long long)(NT - nt0) < u_end - u ? NT : nt0 + (int)(u_end - u);
         u += nt1 - nt0;
         const int m0 = tile * BM;
-        const __amdgpu_buffer_rsrc_t rsA = desc(p.a, Mll * K * 4, (long long)m0 * K * 4);
-        const __amdgpu_buffer_rsrc_t rsR = desc(p.res, Mll * p.N * 4, (long long)m0 * p.N * 4);
-        const __amdgpu_buffer_rsrc_t rsY = desc(p.y, Mll * p.N * 4, (long long)m0 * p.N * 4);
-        // this lane's 16 accumulator rows: 4 groups (t = r >> 2) of 4 consecutive tile rows 8 t + 4 fh + (r & 3); M % 4 == 0
+        const int g0 = row_pixel<POOL>(p, m0);                     // descriptors rebased to the tile's first pixel
+        const __amdgpu_buffer_rsrc_t rsA = desc(p.a, Mll * K * 4, (long long)g0 * K * 4);
+        const __amdgpu_buffer_rsrc_t rsR = desc(p.res, Mll * p.N * 4, (long long)g0 * p.N * 4);
+        const __amdgpu_buffer_rsrc_t rsY = desc(p.y, Mll * p.N * 4, (long long)g0 * p.N * 4);
+        __amdgpu_buffer_rsrc_t rsP = rsY;
+        if constexpr (POOL) rsP = desc(p.yp, (Mll >> 2) * p.N * 4, (long long)(m0 >> 2) * p.N * 4);
+        // this lane's 16 accumulator rows: 4 groups (t = r >> 2) of 4 consecutive tile rows 8 t + 4 fh + (r & 3); M % 4 == 0.  The group's
+        // first pixel goes into the vector offset, the step inside the group (wave-uniform: q, or (dy Wo + dx) of a window) into the scalar one
         unsigned gx[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int row = wave * 32 + 8 * t + 4 * fh;
-            gx[t] = m0 + row < p.M ? (unsigned)row * (unsigned)(p.N * 4) + (unsigned)(fr * 4) : OOR;
+            gx[t] = m0 + row < p.M ? (unsigned)(row_pixel<POOL>(p, m0 + row) - g0) * (unsigned)(p.N * 4) + (unsigned)(fr * 4) : OOR;
         }
+        auto qpix = [&](int q) { return POOL ? (q >> 1) * p.Wo + (q & 1) : q; };
         auto load_w = [&](int nt) {
 #pragma unroll
             for (int j = 0; j < WLD; ++j) w3r[j] = *(const u32x4*)(p.w + (size_t)(nt * BNS + wr + RPP * j) * K + wc * 8);
@@ -126,7 +144,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_res_stream_kernel(const ResStr
             constexpr int S = decltype(slot_c)::value;
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                rr[S][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsR, gx[r >> 2], (unsigned)((nt * BNS) * 4 + (r & 3) * p.N * 4), 0));
+                rr[S][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsR, gx[r >> 2], (unsigned)((nt * BNS) * 4 + qpix(r & 3) * p.N * 4), 0));
         };
         // ---- segment prologue: first weight slab and residual slab in flight; the a tile -> fp16 planes in LDS -> A fragments ----
         load_w(nt0);
@@ -140,7 +158,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_res_stream_kernel(const ResStr
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     const int row = lr + 16 * i;
-                    const unsigned off = m0 + row < p.M ? (unsigned)row * (unsigned)(K * 4) + lc * 16u : OOR;
+                    const unsigned off = m0 + row < p.M ? (unsigned)(row_pixel<POOL>(p, m0 + row) - g0) * (unsigned)(K * 4) + lc * 16u : OOR;
                     q[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, off, (unsigned)(kp * 64 * 4), 0));
                 }
                 __syncthreads();                                  // the previous pass's fragments (the previous segment's last slab) have been read
@@ -185,8 +203,18 @@ __global__ __launch_bounds__(256, 2) void conv1x1_res_stream_kernel(const ResStr
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float v = fmaxf(fmaf(acc[r], sv, bv) + rr[S][r], 0.f);
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsY, gx[r >> 2], (unsigned)((nt * BNS) * 4 + (r & 3) * p.N * 4), 0);
+                acc[r] = v;
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsY, gx[r >> 2], (unsigned)((nt * BNS) * 4 + qpix(r & 3) * p.N * 4), 0);
                 if (gx[r >> 2] != OOR) y_amax = fmaxf(y_amax, v);
+            }
+            if constexpr (POOL) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {                      // window = registers 4 t .. 4 t + 3 of this lane
+                    const float sm = (((acc[4 * t] + acc[4 * t + 1]) + acc[4 * t + 2]) + acc[4 * t + 3]) * 0.25f;
+                    const int mp = wave * 8 + 2 * t + fh;          // pooled row within the tile
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, sm), rsP,
+                                                          gx[t] != OOR ? (unsigned)mp * (unsigned)(p.N * 4) + (unsigned)(fr * 4) : OOR, (unsigned)((nt * BNS) * 4), 0);
+                }
             }
             if (nt + 2 < nt1) load_res(nt + 2, slot_c);            // two slabs ahead, into the slot just consumed
             if (nt + 1 < nt1) store_w(S ^ 1);                      // (that slot's readers left through the previous slab's barrier)
@@ -212,21 +240,27 @@ __global__ __launch_bounds__(256, 2) void conv1x1_res_stream_kernel(const ResStr
 
 }  // namespace
 
-// common.h: conv3 + BatchNorm + residual + ReLU with K = 256; DBMM_E_UNSUPPORTED (nothing launched) for other shapes
+// common.h: conv3 + BatchNorm + residual + ReLU with K = 256 (y_pooled: the rows are pixels of [B][Ho][Wo] maps and AvgPool2d(2) of y is
+// written too); DBMM_E_UNSUPPORTED (nothing launched) for other shapes
 int dbmm_conv1x1_res_stream(const float* a, const float* a_absmax, const void* w_plane_f16, int w_exp, const float* scale, const float* bias,
-                            const float* residual, float* y, float* y_absmax, int64_t M, int64_t K, int64_t N, void* stream) {
+                            const float* residual, float* y, float* y_pooled, float* y_absmax, int64_t M, int64_t Ho, int64_t Wo, int64_t K,
+                            int64_t N, void* stream) {
     if (!a || !a_absmax || !w_plane_f16 || !scale || !residual || !y) return DBMM_E_ARG;
     if (M <= 0 || N <= 0 || M > (INT32_MAX >> 1)) return DBMM_E_SHAPE;
     if (K != 256 || (N % BNS) || (M & 3) || w_exp < -40 || w_exp > 40) return DBMM_E_UNSUPPORTED;
-    if (128LL * N * 4 >= EXT_LIM) return DBMM_E_UNSUPPORTED;
-    if (!dbmm_aligned16(a) || !dbmm_aligned16(w_plane_f16) || !dbmm_aligned16(residual) || !dbmm_aligned16(y)) return DBMM_E_ALIGN;
+    if (y_pooled && (Ho <= 0 || Wo <= 0 || (Ho & 1) || (Wo & 1) || M % (Ho * Wo))) return DBMM_E_UNSUPPORTED;
+    if ((132LL + (y_pooled ? 2 * Wo : 0)) * N * 4 >= EXT_LIM) return DBMM_E_UNSUPPORTED;          // a tile's pixel span under its rebased descriptors
+    if (!dbmm_aligned16(a) || !dbmm_aligned16(w_plane_f16) || !dbmm_aligned16(residual) || !dbmm_aligned16(y) || (y_pooled && !dbmm_aligned16(y_pooled)))
+        return DBMM_E_ALIGN;
     ResStreamP p{};
     p.a = a; p.a_absmax = a_absmax; p.w = (const u16*)w_plane_f16; p.w_exp = w_exp; p.sc = scale; p.b = bias; p.res = residual; p.y = y;
     p.y_absmax = y_absmax; p.M = (int)M; p.N = (int)N; p.n_tiles = (int)((M + BM - 1) / BM);
+    p.yp = y_pooled; p.Ho = (int)Ho; p.Wo = (int)Wo;
     const long long units = (long long)p.n_tiles * (N / BNS);
     const int grid = (int)(units < 512 ? units : 512);              // two workgroups per CU
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL((conv1x1_res_stream_kernel<256>), dim3(grid), dim3(256), 0, s, p);
+    if (y_pooled) hipLaunchKernelGGL((conv1x1_res_stream_kernel<256, 1>), dim3(grid), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((conv1x1_res_stream_kernel<256, 0>), dim3(grid), dim3(256), 0, s, p);
     DBMM_CHECK_LAUNCH();
     return DBMM_OK;
 }

@@ -1729,11 +1729,15 @@ int conv_impl(const float* x, const float* w, const float* bias, const float* re
     if (KH == 1 && KW == 1 && stride == 1 && pad == 0) {                                           // plain GEMM
         // conv3 + residual + ReLU with a short reduction into many channels (layer 3: 256 -> 1024): rows owned by one workgroup for a range
         // of 32-channel slabs, A fragments in registers, residual two slabs ahead (conv1x1_res_stream.hip)
-        if (dbmm_opt(OPT_CONV1X1_RES_STREAM) && residual && act == DBMM_ACT_RELU && p.wh && p.nw == 1 && p.a_absmax && !p.pool2 && sx.oscale &&
-            Cin == 256 && Cout >= 4 * Cin && M >= 131072 && p.wh_bytes) {        // (level with the tile kernel below that size and for K = 128)
-            const int rc = dbmm_conv1x1_res_stream(x, sx.a_absmax, p.wh, p.w_exp, sx.oscale, bias, residual, y, sx.absmax_out, M, Cin, Cout, stream);
+        // (pool = 2 with the un-pooled output kept -- the last block of a stage -- is its window-major variant: y = the pooled tensor there)
+        if (dbmm_opt(OPT_CONV1X1_RES_STREAM) && residual && act == DBMM_ACT_RELU && p.wh && p.nw == 1 && p.a_absmax && (!p.pool2 || p.c_full) &&
+            sx.oscale && Cin == 256 && Cout >= 4 * Cin && M >= 131072 && p.wh_bytes) {   // (level with the tile kernel below that size and for K = 128)
+            const int rc = p.pool2 ? dbmm_conv1x1_res_stream(x, sx.a_absmax, p.wh, p.w_exp, sx.oscale, bias, residual, p.c_full, y, sx.absmax_out, M, Ho,
+                                                             Wo, Cin, Cout, stream)
+                                   : dbmm_conv1x1_res_stream(x, sx.a_absmax, p.wh, p.w_exp, sx.oscale, bias, residual, y, nullptr, sx.absmax_out, M, 0, 0,
+                                                             Cin, Cout, stream);
             if (rc == DBMM_OK) {
-                const int cfg[11] = {(int)Cin, 32, 4, 1, 0, 0, 32, 2, 9, 0, 1};       // [8] = 9: conv1x1_res_stream_kernel<K>
+                const int cfg[11] = {(int)Cin, 32, 4, 1, 0, p.pool2, 32, 2, 9, 0, 1};   // [8] = 9: conv1x1_res_stream_kernel<K, POOL>
                 for (int i = 0; i < 11; ++i) g_last_cfg[i] = cfg[i];
             }
             if (rc != DBMM_E_UNSUPPORTED) return rc;

@@ -76,8 +76,8 @@ def _last_igemm_tag():
         return f"igemm_x3_kernel<{cfg[0]}, {cfg[1]}, {cfg[2]}, {cfg[3]}, 0, {cfg[7]}, {cfg[9]}, 2, 1, 32, 1>"
     if cfg[8] == 8:        # the dual-source GEMM on the deep-pipelined kernel: <ACT, RES, TWO = 1>
         return "gemm_pair_8ph_kernel<dual>"
-    if cfg[8] == 9:        # conv3 + residual, short K into many channels (conv1x1_res_stream.hip): <K>
-        return f"conv1x1_res_stream_kernel<{cfg[0]}>"
+    if cfg[8] == 9:        # conv3 + residual, short K into many channels (conv1x1_res_stream.hip): <K, POOL>
+        return f"conv1x1_res_stream_kernel<{cfg[0]}, {cfg[5]}>"
     if cfg[8] == 6:        # deep-pipelined parity GEMM (gemm_pair_8ph.hip): <ACT, RES> are not reported
         return "gemm_pair_8ph_kernel"
     if cfg[8] == 7:        # eight-phase 3x3 halo kernel (conv3x3_halo8.hip): <POOL, ACT>, ACT not reported

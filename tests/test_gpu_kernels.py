@@ -1167,7 +1167,7 @@ def test_conv1x1_res_stream_kernel(B, H, W, K, N, option):
     kw = dict(w_planes_f16=ph, w_exp=we, x_absmax=xam, out_scale=sc)
     am, am0 = torch.zeros(1, device=DEV), torch.zeros(1, device=DEV)
     y = ops.conv_bn_act(x, wp, b, res, 1, 1, 1, 0, ops.ACT_RELU, wl, y_absmax=am, **kw)
-    assert ops._last_igemm_tag() == f"conv1x1_res_stream_kernel<{K}>", ops._last_igemm_tag()
+    assert ops._last_igemm_tag() == f"conv1x1_res_stream_kernel<{K}, 0>", ops._last_igemm_tag()
     option("conv1x1_res_stream", 0)
     y0 = ops.conv_bn_act(x, wp, b, res, 1, 1, 1, 0, ops.ACT_RELU, wl, y_absmax=am0, **kw)
     assert not ops._last_igemm_tag().startswith("conv1x1_res_stream"), ops._last_igemm_tag()
@@ -1188,3 +1188,42 @@ def test_conv1x1_res_stream_kernel(B, H, W, K, N, option):
     assert rc == 0 and ops._last_igemm_tag().startswith("conv1x1_res_stream"), (rc, ops._last_igemm_tag())
     torch.cuda.synchronize()
     assert (buf[:guard] == 777.0).all() and (buf[guard + M * N:] == 777.0).all() and torch.equal(out, y)
+
+
+@pytest.mark.parametrize("B,H,W,N", [(1024, 14, 14, 1024), (673, 14, 14, 1056), (170, 28, 28, 1024), (46, 54, 58, 1024)])
+def test_conv1x1_res_stream_kernel_pooled(B, H, W, N, option):
+    """the last block of a stage: conv3 + BatchNorm + residual + ReLU writes the un-pooled map AND its AvgPool2d(2) (clip/model.py:36-38,
+    50-54) -- conv1x1_res_stream_kernel<256, 1> walks 2x2-window-major tiles; against fp64, against the 128 x 128-tile kernel's dual-output
+    epilogue, pooled == avg_pool2d of the written map; windows wrapping over pooled rows and images inside a tile (W / 2 = 7, 14, 29), a ragged
+    last tile, guard zones around both outputs"""
+    K = 256
+    g = torch.Generator(device=DEV); g.manual_seed(B + N + W)
+    x = torch.relu(torch.randn((B, H, W, K), device=DEV, generator=g))
+    res = torch.relu(torch.randn((B, H, W, N), device=DEV, generator=g) * 2.0)
+    w = (torch.randn((N, K, 1, 1), device=DEV, generator=g) * K ** -0.5).half().float()
+    sc = 0.5 + torch.rand((N,), device=DEV, generator=g); b = torch.randn((N,), device=DEV, generator=g) * 0.1
+    wp, wl = ops.pack_conv_weight(w, chunk_major=32)
+    ph, we, n = ops.split_planes_f16(wp, allow_single=True)
+    xam = (x.abs().max() * 1.2).reshape(1)
+    kw = dict(w_planes_f16=ph, w_exp=we, x_absmax=xam, out_scale=sc)
+    am, am0 = torch.zeros(1, device=DEV), torch.zeros(1, device=DEV)
+    yp, y = ops.conv_bn_act(x, wp, b, res, 1, 1, 1, 0, ops.ACT_RELU, wl, y_absmax=am, pool=2, keep_full=True, **kw)
+    assert ops._last_igemm_tag() == "conv1x1_res_stream_kernel<256, 1>", ops._last_igemm_tag()
+    option("conv1x1_res_stream", 0)
+    yp0, y0 = ops.conv_bn_act(x, wp, b, res, 1, 1, 1, 0, ops.ACT_RELU, wl, y_absmax=am0, pool=2, keep_full=True, **kw)
+    assert not ops._last_igemm_tag().startswith("conv1x1_res_stream")
+    M = B * H * W
+    ref = torch.relu(x.view(M, K).double() @ w.view(N, K).double().t() * sc.double() + b.double() + res.view(M, N).double()).view(B, H, W, N)
+    assert relerr(y.double().cpu(), ref.cpu()) < 5e-6 and relerr(y.cpu(), y0.cpu()) < 2e-6 and relerr(yp.cpu(), yp0.cpu()) < 2e-6
+    assert tuple(yp.shape) == (B, H // 2, W // 2, N)
+    assert relerr(yp.cpu(), F.avg_pool2d(y.permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1).cpu()) < 2e-6
+    assert am.item() == y.abs().max().item() and am0.item() == y0.abs().max().item()
+    option("conv1x1_res_stream", 1)
+    guard = 4096
+    bf = torch.full((M * N + 2 * guard,), 777.0, device=DEV); bp = torch.full((M // 4 * N + 2 * guard,), 777.0, device=DEV)
+    of, op = bf[guard:guard + M * N].view(B, H, W, N), bp[guard:guard + M // 4 * N].view(B, H // 2, W // 2, N)
+    rc = ops._conv_x2(x, wp, b, res, op, 1, 1, 1, 0, ops.ACT_RELU, wl, ph, we, xam, None, sc, 2, of)
+    assert rc == 0 and ops._last_igemm_tag() == "conv1x1_res_stream_kernel<256, 1>", (rc, ops._last_igemm_tag())
+    torch.cuda.synchronize()
+    assert (bf[:guard] == 777.0).all() and (bf[guard + M * N:] == 777.0).all() and (bp[:guard] == 777.0).all() and (bp[guard + M // 4 * N:] == 777.0).all()
+    assert torch.equal(of, y) and torch.equal(op, yp)
