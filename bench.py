@@ -113,7 +113,7 @@ HBM_PEAK_GBS = 8000.0                  # HBM3E spec, same table (measured copy c
 def kernel_products(tag):
     """16-bit partial products per fp32 product of a kernel name (1 = fp32-input MFMA; 0 = fp16-mode kernel: one fp16
     product per product, priced against the full 2500 TFLOP/s)."""
-    if tag.startswith(("gemm_f16_kernel", "gemm_f16_8ph_kernel", "mha_f16_kernel", "conv3x3_f16_kernel", "conv3x3_f16_8ph_kernel", "conv3x3_c32_f16_kernel", "chain_f16_kernel", "conv1x1_f16_kernel", "stem_s2_f16_kernel", "stem_s2_f16_mfma_kernel",
+    if tag.startswith(("gemm_f16_kernel", "gemm_f16_8ph_kernel", "mha_f16_kernel", "conv3x3_f16_kernel", "conv3x3_f16_8ph_kernel", "conv3x3_c32_f16_kernel", "chain_f16_kernel", "conv1x1_f16_kernel", "conv1x1_res_stream_f16_kernel", "stem_s2_f16_kernel", "stem_s2_f16_mfma_kernel",
                        "avgpool2_f16_kernel")):
         return 0
     if tag.startswith("gemm_pair_8ph_kernel"):

@@ -35,6 +35,7 @@ KERNEL_SOURCES = (
     ("gemm_f16", ("f16_ops.hip", "common.h")), ("mha_f16", ("f16_ops.hip", "common.h")), ("layernorm_f16", ("f16_ops.hip", "common.h")),
     ("chain_f16", ("chain_f16.hip", "common.h")),
     ("conv1x1_res_stream", ("conv1x1_res_stream.hip", "common.h")),
+    ("conv1x1_res_stream_f16", ("conv1x1_res_stream_f16.hip", "common.h")),
     ("conv3x3_f16", ("conv_f16.hip", "common.h")), ("conv1x1_f16", ("conv_f16.hip", "common.h")), ("stem_s2_f16", ("conv_f16.hip", "common.h")),
     ("avgpool2_f16", ("conv_f16.hip", "common.h")),
     ("stem_s2", ("resnet_ops.hip", "common.h")), ("attnpool", ("resnet_ops.hip", "common.h")),
@@ -128,6 +129,7 @@ _SIGS = {
     "dbmm_bottleneck_chain_dual_f16": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _L, _L, _L, _L, _P],
     "dbmm_conv3x3_bn_relu_f16": [_P, _P, _P, _P, _P, _L, _L, _L, _L, _L, _I, _P],
     "dbmm_conv_stem_s2_f16": [_P, _I, _P, _P, _P, _L, _L, _L, _L, _P],
+    "dbmm_conv1x1_res_pool_f16": [_P, _P, _P, _P, _P, _P, _P, _L, _L, _L, _L, _L, _P],
     "dbmm_conv_stem_s2_bn_f16": [_P, _I, _P, _P, _P, _P, _L, _L, _L, _L, _P],
     "dbmm_avgpool2_f16": [_P, _P, _L, _L, _L, _L, _P],
     "dbmm_im2col_patch_f16": [_P, _I, _P, _L, _L, _L, _L, _P],

@@ -372,6 +372,11 @@ class ModifiedResNet(nn.Module):
                         x = fused
                         continue
                     identity = ops.conv1x1_f16(identity, *e["ds"], act=ops.ACT_NONE)
+                if bi < len(P["blocks"]) and "ds" in P["blocks"][bi] and P["blocks"][bi]["stride"] == 2 and _opt["seam_pool"] > 0:
+                    r = ops.conv1x1_res_pool_f16(out, e["c3"], identity)         # a seam without a chain kernel (layer 3 -> 4): the same launch
+                    if r is not None:                                           # also writes AvgPool2d(2) of x for the downsample branch
+                        x, x_pooled = r
+                        continue
                 x = ops.conv1x1_f16(out, *e["c3"], residual=identity)   # bn3(conv3) + identity, ReLU
             stages[f"layer{li}"] = x
         a = P["attn"]

@@ -56,6 +56,10 @@ int dbmm_conv1x1_res_stream(const float* a, const float* a_absmax, const void* w
                             const float* residual, float* y, float* y_pooled, float* y_absmax, int64_t M, int64_t Ho, int64_t Wo, int64_t K,
                             int64_t N, void* stream);
 
+// conv1x1_res_stream_f16.hip: the fp16 twin (K = 256, Cout % 64 == 0; y_pooled: also AvgPool2d(2) of y, rows = pixels of [B][Ho][Wo] maps)
+int dbmm_conv1x1_res_stream_f16(const void* x, const void* w, const float* scale, const float* bias, const void* residual, void* y, void* y_pooled,
+                                int64_t M, int64_t Ho, int64_t Wo, int64_t Cin, int64_t Cout, void* stream);
+
 static inline bool dbmm_aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
 
 // wave64 butterfly sum / max (all lanes get the result)

@@ -1019,6 +1019,12 @@ extern "C" int dbmm_conv1x1_bn_act_f16(const void* x, const void* w, const float
 // see include/dbmm.h: dbmm_conv1x1_bn_act_f16 with a workspace
 extern "C" int dbmm_conv1x1_bn_act_f16_ws(const void* x, const void* w, const float* scale, const float* bias, const void* residual, void* y,
                                           int64_t M, int64_t Cin, int64_t Cout, int act, void* workspace, size_t workspace_bytes, void* stream) {
+    // conv3 + residual + ReLU with K = 256 into >= 1024 channels (layer 3): rows owned by one workgroup for a range of 64-channel slabs
+    // (conv1x1_res_stream_f16.hip; same arithmetic bit for bit)
+    if (dbmm_opt(OPT_CONV1X1_RES_STREAM) && residual && act == DBMM_ACT_RELU && Cin == 256 && Cout >= 1024 && M >= 131072) {
+        const int rc = dbmm_conv1x1_res_stream_f16(x, w, scale, bias, residual, y, nullptr, M, 0, 0, Cin, Cout, stream);
+        if (rc != DBMM_E_UNSUPPORTED) return rc;
+    }
     const int mode = dbmm_opt(OPT_CONV1X1_STREAM);
     const bool gemm8 = (Cout % 256) == 0 && (Cin % 128) == 0 && M >= 16384 && !(residual && Cin <= 256 && mode != 3);
     if ((mode == 2 || ((mode == 1 || mode == 3) && !gemm8)) && (act == DBMM_ACT_NONE || act == DBMM_ACT_RELU) && (Cin % 32) == 0) {

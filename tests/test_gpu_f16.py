@@ -601,3 +601,46 @@ def test_bottleneck_chain_f16_at_a_stage_seam(B, H, W, K, N, P):
     assert (bx[M * N:] == 7.0).all() and (by[M * P:] == 7.0).all() and (bp[M // 4 * N:] == 7.0).all()
     # odd map sides: no kernel
     assert ops.chain_f16(y2[:, :H - 1].contiguous(), (w3, s3, b3), res[:, :H - 1].contiguous(), (w1, s1, b1), pooled=True) is None
+
+
+@pytest.mark.parametrize("B,H,W,N", [(1024, 14, 14, 1024), (673, 14, 14, 1088), (170, 28, 28, 1024), (46, 54, 58, 1024)])
+def test_conv1x1_res_stream_f16_kernel(B, H, W, N, option):
+    """fp16 mode: conv3 + BatchNorm + residual + ReLU with K = 256 into >= 1024 channels (clip/model.py:50-54, layer 3) on the row-owning
+    streaming kernel, through dbmm_conv1x1_bn_act_f16: BIT-EQUAL to conv1x1_f16_kernel (option conv1x1_res_stream = 0), against fp64; the
+    stage's last block (dbmm_conv1x1_res_pool_f16): same y, pooled copy == avgpool2_f16 of y bit for bit; a ragged last tile (B = 673), a
+    slab count that does not divide over the workgroups (N = 1088: 17 slabs), windows wrapping over pooled rows and images, guard zones"""
+    K = 256
+    g = torch.Generator(device=DEV); g.manual_seed(B + N + W)
+    x = torch.relu(torch.randn((B, H, W, K), device=DEV, generator=g)).half()
+    res = torch.relu(torch.randn((B, H, W, N), device=DEV, generator=g, dtype=torch.float16) * 2.0)
+    w = (torch.randn((N, K), device=DEV, generator=g) * K ** -0.5).half()
+    sc, b = _bn(g, N)
+    ops.profile_begin()
+    y = ops.conv1x1_f16(x, w, sc, b, residual=res)
+    assert list(ops.profile_end()) == ["conv1x1_res_stream_f16_kernel<0>"]
+    r = ops.conv1x1_res_pool_f16(x, (w, sc, b), res)
+    assert r is not None
+    y2, yp = r
+    option("conv1x1_res_stream", 0)
+    ops.profile_begin()
+    y0 = ops.conv1x1_f16(x, w, sc, b, residual=res)
+    assert not any(t.startswith("conv1x1_res_stream") for t in ops.profile_end())
+    assert ops.conv1x1_res_pool_f16(x, (w, sc, b), res) is None
+    option("conv1x1_res_stream", 1)
+    assert torch.equal(y, y0), (y != y0).sum().item()
+    assert torch.equal(y2, y) and torch.equal(yp, ops.avgpool2_f16(y))
+    M = B * H * W
+    rows = torch.cat([torch.arange(0, 300, device=DEV), torch.randint(0, M, (1500,), device=DEV, generator=g), torch.arange(M - 300, M, device=DEV)])
+    ref = torch.relu(x.view(M, K)[rows].double() @ w.double().t() * sc.double() + b.double() + res.view(M, N)[rows].double())
+    assert torch.allclose(y.view(M, N)[rows].double(), ref, rtol=2e-3, atol=2e-3)
+    from dbmm_amd import _lib
+    bf = torch.full((M * N + 4096,), 7.0, device=DEV, dtype=torch.float16); bp = torch.full((M // 4 * N + 4096,), 7.0, device=DEV, dtype=torch.float16)
+    rc = _lib.lib().dbmm_conv1x1_res_pool_f16(x.data_ptr(), w.data_ptr(), sc.data_ptr(), b.data_ptr(), res.data_ptr(), bf.data_ptr(), bp.data_ptr(),
+                                              B, H, W, K, N, _lib.stream())
+    torch.cuda.synchronize()
+    assert rc == 0 and torch.equal(bf[:M * N].view_as(y), y) and torch.equal(bp[:M // 4 * N].view_as(yp), yp)
+    assert (bf[M * N:] == 7.0).all() and (bp[M // 4 * N:] == 7.0).all()
+    # smaller problems / other depths keep the other kernels
+    ops.profile_begin()
+    ops.conv1x1_f16(x[:40].contiguous(), w, sc, b, residual=res[:40].contiguous())
+    assert not any(t.startswith("conv1x1_res_stream") for t in ops.profile_end())
