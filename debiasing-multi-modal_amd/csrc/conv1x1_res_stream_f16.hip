@@ -1,7 +1,7 @@
 // fp16 mode: conv3 + BatchNorm + residual + ReLU of a bottleneck block (clip/model.py:50-54) for K = 256 into many channels (layer 3:
-// 256 -> 1024), the fp16 twin of conv1x1_res_stream.hip:
+// 256 -> 1024; K = 128 for layer 2's last block, pooled variant only), the fp16 twin of conv1x1_res_stream.hip:
 //
-//   y = relu( (a @ W^T) * scale + bias + residual )        a f16 [M][256], W f16 [N][256], residual / y f16 [M][N]
+//   y = relu( (a @ W^T) * scale + bias + residual )        a f16 [M][K], W f16 [N][K], residual / y f16 [M][N]
 //   (POOL: also AvgPool2d(2) of y, f16 [M / 4][N], for the next stage's downsample branch -- the stage's last block)
 //
 // One workgroup owns 128 pixel rows for a RANGE of 64-channel slabs: the a fragments are loaded once straight into registers (64 of them)
@@ -52,11 +52,13 @@ __device__ __forceinline__ int row_pixel(const ResStreamHP& p, int m) {
     return (n * p.Ho + 2 * hp + (q >> 1)) * p.Wo + 2 * (rem - hp * wp2) + (q & 1);
 }
 
-constexpr int BM = 128, BNS = 64, K = 256, KS = K / 16;
+constexpr int BM = 128, BNS = 64;
 
-template <int POOL>
+template <int K, int POOL>
 __global__ __launch_bounds__(256, 2) void conv1x1_res_stream_f16_kernel(const ResStreamHP p) {
-    __shared__ __attribute__((aligned(256))) unsigned char lds[2 * BNS * K * 2];      // ring of two weight slabs [64 rows (block j, column c)][256]
+    static_assert(K == 128 || K == 256, "reduction depth: layer 2 / layer 3");
+    constexpr int KS = K / 16;
+    __shared__ __attribute__((aligned(256))) unsigned char lds[2 * BNS * K * 2];      // ring of two weight slabs [64 rows (block j, column c)][K]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 31, fh = lane >> 5;
     const int NT = p.N / BNS;
@@ -64,7 +66,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_res_stream_f16_kernel(const Re
     long long u = U * blockIdx.x / gridDim.x;
     const long long u_end = U * (blockIdx.x + 1) / gridDim.x;
     const long long Mll = p.M;
-    // weight slab: 16-B chunks dealt over the 256 threads (32 chunks per row, 8 rows per pass, 8 loads per thread)
+    // weight slab: 16-B chunks dealt over the 256 threads (K = 256: 32 chunks per row, 8 rows per pass, 8 loads per thread)
     constexpr int CPR = K / 8, RPP = 256 / CPR, WLD = BNS * CPR / 256;
     const int wc = tid % CPR, wr = tid / CPR;
     u32x4 wreg[WLD];
@@ -185,7 +187,7 @@ int dbmm_conv1x1_res_stream_f16(const void* x, const void* w, const float* scale
                                 int64_t M, int64_t Ho, int64_t Wo, int64_t Cin, int64_t Cout, void* stream) {
     if (!x || !w || !residual || !y) return DBMM_E_ARG;
     if (M <= 0 || Cout <= 0 || M > (INT32_MAX >> 1)) return DBMM_E_SHAPE;
-    if (Cin != K || (Cout % BNS)) return DBMM_E_UNSUPPORTED;
+    if ((Cin != 256 && !(Cin == 128 && y_pooled)) || (Cout % BNS)) return DBMM_E_UNSUPPORTED;     // (K = 128: only the pooled variant pays)
     if (y_pooled && (Ho <= 0 || Wo <= 0 || (Ho & 1) || (Wo & 1) || (M & 3) || M % (Ho * Wo))) return DBMM_E_UNSUPPORTED;
     if ((132LL + (y_pooled ? 2 * Wo : 0)) * Cout * 2 >= EXT_LIM) return DBMM_E_UNSUPPORTED;       // a tile's pixel span under its rebased descriptors
     if (!dbmm_aligned16(x) || !dbmm_aligned16(w) || !dbmm_aligned16(residual) || !dbmm_aligned16(y) || (y_pooled && !dbmm_aligned16(y_pooled)))
@@ -196,8 +198,9 @@ int dbmm_conv1x1_res_stream_f16(const void* x, const void* w, const float* scale
     const long long units = (long long)p.n_tiles * (Cout / BNS);
     const int grid = (int)(units < 512 ? units : 512);              // two workgroups per CU
     hipStream_t s = (hipStream_t)stream;
-    if (y_pooled) hipLaunchKernelGGL((conv1x1_res_stream_f16_kernel<1>), dim3(grid), dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((conv1x1_res_stream_f16_kernel<0>), dim3(grid), dim3(256), 0, s, p);
+    if (Cin == 128) hipLaunchKernelGGL((conv1x1_res_stream_f16_kernel<128, 1>), dim3(grid), dim3(256), 0, s, p);
+    else if (y_pooled) hipLaunchKernelGGL((conv1x1_res_stream_f16_kernel<256, 1>), dim3(grid), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((conv1x1_res_stream_f16_kernel<256, 0>), dim3(grid), dim3(256), 0, s, p);
     DBMM_CHECK_LAUNCH();
     return DBMM_OK;
 }

@@ -857,7 +857,7 @@ def conv1x1_f16(x, w, scale, bias, residual=None, act=ACT_RELU):
     tag = (f"conv1x1_f16_kernel<{'4, 1, 2' if Cout <= 64 else '2, 2, 4'}, {res}>" if stream_k
            else (f"gemm_f16_8ph_kernel<{act}, {res}>" if deep and get_option("f16_8ph") else _gemm_f16_tag(M, Cout)))
     if residual is not None and act == ACT_RELU and Cin == 256 and Cout >= 1024 and Cout % 64 == 0 and M >= 131072 and get_option("conv1x1_res_stream"):
-        tag = "conv1x1_res_stream_f16_kernel<0>"                 # layer 3's conv3 + residual: the row-owning streaming kernel
+        tag = "conv1x1_res_stream_f16_kernel<256, 0>"            # layer 3's conv3 + residual: the row-owning streaming kernel
     t = _TimedTag(tag, 2.0 * M * Cout * Cin,
                   2 * (M * Cin + Cout * Cin + M * Cout * (2 if residual is not None else 1)))
     t.__enter__()
@@ -873,7 +873,7 @@ def conv1x1_f16(x, w, scale, bias, residual=None, act=ACT_RELU):
 
 def conv1x1_res_pool_f16(x, c3, residual):
     """fp16 mode, the last block of a stage: (y, AvgPool2d(2) of y) with y = relu(conv1x1(x) * scale + bias + residual) in one launch
-    (dbmm_conv1x1_res_pool_f16); x NHWC f16 [B,H,W,256]; None when the library has no kernel for the shape."""
+    (dbmm_conv1x1_res_pool_f16); x NHWC f16 [B,H,W,128 | 256]; None when the library has no kernel for the shape."""
     require_cuda(x, residual)
     _f16c(x); _f16c(residual)
     w, scale, bias = c3
@@ -884,7 +884,7 @@ def conv1x1_res_pool_f16(x, c3, residual):
     M = B * H * W
     y = _empty((B, H, W, Cout), device=x.device, dtype=torch.float16)
     yp = _empty((B, H // 2, W // 2, Cout), device=x.device, dtype=torch.float16)
-    t = _TimedTag("conv1x1_res_stream_f16_kernel<1>", 2.0 * M * Cout * Cin, 2 * (M * Cin + Cout * Cin + 2 * M * Cout + M // 4 * Cout))
+    t = _TimedTag(f"conv1x1_res_stream_f16_kernel<{Cin}, 1>", 2.0 * M * Cout * Cin, 2 * (M * Cin + Cout * Cin + 2 * M * Cout + M // 4 * Cout))
     t.__enter__()
     rc = _lib.lib().dbmm_conv1x1_res_pool_f16(ptr(x), ptr(w), ptr(scale), ptr(bias), ptr(residual), ptr(y), ptr(yp), B, H, W, Cin, Cout, stream())
     t.__exit__(None if rc == 0 else DbmmUnsupported, None, None)

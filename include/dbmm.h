@@ -311,8 +311,8 @@ int dbmm_conv1x1_bn_act_f16_ws(const void* x, const void* w, const float* scale,
                                void* stream);          /* with a workspace, as dbmm_gemm_f16_ws */
 /* fp16 mode, the LAST block of a stage (clip/model.py:50-54, then 36-38 of the next block): y = relu(conv1x1(x) * scale + bias + residual)
  * f16 [B*Ho*Wo][Cout] AND y_pooled = AvgPool2d(2) of y f16 [B*Ho/2*Wo/2][Cout] (equal to dbmm_avgpool2_f16 of y bit for bit) in one launch.
- * Cin = 256, Cout % 64 == 0, Ho and Wo even (layer 3); DBMM_E_UNSUPPORTED (nothing launched) otherwise -- the caller then issues the conv
- * and the pool. */
+ * Cin in {128, 256}, Cout % 64 == 0, Ho and Wo even (layers 2 / 3); DBMM_E_UNSUPPORTED (nothing launched) otherwise -- the caller then issues
+ * the conv and the pool. */
 int dbmm_conv1x1_res_pool_f16(const void* x, const void* w, const float* scale, const float* bias, const void* residual, void* y,
                               void* y_pooled, int64_t B, int64_t Ho, int64_t Wo, int64_t Cin, int64_t Cout, void* stream);
 int dbmm_conv3x3_bn_relu_f16(const void* x, const void* w, const float* scale, const float* bias, void* y, int64_t B, int64_t H,

@@ -617,7 +617,7 @@ def test_conv1x1_res_stream_f16_kernel(B, H, W, N, option):
     sc, b = _bn(g, N)
     ops.profile_begin()
     y = ops.conv1x1_f16(x, w, sc, b, residual=res)
-    assert list(ops.profile_end()) == ["conv1x1_res_stream_f16_kernel<0>"]
+    assert list(ops.profile_end()) == ["conv1x1_res_stream_f16_kernel<256, 0>"]
     r = ops.conv1x1_res_pool_f16(x, (w, sc, b), res)
     assert r is not None
     y2, yp = r
@@ -640,7 +640,28 @@ def test_conv1x1_res_stream_f16_kernel(B, H, W, N, option):
     torch.cuda.synchronize()
     assert rc == 0 and torch.equal(bf[:M * N].view_as(y), y) and torch.equal(bp[:M // 4 * N].view_as(yp), yp)
     assert (bf[M * N:] == 7.0).all() and (bp[M // 4 * N:] == 7.0).all()
-    # smaller problems / other depths keep the other kernels
+    # smaller problems keep the other kernels
     ops.profile_begin()
     ops.conv1x1_f16(x[:40].contiguous(), w, sc, b, residual=res[:40].contiguous())
     assert not any(t.startswith("conv1x1_res_stream") for t in ops.profile_end())
+
+
+@pytest.mark.parametrize("B,H,W,N", [(128, 28, 28, 512), (37, 30, 26, 576), (3, 2, 2, 64)])
+def test_conv1x1_res_pool_f16_layer2_depth(B, H, W, N):
+    """the same pooled launch at layer 2's depth (K = 128, the layer 2 -> 3 seam): y bit-equal to conv1x1_f16, pooled copy == avgpool2_f16 of y"""
+    K = 128
+    g = torch.Generator(device=DEV); g.manual_seed(B + N + W)
+    x = torch.relu(torch.randn((B, H, W, K), device=DEV, generator=g)).half()
+    res = torch.relu(torch.randn((B, H, W, N), device=DEV, generator=g, dtype=torch.float16) * 2.0)
+    w = (torch.randn((N, K), device=DEV, generator=g) * K ** -0.5).half()
+    sc, b = _bn(g, N)
+    ops.profile_begin()
+    r = ops.conv1x1_res_pool_f16(x, (w, sc, b), res)
+    assert r is not None and list(ops.profile_end()) == ["conv1x1_res_stream_f16_kernel<128, 1>"]
+    y, yp = r
+    y0 = ops.conv1x1_f16(x, w, sc, b, residual=res)
+    assert torch.equal(y, y0) and torch.equal(yp, ops.avgpool2_f16(y0))
+    M = B * H * W
+    ref = torch.relu(x.view(M, K)[:2000].double() @ w.double().t() * sc.double() + b.double() + res.view(M, N)[:2000].double())
+    assert torch.allclose(y.view(M, N)[:2000].double(), ref, rtol=2e-3, atol=2e-3)
+    assert ops.conv1x1_res_pool_f16(torch.zeros((B, H, W, 64), device=DEV, dtype=torch.float16), (w[:, :64].contiguous(), sc, b), res) is None
