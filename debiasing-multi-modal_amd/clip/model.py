@@ -385,6 +385,12 @@ class ModifiedResNet(nn.Module):
         out = out.to(torch.float16)
         return (out, stages) if return_stages else out
 
+    def rounds_fp32_images_itself(self):
+        """fp16 mode on the fp16 kernels: the stem conv reads an fp32 image and rounds it to fp16 as it gathers (the values of the
+        reference's `image.type(self.dtype)`, clip/model.py:341), so the caller's cast pass (0.9 MB per image) is not needed"""
+        return (self.conv1.weight.dtype == torch.float16 and self._f16_eligible()
+                and all(b.stride in (1, 2) for li in (1, 2, 3, 4) for b in getattr(self, f"layer{li}")))
+
     @torch.no_grad()
     def forward(self, x, return_stages=False):
         if self.conv1.weight.dtype == torch.float16:
@@ -715,6 +721,8 @@ class CLIP(nn.Module):
         return self.visual.conv1.weight.dtype
 
     def encode_image(self, image):
+        if image.dtype == torch.float32 and self.dtype == torch.float16 and getattr(self.visual, "rounds_fp32_images_itself", lambda: False)():
+            return self.visual(image)                  # (same values as the cast below, without the extra pass over the batch)
         return self.visual(image.type(self.dtype))
 
     @torch.no_grad()

@@ -665,3 +665,14 @@ def test_conv1x1_res_pool_f16_layer2_depth(B, H, W, N):
     ref = torch.relu(x.view(M, K)[:2000].double() @ w.double().t() * sc.double() + b.double() + res.view(M, N)[:2000].double())
     assert torch.allclose(y.view(M, N)[:2000].double(), ref, rtol=2e-3, atol=2e-3)
     assert ops.conv1x1_res_pool_f16(torch.zeros((B, H, W, 64), device=DEV, dtype=torch.float16), (w[:, :64].contiguous(), sc, b), res) is None
+
+
+def test_fp16_mode_encode_image_takes_fp32_images_without_a_cast_pass():
+    """CLIP.encode_image casts the batch to the model dtype (clip/model.py:340-341); in fp16 mode on the fp16 kernels the stem conv rounds an
+    fp32 image itself: same embedding bit for bit as for the pre-cast batch, and no cast kernel in between"""
+    model = convert_weights(build_model(synth.clip_state_dict(3, "RN50")).cuda())
+    img = synth.images(11, 3, 224).cuda()
+    assert model.visual.rounds_fp32_images_itself()
+    a = model.encode_image(img)
+    b = model.encode_image(img.half())
+    assert a.dtype == torch.float16 and torch.equal(a, b)
