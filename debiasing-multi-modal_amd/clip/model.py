@@ -638,6 +638,10 @@ class VisionTransformer(nn.Module):
         self.ln_post = _LNParams(width)
         self.proj = nn.Parameter(scale * torch.randn(width, output_dim))
 
+    def rounds_fp32_images_itself(self):
+        """fp16 mode: the patch gather reads an fp32 image and rounds it to fp16 (the values of `image.type(self.dtype)`, clip/model.py:341)"""
+        return self.conv1.weight.dtype == torch.float16
+
     @torch.no_grad()
     def forward_f16(self, x):
         """fp16 mode: patch GEMM (K zero-padded to a multiple of 64), fp16 token stream, fp16 output [B, D]."""

@@ -669,10 +669,11 @@ def test_conv1x1_res_pool_f16_layer2_depth(B, H, W, N):
 
 def test_fp16_mode_encode_image_takes_fp32_images_without_a_cast_pass():
     """CLIP.encode_image casts the batch to the model dtype (clip/model.py:340-341); in fp16 mode on the fp16 kernels the stem conv rounds an
-    fp32 image itself: same embedding bit for bit as for the pre-cast batch, and no cast kernel in between"""
-    model = convert_weights(build_model(synth.clip_state_dict(3, "RN50")).cuda())
-    img = synth.images(11, 3, 224).cuda()
-    assert model.visual.rounds_fp32_images_itself()
-    a = model.encode_image(img)
-    b = model.encode_image(img.half())
-    assert a.dtype == torch.float16 and torch.equal(a, b)
+    fp32 image itself (so does the ViT towers' patch gather): same embedding bit for bit as for the pre-cast batch, no cast kernel in between"""
+    for arch in ("RN50", "ViT-B/32"):
+        model = convert_weights(build_model(synth.clip_state_dict(3, arch)).cuda())
+        img = synth.images(11, 3, 224).cuda()
+        assert model.visual.rounds_fp32_images_itself()
+        a = model.encode_image(img)
+        b = model.encode_image(img.half())
+        assert a.dtype == torch.float16 and torch.equal(a, b), arch
