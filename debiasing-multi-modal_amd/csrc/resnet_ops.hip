@@ -185,7 +185,8 @@ __global__ __launch_bounds__(256, STEM_MINB(NB)) void stem_s2_mfma_kernel(const 
         const long long mb = (long long)blk * 32;
         img0 = mb / ((long long)Ho * Wo);
         const long long left = (long long)B - img0;
-        const long long ext = (left < 2 ? left : 2) * img * 4;        // 32 pixels touch at most two images
+        const long long span = 31 / ((long long)Ho * Wo) + 2;         // images a block of 32 pixels can touch (two, unless an image has < 31 of them)
+        const long long ext = (left < span ? left : span) * img * 4;
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(x + img0 * img), 0, (int)ext, 0x00020000);
         unsigned base = OOR;
         int mask = 0;

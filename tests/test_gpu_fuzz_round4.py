@@ -1,0 +1,111 @@
+"""Seeded random shapes for the fp16 ModifiedResNet kernels added in round 4 (clip/model.py:42-55, 108-116, 141-148): every launch writes
+into the middle of a canary buffer and is compared with the kernel it replaces (bit for bit where the arithmetic is the same), so an index
+that leaves the tensor, a ragged tile or a window wrap that a hand-picked shape happened to miss shows up here."""
+import random
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import relerr
+from dbmm_amd import ops, _lib
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+GUARD = 2048
+
+
+def _bn(g, n):
+    return 0.5 + torch.rand((n,), device=DEV, generator=g), torch.randn((n,), device=DEV, generator=g) * 0.1
+
+
+def _guarded(shape):
+    n = 1
+    for s in shape:
+        n *= s
+    buf = torch.full((n + 2 * GUARD,), 7.0, device=DEV, dtype=torch.float16)
+    return buf, buf[GUARD:GUARD + n].view(shape)
+
+
+def _intact(buf, n):
+    return bool((buf[:GUARD] == 7.0).all() and (buf[GUARD + n:] == 7.0).all())
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_fuzz_chain_and_seam_kernels_f16(seed):
+    rnd = random.Random(1000 + seed)
+    g = torch.Generator(device=DEV); g.manual_seed(seed)
+    K = rnd.choice([64, 128]); P = rnd.choice([64, 128]); N = 64 * rnd.randint(1, 9)
+    B = rnd.randint(1, 9); H = 2 * rnd.randint(1, 15); W = 2 * rnd.randint(1, 15)
+    y2 = torch.relu(torch.randn((B, H, W, K), device=DEV, generator=g)).half()
+    res = torch.relu(torch.randn((B, H, W, N), device=DEV, generator=g, dtype=torch.float16) * 2.0)
+    w3 = (torch.randn((N, K), device=DEV, generator=g) * K ** -0.5).half(); w1 = (torch.randn((P, N), device=DEV, generator=g) * N ** -0.5).half()
+    (s3, b3), (s1, b1) = _bn(g, N), _bn(g, P)
+    x_ref = ops.conv1x1_f16(y2, w3, s3, b3, residual=res)
+    y1_ref = ops.conv1x1_f16(x_ref, w1, s1, b1)
+    xp_ref = ops.avgpool2_f16(x_ref)
+    M = B * H * W
+    for pooled, full in ((False, True), (True, True), (True, False)):
+        bx, x = _guarded((B, H, W, N)); by, y1 = _guarded((B, H, W, P)); bp, xp = _guarded((B, H // 2, W // 2, N))
+        if pooled:
+            rc = _lib.lib().dbmm_bottleneck_chain_pool_f16(y2.data_ptr(), w3.data_ptr(), s3.data_ptr(), b3.data_ptr(), res.data_ptr(),
+                                                           x.data_ptr() if full else None, xp.data_ptr(), w1.data_ptr(), s1.data_ptr(), b1.data_ptr(),
+                                                           y1.data_ptr(), B, H, W, K, N, P, _lib.stream())
+        else:
+            rc = _lib.lib().dbmm_bottleneck_chain_f16(y2.data_ptr(), w3.data_ptr(), s3.data_ptr(), b3.data_ptr(), res.data_ptr(), x.data_ptr(),
+                                                      w1.data_ptr(), s1.data_ptr(), b1.data_ptr(), y1.data_ptr(), M, K, N, P, _lib.stream())
+        torch.cuda.synchronize()
+        assert rc == 0, (rc, B, H, W, K, N, P)
+        assert _intact(bx, M * N) and _intact(by, M * P) and _intact(bp, M // 4 * N), (B, H, W, K, N, P, pooled, full)
+        assert torch.equal(y1, y1_ref), (B, H, W, K, N, P, pooled, full)
+        assert torch.equal(x, x_ref) if full else bool((x == 7.0).all())
+        assert torch.equal(xp, xp_ref) if pooled else bool((xp == 7.0).all())
+    # the seam without a chain kernel: conv3 + residual + pooled copy in one launch
+    bx, x = _guarded((B, H, W, N)); bp, xp = _guarded((B, H // 2, W // 2, N))
+    for Kc in (128, 256):
+        a = torch.relu(torch.randn((B, H, W, Kc), device=DEV, generator=g)).half(); wc = (torch.randn((N, Kc), device=DEV, generator=g) * Kc ** -0.5).half()
+        rc = _lib.lib().dbmm_conv1x1_res_pool_f16(a.data_ptr(), wc.data_ptr(), s3.data_ptr(), b3.data_ptr(), res.data_ptr(), x.data_ptr(), xp.data_ptr(),
+                                                  B, H, W, Kc, N, _lib.stream())
+        torch.cuda.synchronize()
+        ref = ops.conv1x1_f16(a, wc, s3, b3, residual=res)
+        assert rc == 0 and _intact(bx, M * N) and _intact(bp, M // 4 * N), (B, H, W, Kc, N)
+        assert torch.equal(x, ref) and torch.equal(xp, ops.avgpool2_f16(ref)), (B, H, W, Kc, N)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_fuzz_stem_kernels_f16(seed, option):
+    rnd = random.Random(2000 + seed)
+    g = torch.Generator(device=DEV); g.manual_seed(seed)
+    # stem conv1 on the MFMA gather kernel: any image size, fp32 or fp16 input
+    B = rnd.randint(1, 6); R = rnd.randint(5, 70); R2 = rnd.randint(5, 70); Cout = rnd.choice([32, 64]); half_in = rnd.random() < 0.5
+    img = torch.randn((B, 3, R, R2), device=DEV, generator=g)
+    w = (torch.randn((3, 3, 3, Cout), device=DEV, generator=g) * 0.2).half().float()
+    sc, b = _bn(g, Cout)
+    Ho, Wo = (R - 1) // 2 + 1, (R2 - 1) // 2 + 1
+    buf, y = _guarded((B, Ho, Wo, Cout))
+    xin = img.half() if half_in else img
+    rc = _lib.lib().dbmm_conv_stem_s2_bn_f16(xin.data_ptr(), int(half_in), w.data_ptr(), sc.data_ptr(), b.data_ptr(), y.data_ptr(), B, R, R2, Cout, _lib.stream())
+    torch.cuda.synchronize()
+    assert rc == 0 and _intact(buf, y.numel()), (B, R, R2, Cout)
+    ref = F.conv2d(img.half().double(), w.permute(3, 2, 0, 1).double(), None, stride=2, padding=1) * sc.double().view(1, -1, 1, 1) + b.double().view(1, -1, 1, 1)
+    assert relerr(y.double().cpu(), torch.relu(ref).permute(0, 2, 3, 1).cpu()) < 1e-3, (B, R, R2, Cout)
+    # the parity mode's stem conv on the same gather (images with fewer than 31 output pixels: a block of 32 touches more than two images)
+    w32 = torch.randn((3, 3, 3, Cout), device=DEV, generator=g) * 0.2; b32 = torch.randn((Cout,), device=DEV, generator=g) * 0.1
+    am = torch.zeros(1, device=DEV)
+    y32 = ops.conv_stem_s2(img, w32, b32, y_absmax=am)
+    ref32 = torch.relu(F.conv2d(img.double(), w32.permute(3, 2, 0, 1).double(), b32.double(), stride=2, padding=1)).permute(0, 2, 3, 1)
+    assert relerr(y32.double().cpu(), ref32.cpu()) < 5e-6 and am.item() == y32.abs().max().item(), (B, R, R2, Cout)
+    # the 32-channel convs on the patch kernel: maps of 4 i x 28 j pixels
+    B = rnd.randint(1, 5); H = 4 * rnd.randint(1, 8); W = 28 * rnd.randint(1, 3); Cout = rnd.choice([32, 64]); pool = rnd.choice([1, 2])
+    x = torch.relu(torch.randn((B, H, W, 32), device=DEV, generator=g)).half()
+    wc = (torch.randn((Cout, 32, 3, 3), device=DEV, generator=g) * 288 ** -0.5).half()
+    wp, _ = ops.pack_conv_weight(wc.float(), chunk_major=32)
+    wh = wp.half().contiguous()
+    sc, b = _bn(g, Cout)
+    buf, y = _guarded((B, H // pool, W // pool, Cout))
+    rc = _lib.lib().dbmm_conv3x3_bn_relu_f16(x.data_ptr(), wh.data_ptr(), sc.data_ptr(), b.data_ptr(), y.data_ptr(), B, H, W, 32, Cout, 2 if pool == 2 else 0,
+                                             _lib.stream())
+    torch.cuda.synchronize()
+    assert rc == 0 and _intact(buf, y.numel()), (B, H, W, Cout, pool)
+    option("conv_patch", 0)
+    assert torch.equal(y, ops.conv3x3_f16(x, wh, sc, b, pool=pool)), (B, H, W, Cout, pool)
