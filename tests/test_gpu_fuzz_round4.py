@@ -109,3 +109,57 @@ def test_fuzz_stem_kernels_f16(seed, option):
     assert rc == 0 and _intact(buf, y.numel()), (B, H, W, Cout, pool)
     option("conv_patch", 0)
     assert torch.equal(y, ops.conv3x3_f16(x, wh, sc, b, pool=pool)), (B, H, W, Cout, pool)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_fuzz_parity_seam_kernels(seed, option):
+    """fp32-accurate mode: the chain launch that writes only the pooled stage output (bottleneck_chain_kernel<.., POOL = 2>) and the row-owning
+    conv3 + residual kernel (conv1x1_res_stream_kernel<256, POOL>) on random maps, against the launches they replace, canaries around every output"""
+    rnd = random.Random(3000 + seed)
+    g = torch.Generator(device=DEV); g.manual_seed(seed)
+    mk = lambda n: (0.5 + torch.rand((n,), device=DEV, generator=g), torch.randn((n,), device=DEV, generator=g) * 0.1)
+    K = rnd.choice([64, 128]); P = rnd.choice([64, 128]); N = 64 * rnd.randint(1, 8)
+    B = rnd.randint(1, 7); H = 2 * rnd.randint(1, 14); W = 2 * rnd.randint(1, 14)
+    y2 = torch.relu(torch.randn((B, H, W, K), device=DEV, generator=g)); res = torch.relu(torch.randn((B, H, W, N), device=DEV, generator=g) * 2.0)
+    w3 = (torch.randn((N, K), device=DEV, generator=g) * K ** -0.5).half().float(); w1 = (torch.randn((P, N), device=DEV, generator=g) * N ** -0.5).half().float()
+    (s3, b3), (s1, b1) = mk(N), mk(P)
+    p3, e3, _ = ops.split_planes_f16(w3, allow_single=True); p1, e1, _ = ops.split_planes_f16(w1, allow_single=True)
+    c3 = dict(w=w3, ph=p3, we=e3, sc=s3, b=b3); c1 = dict(w=w1, ph=p1, we=e1, sc=s1, b=b1)
+    ya = (y2.abs().max() * 1.1).reshape(1)
+    xa, ya1 = torch.zeros(1, device=DEV), torch.zeros(1, device=DEV)
+    x, xp, y1 = ops.bottleneck_chain(y2, ya, c3, res, c1, xa, ya1, pooled=True)
+    xb, yb = torch.zeros(1, device=DEV), torch.zeros(1, device=DEV)
+    M = B * H * W
+    bp = torch.full((M // 4 * N + 2 * GUARD,), 7.0, device=DEV); by = torch.full((M * P + 2 * GUARD,), 7.0, device=DEV)
+    op, oy = bp[GUARD:GUARD + M // 4 * N].view(B, H // 2, W // 2, N), by[GUARD:GUARD + M * P].view(B, H, W, P)
+    rc = _lib.lib().dbmm_bottleneck_chain_x2(y2.data_ptr(), ya.data_ptr(), p3.data_ptr(), int(e3), s3.data_ptr(), b3.data_ptr(), res.data_ptr(), None,
+                                            op.data_ptr(), xb.data_ptr(), p1.data_ptr(), int(e1), s1.data_ptr(), b1.data_ptr(), oy.data_ptr(), yb.data_ptr(),
+                                            B, H, W, K, N, P, _lib.stream())
+    torch.cuda.synchronize()
+    assert rc == 0, (rc, B, H, W, K, N, P)
+    assert (bp[:GUARD] == 7.0).all() and (bp[GUARD + M // 4 * N:] == 7.0).all() and (by[:GUARD] == 7.0).all() and (by[GUARD + M * P:] == 7.0).all()
+    assert torch.equal(op, xp) and torch.equal(oy, y1) and xb.item() == xa.item() and yb.item() == ya1.item(), (B, H, W, K, N, P)
+    # conv1x1_res_stream_kernel: K = 256, >= 131,072 rows
+    H = 2 * rnd.randint(4, 20); W = 2 * rnd.randint(4, 20); B = 131072 // (H * W) + rnd.randint(1, 5); N = 32 * rnd.randint(32, 36)
+    x = torch.relu(torch.randn((B, H, W, 256), device=DEV, generator=g)); res = torch.relu(torch.randn((B, H, W, N), device=DEV, generator=g) * 2.0)
+    w = (torch.randn((N, 256, 1, 1), device=DEV, generator=g) * 256 ** -0.5).half().float()
+    sc, b = mk(N)
+    wp, wl = ops.pack_conv_weight(w, chunk_major=32)
+    ph, we, _ = ops.split_planes_f16(wp, allow_single=True)
+    xam = (x.abs().max() * 1.2).reshape(1)
+    kw = dict(w_planes_f16=ph, w_exp=we, x_absmax=xam, out_scale=sc)
+    M = B * H * W
+    for pool in (1, 2):
+        option("conv1x1_res_stream", 0)
+        r0 = ops.conv_bn_act(x, wp, b, res, 1, 1, 1, 0, ops.ACT_RELU, wl, pool=pool, keep_full=pool == 2, **kw)
+        option("conv1x1_res_stream", 1)
+        bf = torch.full((M * N + 2 * GUARD,), 7.0, device=DEV); bq = torch.full((M // 4 * N + 2 * GUARD,), 7.0, device=DEV)
+        of, oq = bf[GUARD:GUARD + M * N].view(B, H, W, N), bq[GUARD:GUARD + M // 4 * N].view(B, H // 2, W // 2, N)
+        rc = ops._conv_x2(x, wp, b, res, oq if pool == 2 else of, 1, 1, 1, 0, ops.ACT_RELU, wl, ph, we, xam, None, sc, pool if pool == 2 else 0, of if pool == 2 else None)
+        torch.cuda.synchronize()
+        assert rc == 0 and ops._last_igemm_tag() == f"conv1x1_res_stream_kernel<256, {int(pool == 2)}>", (rc, ops._last_igemm_tag(), B, H, W, N)
+        assert (bf[:GUARD] == 7.0).all() and (bf[GUARD + M * N:] == 7.0).all() and (bq[:GUARD] == 7.0).all() and (bq[GUARD + M // 4 * N:] == 7.0).all()
+        if pool == 2:
+            assert relerr(oq.cpu(), r0[0].cpu()) < 2e-6 and relerr(of.cpu(), r0[1].cpu()) < 2e-6, (B, H, W, N)
+        else:
+            assert relerr(of.cpu(), r0.cpu()) < 2e-6 and (oq == 7.0).all(), (B, H, W, N)
