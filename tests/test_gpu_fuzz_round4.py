@@ -163,3 +163,44 @@ def test_fuzz_parity_seam_kernels(seed, option):
             assert relerr(oq.cpu(), r0[0].cpu()) < 2e-6 and relerr(of.cpu(), r0[1].cpu()) < 2e-6, (B, H, W, N)
         else:
             assert relerr(of.cpu(), r0.cpu()) < 2e-6 and (oq == 7.0).all(), (B, H, W, N)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_fuzz_eight_phase_3x3_kernels(seed, option):
+    """the eight-phase 3x3 kernels of both modes (conv3x3_halo8 / halo8n, conv3x3_f16_8ph) on random maps with >= 16,384 pixels: equal to the
+    kernels they replace (bit for bit; whole tiles: tail_split = 0), canaries around the output"""
+    rnd = random.Random(4000 + seed)
+    g = torch.Generator(device=DEV); g.manual_seed(seed)
+    Cin = rnd.choice([64, 128, 256]); Cout = rnd.choice([128, 256, 384, 512]); pool = rnd.choice([1, 2])
+    H = 2 * rnd.randint(2, 16); W = 2 * rnd.randint(2, 16); B = 16384 // (H * W) + rnd.randint(1, 40)
+    sc = 0.5 + torch.rand((Cout,), device=DEV, generator=g); b = torch.randn((Cout,), device=DEV, generator=g) * 0.1
+    w = (torch.randn((Cout, Cin, 3, 3), device=DEV, generator=g) * (9 * Cin) ** -0.5).half().float()
+    wp, wl = ops.pack_conv_weight(w, chunk_major=32)
+    Ho, Wo = H // pool, W // pool
+    n_out = B * Ho * Wo * Cout
+    # parity mode
+    x = torch.relu(torch.randn((B, H, W, Cin), device=DEV, generator=g))
+    ph, we, _ = ops.split_planes_f16(wp, allow_single=True)
+    xam = x.abs().max().reshape(1)
+    option("igemm_streamk", 0); option("tail_split", 0)
+    option("halo8", 0)
+    y0 = ops.conv_bn_act(x, wp, b, None, 3, 3, 1, 1, ops.ACT_RELU, wl, w_planes_f16=ph, w_exp=we, x_absmax=xam, out_scale=sc, pool=pool)
+    option("halo8", 2)
+    buf = torch.full((n_out + 2 * GUARD,), 7.0, device=DEV)
+    out = buf[GUARD:GUARD + n_out].view(B, Ho, Wo, Cout)
+    rc = ops._conv_x2(x, wp, b, None, out, 3, 3, 1, 1, ops.ACT_RELU, wl, ph, we, xam, None, sc, 2 if pool == 2 else 0, None)
+    torch.cuda.synchronize()
+    assert rc == 0 and ops._last_igemm_tag().startswith("conv3x3_halo8"), (rc, ops._last_igemm_tag(), B, H, W, Cin, Cout, pool)
+    assert (buf[:GUARD] == 7.0).all() and (buf[GUARD + n_out:] == 7.0).all() and torch.equal(out, y0), (B, H, W, Cin, Cout, pool)
+    # fp16 mode (the eight-phase kernel takes Cout % 256 == 0)
+    if Cout % 256 == 0:
+        xh = x.half(); wh = wp.half().contiguous()
+        option("f16_conv_8ph", 0)
+        yh0 = ops.conv3x3_f16(xh, wh, sc, b, pool=pool)
+        option("f16_conv_8ph", 1)
+        bh = torch.full((n_out + 2 * GUARD,), 7.0, device=DEV, dtype=torch.float16)
+        oh = bh[GUARD:GUARD + n_out].view(B, Ho, Wo, Cout)
+        rc = _lib.lib().dbmm_conv3x3_bn_relu_f16(xh.data_ptr(), wh.data_ptr(), sc.data_ptr(), b.data_ptr(), oh.data_ptr(), B, H, W, Cin, Cout,
+                                                 2 if pool == 2 else 0, _lib.stream())
+        torch.cuda.synchronize()
+        assert rc == 0 and (bh[:GUARD] == 7.0).all() and (bh[GUARD + n_out:] == 7.0).all() and torch.equal(oh, yh0), (B, H, W, Cin, Cout, pool)
