@@ -204,3 +204,40 @@ def test_fuzz_eight_phase_3x3_kernels(seed, option):
                                                  2 if pool == 2 else 0, _lib.stream())
         torch.cuda.synchronize()
         assert rc == 0 and (bh[:GUARD] == 7.0).all() and (bh[GUARD + n_out:] == 7.0).all() and torch.equal(oh, yh0), (B, H, W, Cin, Cout, pool)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_fuzz_eight_phase_gemms(seed, option):
+    """the eight-phase GEMM kernels of both modes (gemm_pair_8ph, gemm_f16_8ph; K cut / row split of a short last round wherever it applies:
+    tail_split = 2) on random (M, N, K) with bias, residual and both activations: against the two-barrier kernels (gemm_8ph / f16_8ph = 0)
+    -- the cut changes the order of summation, so to rounding -- and with the maximum scalar; outputs sit inside canary buffers"""
+    rnd = random.Random(5000 + seed)
+    g = torch.Generator(device=DEV); g.manual_seed(seed)
+    M = rnd.randint(16384, 60000); N = 256 * rnd.randint(1, 6); K = 128 * rnd.randint(1, 16)
+    act = rnd.choice([ops.ACT_NONE, ops.ACT_RELU, ops.ACT_QUICKGELU]); use_res = rnd.random() < 0.5
+    a = torch.randn((M, K), device=DEV, generator=g); w = (torch.randn((N, K), device=DEV, generator=g) * K ** -0.5).half().float()
+    bias = torch.randn((N,), device=DEV, generator=g) * 0.1
+    r = torch.randn((M, N), device=DEV, generator=g) if use_res else None
+    ph, we, n = ops.split_planes_f16(w, allow_single=True)
+    aam = a.abs().max().reshape(1)
+    option("tail_split", 2)
+    option("gemm_8ph", 0)
+    am0 = torch.zeros(1, device=DEV)
+    c0 = ops.gemm(a, w, bias, residual=r, act=act, w_planes_f16=ph, w_exp=we, a_absmax=aam, c_absmax=am0)
+    option("gemm_8ph", 2)
+    buf = torch.full((M * N + 2 * GUARD,), 7.0, device=DEV)
+    out = buf[GUARD:GUARD + M * N].view(M, N)
+    am = torch.zeros(1, device=DEV)
+    c = ops.gemm(a, w, bias, residual=r, act=act, w_planes_f16=ph, w_exp=we, a_absmax=aam, c_absmax=am, out=out)
+    torch.cuda.synchronize()
+    assert ops._last_igemm_tag().startswith("gemm_pair_8ph_kernel"), (ops._last_igemm_tag(), M, N, K)
+    assert (buf[:GUARD] == 7.0).all() and (buf[GUARD + M * N:] == 7.0).all(), (M, N, K)
+    assert relerr(c.cpu(), c0.cpu()) < 3e-6 and am.item() == c.abs().max().item(), (M, N, K, act, use_res, relerr(c.cpu(), c0.cpu()))
+    # fp16 mode
+    ah = a.half(); wh = w.half(); rh = r.half() if use_res else None
+    option("f16_8ph", 0)
+    h0 = ops.gemm_f16(ah, wh, bias, residual=rh, act=act)
+    option("f16_8ph", 1)
+    h = ops.gemm_f16(ah, wh, bias, residual=rh, act=act)
+    tol = 4e-3 * max(1.0, h0.float().abs().max().item())
+    assert (h.float() - h0.float()).abs().max().item() <= tol, (M, N, K, act, use_res)
