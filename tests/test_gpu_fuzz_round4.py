@@ -241,3 +241,34 @@ def test_fuzz_eight_phase_gemms(seed, option):
     h = ops.gemm_f16(ah, wh, bias, residual=rh, act=act)
     tol = 4e-3 * max(1.0, h0.float().abs().max().item())
     assert (h.float() - h0.float()).abs().max().item() <= tol, (M, N, K, act, use_res)
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_fuzz_attention_cores(seed, option):
+    """softmax(q k^T / 8) v per (image, head) (clip/model.py:185-189 through nn.MultiheadAttention) on random sequence lengths around the
+    workgroup sizes (1 ... 150 tokens: two-wave workgroups up to 64, four-wave above), heads and batch, causal or not, both modes, against
+    fp64; with mha_short = 0 the same results bit for bit"""
+    rnd = random.Random(6000 + seed)
+    g = torch.Generator(device=DEV); g.manual_seed(seed)
+    L = rnd.choice([1, 2, 7, 31, 32, 33, 49, 50, 63, 64, 65, 77, 96, 127, 128, 129, 150]); heads = rnd.randint(1, 12); B = rnd.randint(1, 40)
+    causal = rnd.random() < 0.5
+    E = 64 * heads
+    qkv = torch.randn((B * L, 3 * E), device=DEV, generator=g)
+    q, k, v = [t.view(B, L, heads, 64).permute(0, 2, 1, 3).double() for t in qkv.split(E, dim=1)]
+    s = q @ k.transpose(-1, -2) / 8.0
+    if causal:
+        s = s + torch.full((L, L), float("-inf"), device=DEV, dtype=torch.float64).triu(1)
+    ref = (torch.softmax(s, -1) @ v).permute(0, 2, 1, 3).reshape(B * L, E)
+    am = qkv.abs().max().reshape(1)
+    o = ops.mha_core(qkv, B, L, E, heads, causal, qkv_absmax=am)
+    assert relerr(o.double().cpu(), ref.cpu()) < 1e-5, (B, L, heads, causal)
+    qh = qkv.half()
+    qr, kr, vr = [t.view(B, L, heads, 64).permute(0, 2, 1, 3).double() for t in qh.split(E, dim=1)]
+    sr = qr @ kr.transpose(-1, -2) / 8.0
+    if causal:
+        sr = sr + torch.full((L, L), float("-inf"), device=DEV, dtype=torch.float64).triu(1)
+    refh = (torch.softmax(sr, -1) @ vr).permute(0, 2, 1, 3).reshape(B * L, E)
+    oh = ops.mha_core_f16(qh, B, L, E, heads, causal)
+    assert (oh.double() - refh).abs().max().item() <= 6e-3 * max(1.0, refh.abs().max().item()), (B, L, heads, causal)
+    option("mha_short", 0)
+    assert torch.equal(ops.mha_core(qkv, B, L, E, heads, causal, qkv_absmax=am), o) and torch.equal(ops.mha_core_f16(qh, B, L, E, heads, causal), oh)
