@@ -488,6 +488,17 @@ def attnpool(x, pos, wq, bq, wkv, bkv, wc, bc, heads):
     B, H, W, C = x.shape
     HW = H * W
     Dout = wc.shape[0]
+    # the library sees raw pointers: the operand shapes are checked here.  A feature map of another resolution than the positional table
+    # was built for fails like the reference's `x + self.positional_embedding[:, None, :]` (clip/model.py:72), not as a stray read
+    if tuple(pos.shape) != (HW + 1, C):
+        raise RuntimeError(f"attnpool: positional embedding {tuple(pos.shape)} does not match a {H} x {W} x {C} feature map "
+                           f"(expected ({HW + 1}, {C})): the input resolution differs from the one the model was built for")
+    if (tuple(wq.shape) != (C, C) or tuple(wkv.shape) != (2 * C, C) or wc.shape[1] != C or bq.numel() != C or bkv.numel() != 2 * C
+            or bc.numel() != Dout):
+        raise RuntimeError(f"attnpool: projection shapes {tuple(wq.shape)}, {tuple(wkv.shape)}, {tuple(wc.shape)} do not match C = {C}")
+    for t in (pos, wq, bq, wkv, bkv, wc, bc):
+        require_cuda(t)
+        _f32c(t)
     nbytes = _lib.lib().dbmm_workspace_bytes_attnpool(B, HW, C)
     ws = _empty(nbytes // 4, device=x.device, dtype=torch.float32)
     out = _empty((B, Dout), device=x.device, dtype=torch.float32)
@@ -532,6 +543,8 @@ def embed_gather(tokens, table, pos):
     tokens = tokens.contiguous()
     n, L = tokens.shape
     W = table.shape[1]
+    if tuple(pos.shape) != (L, W):          # (clip/model.py:346: `x + self.positional_embedding` needs context_length tokens)
+        raise RuntimeError(f"embed_gather: {L} tokens per prompt against a positional embedding of shape {tuple(pos.shape)}")
     out = _empty((n, L, W), device=table.device, dtype=torch.float32)
     check(_lib.lib().dbmm_embed_gather(ptr(tokens), ptr(table), ptr(pos), ptr(out), n, L, W, table.shape[0], stream()),
           "embed_gather")
@@ -549,8 +562,18 @@ def im2col_patch(x_nchw, P, out_absmax=None):
     return out
 
 
+def _vit_tokens_check(patches, cls, pos, B):
+    # raw pointers below: a patch count other than the positional table's (another input resolution) fails like the reference's
+    # `x + self.positional_embedding` (clip/model.py:229), not as a stray read
+    L, W = pos.shape
+    if patches.numel() != B * (L - 1) * W or cls.numel() != W:
+        raise RuntimeError(f"vit_tokens: {patches.numel() // max(1, B * W)} patches of width {W} per image do not match a positional embedding of "
+                           f"{L} rows: the input resolution differs from the one the model was built for")
+
+
 def vit_tokens(patches, cls, pos, B):
     L, W = pos.shape
+    _vit_tokens_check(patches, cls, pos, B)
     out = _empty((B, L, W), device=patches.device, dtype=torch.float32)
     check(_lib.lib().dbmm_vit_tokens(ptr(patches), ptr(cls), ptr(pos), ptr(out), B, L, W, stream()), "vit_tokens")
     return out
@@ -813,6 +836,7 @@ def im2col_patch_f16(x_nchw, P, Kp):
 
 def vit_tokens_f16(patches, cls, pos, B):
     L, W = pos.shape
+    _vit_tokens_check(patches, cls, pos, B)
     out = _empty((B, L, W), device=patches.device, dtype=torch.float16)
     check(_lib.lib().dbmm_vit_tokens_f16(ptr(patches), ptr(cls), ptr(pos), ptr(out), B, L, W, stream()), "vit_tokens_f16")
     return out
@@ -825,6 +849,8 @@ def embed_gather_f16(tokens, table, pos):
     tokens = tokens.contiguous()
     n, L = tokens.shape
     W = table.shape[1]
+    if tuple(pos.shape) != (L, W):
+        raise RuntimeError(f"embed_gather_f16: {L} tokens per prompt against a positional embedding of shape {tuple(pos.shape)}")
     out = _empty((n, L, W), device=table.device, dtype=torch.float16)
     check(_lib.lib().dbmm_embed_gather_f16(ptr(tokens), ptr(table), ptr(pos), ptr(out), n, L, W, table.shape[0], stream()),
           "embed_gather_f16")

@@ -272,3 +272,58 @@ def test_fuzz_attention_cores(seed, option):
     assert (oh.double() - refh).abs().max().item() <= 6e-3 * max(1.0, refh.abs().max().item()), (B, L, heads, causal)
     option("mha_short", 0)
     assert torch.equal(ops.mha_core(qkv, B, L, E, heads, causal, qkv_absmax=am), o) and torch.equal(ops.mha_core_f16(qh, B, L, E, heads, causal), oh)
+
+
+def test_other_input_resolutions_raise_in_the_vit_towers_too():
+    """ViT-B/32 built for 224 px fed 160 / 256 px images: the reference fails at `x + self.positional_embedding` (clip/model.py:229)"""
+    from dbmm_amd import synth
+    from dbmm_amd.clip.model import build_model, convert_weights
+    sd = synth.clip_state_dict(5, "ViT-B/32")
+    for R in (160, 256):
+        img = F.interpolate(synth.images(3, 2, 224).cuda(), size=(R, R), mode="bilinear", align_corners=False).contiguous()
+        with pytest.raises(RuntimeError, match="positional embedding"):
+            build_model(sd).cuda().encode_image(img)
+        with pytest.raises(RuntimeError, match="positional embedding"):
+            convert_weights(build_model(sd).cuda()).encode_image(img)
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_fuzz_whole_towers_inside_guard_zones(seed, monkeypatch):
+    """the full RN50 tower in both modes at random batch sizes (ragged tiles in every layer), with EVERY tensor the library allocates between
+    sentinel zones; rows of a call == the same images in other batches (no cross-row leakage), fp16 mode within its distance of the
+    fp32-accurate embedding; other input resolutions (other map sizes in every stage up to the attention pool) raise as the reference does"""
+    from test_gpu_headline import GuardedAlloc
+    from dbmm_amd import synth
+    from dbmm_amd.clip.model import build_model, convert_weights
+    rnd = random.Random(7000 + seed)
+    B = rnd.randint(1, 23); R = 224 if rnd.random() < 0.6 else 32 * rnd.randint(2, 8)
+    sd = synth.clip_state_dict(5, "RN50")
+    model = build_model(sd).cuda()
+    img = synth.images(100 + seed, B, 224).cuda()
+    if R != 224:
+        img = F.interpolate(img, size=(R, R), mode="bilinear", align_corners=False).contiguous()
+    ga = GuardedAlloc()
+    monkeypatch.setattr(ops, "_empty", ga)
+    if R != 224:
+        # another input resolution than the model was built for: the reference fails at `x + self.positional_embedding` (clip/model.py:72);
+        # here the wrapper checks the operand shapes before the library sees raw pointers -- both modes raise, nothing faults
+        with pytest.raises(RuntimeError, match="positional embedding"):
+            model.encode_image(img)
+        with pytest.raises(RuntimeError, match="positional embedding"):
+            convert_weights(build_model(sd).cuda()).encode_image(img)
+        torch.cuda.synchronize()
+        ga.check()
+        return
+    out = model.encode_image(img)
+    ga.check()
+    k = rnd.randint(0, B - 1)
+    one = model.encode_image(img[k:k + 1].contiguous())
+    assert relerr(out[k:k + 1].cpu(), one.cpu()) < 1e-5, (B, k)
+    m16 = convert_weights(build_model(sd).cuda())
+    ga16 = GuardedAlloc()
+    monkeypatch.setattr(ops, "_empty", ga16)
+    o16 = m16.encode_image(img)
+    ga16.check()
+    assert o16.dtype == torch.float16 and relerr(o16.float().cpu(), out.cpu()) < 3e-2, (B, relerr(o16.float().cpu(), out.cpu()))
+    assert torch.equal(m16.encode_image(img[k:k + 1].contiguous()), o16[k:k + 1]) or relerr(m16.encode_image(img[k:k + 1].contiguous()).float().cpu(), o16[k:k + 1].float().cpu()) < 2e-3
