@@ -133,6 +133,12 @@ def igemm_workspace(device):
     return ws
 
 
+def _sized(name, t, n):
+    """an optional per-channel / per-row operand the library will index as n elements (it only sees the pointer)"""
+    if t is not None and t.numel() != n:
+        raise RuntimeError(f"{name}: {t.numel()} elements where the kernels will index {n}")
+
+
 def _f32c(t):
     if t.dtype != torch.float32 or not t.is_contiguous():
         raise _lib.DbmmError(f"expected a contiguous float32 tensor, got {t.dtype} contiguous={t.is_contiguous()}")
@@ -192,6 +198,14 @@ def gemm(a, w, bias=None, residual=None, act=ACT_NONE, alpha=1.0, trans_a=False,
     if out is None:
         out = _empty((M, N), device=a.device, dtype=torch.float32)
     ldr = residual.shape[-1] if residual is not None else 0
+    # the library sees raw pointers and leading dimensions: what it will index must be there
+    if w.numel() != N * K or (not trans_a and a.numel() < (M - 1) * lda + K) or out.numel() < (M - 1) * out.shape[-1] + N:
+        raise RuntimeError(f"gemm: operands {tuple(a.shape)}, {tuple(w.shape)}, out {tuple(out.shape)} do not hold an M = {M}, N = {N}, K = {K} product")
+    _sized("gemm bias", bias, N)
+    if residual is not None and (ldr < N or residual.numel() < (M - 1) * ldr + N):
+        raise RuntimeError(f"gemm: residual {tuple(residual.shape)} for an [{M}, {N}] output")
+    if w_planes_f16 is not None and tuple(w_planes_f16.shape[1:]) != (N, K):
+        raise RuntimeError(f"gemm: weight planes {tuple(w_planes_f16.shape)} for a [{N}, {K}] weight")
     ws = igemm_workspace(a.device)
     # algorithmic bytes: A and the residual read once, C written once, W once in the form the kernel reads it
     nby = 4 * (M * K + M * N * (2 if residual is not None else 1)) + \
@@ -256,6 +270,13 @@ def conv_bn_act(x, w, bias, residual, kh, kw, stride, pad, act, w_layout=WL_TAP_
     Wo = (W + 2 * pad - kw) // stride + 1
     if pool not in (1, 2):
         raise _lib.DbmmError("conv_bn_act: pool must be 1 or 2")
+    if w.numel() != Cout * kh * kw * Cin:
+        raise RuntimeError(f"conv_bn_act: packed weight {tuple(w.shape)} for a {kh} x {kw} conv over {Cin} channels")
+    _sized("conv_bn_act bias", bias, Cout); _sized("conv_bn_act out_scale", out_scale, Cout)
+    if residual is not None and tuple(residual.shape) != (B, Ho, Wo, Cout):
+        raise RuntimeError(f"conv_bn_act: residual {tuple(residual.shape)} for a {(B, Ho, Wo, Cout)} output")
+    if w_planes_f16 is not None and w_planes_f16.numel() != w_planes_f16.shape[0] * w.numel():
+        raise RuntimeError(f"conv_bn_act: weight planes {tuple(w_planes_f16.shape)} for a packed weight {tuple(w.shape)}")
     plain = kh == 1 and kw == 1 and stride == 1 and pad == 0
     split = w_planes_f16 is not None or y_absmax is not None or out_scale is not None
     # algorithmic bytes: input map and residual read once, output(s) written once, weights once
@@ -514,6 +535,9 @@ def layernorm(x, gamma, beta, rows=None, ldx=None, eps=1e-5, y_absmax=None):
         rows = x.numel() // E
     if ldx is None:
         ldx = E
+    _sized("layernorm beta", beta, E)
+    if ldx < E or x.numel() < (rows - 1) * ldx + E:
+        raise RuntimeError(f"layernorm: input {tuple(x.shape)} for {rows} rows of {E} at pitch {ldx}")
     y = _empty((rows, E), device=x.device, dtype=torch.float32)
     check(_lib.lib().dbmm_layernorm(ptr(x), ldx, ptr(gamma), ptr(beta), ptr(y), E, rows, E, eps, ptr(y_absmax), stream()),
           "layernorm")
@@ -525,6 +549,8 @@ def mha_core(qkv, B, L, E, heads, causal, qkv_absmax=None):
     fp16-pair kernel runs (16-bit matrix cores, three partial products, fp32 accuracy); without it, or with
     option mha_x2 = 0, the fp32-input-MFMA kernel."""
     require_cuda(qkv)
+    if qkv.numel() != B * L * 3 * E or E != heads * 64:
+        raise RuntimeError(f"mha_core: qkv {tuple(qkv.shape)} for B = {B}, L = {L}, E = {E}, {heads} heads of 64")
     out = _empty((B * L, E), device=qkv.device, dtype=torch.float32)
     if qkv_absmax is not None and get_option("mha_x2"):
         with _TimedTag("mha_pair_kernel", 4.0 * B * heads * L * L * 64, 4 * (B * L * 4 * E)):
@@ -791,6 +817,9 @@ def gemm_f16(a, w, bias=None, residual=None, act=ACT_NONE, M=None, lda=None):
         lda = a.shape[-1]
     if M is None:
         M = a.numel() // a.shape[-1]
+    if a.numel() < (M - 1) * lda + K or lda < K:
+        raise RuntimeError(f"gemm_f16: activations {tuple(a.shape)} (row pitch {lda}) for M = {M}, K = {K}")
+    _sized("gemm_f16 bias", bias, N); _sized("gemm_f16 residual", residual, M * N)
     c = _empty((M, N), device=a.device, dtype=torch.float16)
     deep = N % 256 == 0 and K % 128 == 0 and M >= 16384 and get_option("f16_8ph")   # dbmm_gemm_f16's own rule
     with _TimedTag(f"gemm_f16_8ph_kernel<{act}, {int(residual is not None)}>" if deep else _gemm_f16_tag(M, N), 2.0 * M * N * K,
@@ -804,6 +833,8 @@ def gemm_f16(a, w, bias=None, residual=None, act=ACT_NONE, M=None, lda=None):
 def mha_core_f16(qkv, B, L, E, heads, causal):
     require_cuda(qkv)
     _f16c(qkv)
+    if qkv.numel() != B * L * 3 * E or E != heads * 64:
+        raise RuntimeError(f"mha_core_f16: qkv {tuple(qkv.shape)} for B = {B}, L = {L}, E = {E}, {heads} heads of 64")
     out = _empty((B * L, E), device=qkv.device, dtype=torch.float16)
     with _TimedTag("mha_f16_kernel", 4.0 * B * heads * L * L * 64, 2 * (B * L * 4 * E)):
         check(_lib.lib().dbmm_mha_core_f16(ptr(qkv), ptr(out), B, L, E, heads, int(causal), stream()), "mha_core_f16")
@@ -817,6 +848,9 @@ def layernorm_f16(x, gamma, beta, rows=None, ldx=None, eps=1e-5):
         rows = x.numel() // E
     if ldx is None:
         ldx = E
+    _sized("layernorm_f16 beta", beta, E)
+    if ldx < E or x.numel() < (rows - 1) * ldx + E:
+        raise RuntimeError(f"layernorm_f16: input {tuple(x.shape)} for {rows} rows of {E} at pitch {ldx}")
     y = _empty((rows, E), device=x.device, dtype=torch.float16)
     check(_lib.lib().dbmm_layernorm_f16(ptr(x), ldx, ptr(gamma), ptr(beta), ptr(y), E, rows, E, eps, stream()), "layernorm_f16")
     return y
@@ -872,7 +906,10 @@ def conv1x1_f16(x, w, scale, bias, residual=None, act=ACT_RELU):
     require_cuda(x, w)
     _f16c(x); _f16c(w)
     Cout, Cin = w.shape
+    if x.shape[-1] != Cin:
+        raise RuntimeError(f"conv1x1_f16: {x.shape[-1]} input channels against a weight {tuple(w.shape)}")
     M = x.numel() // Cin
+    _sized("conv1x1_f16 scale", scale, Cout); _sized("conv1x1_f16 bias", bias, Cout); _sized("conv1x1_f16 residual", residual, M * Cout)
     y = _empty(tuple(x.shape[:-1]) + (Cout,), device=x.device, dtype=torch.float16)
     deep = Cout % 256 == 0 and Cin % 128 == 0 and M >= 16384                            # what dbmm_gemm_f16 gives the eight-phase kernel
     mode = get_option("conv1x1_stream")
@@ -1003,6 +1040,9 @@ def conv3x3_f16(x, w, scale, bias, pool=1):
     _f16c(x); _f16c(w)
     B, H, W, Cin = x.shape
     Cout = w.shape[0]
+    if w.numel() != Cout * 9 * Cin:
+        raise RuntimeError(f"conv3x3_f16: packed weight {tuple(w.shape)} for a 3 x 3 conv over {Cin} channels")
+    _sized("conv3x3_f16 scale", scale, Cout); _sized("conv3x3_f16 bias", bias, Cout)
     y = _empty((B, H // pool, W // pool, Cout), device=x.device, dtype=torch.float16)
     geo = "2, 2, 2" if Cout > 64 else ("4, 1, 2" if Cout > 32 else "4, 1, 1")
     deep = Cout % 256 == 0 and B * H * W >= 16384 and get_option("f16_conv_8ph")     # dbmm_conv3x3_bn_relu_f16's own routing rule

@@ -327,3 +327,38 @@ def test_fuzz_whole_towers_inside_guard_zones(seed, monkeypatch):
     ga16.check()
     assert o16.dtype == torch.float16 and relerr(o16.float().cpu(), out.cpu()) < 3e-2, (B, relerr(o16.float().cpu(), out.cpu()))
     assert torch.equal(m16.encode_image(img[k:k + 1].contiguous()), o16[k:k + 1]) or relerr(m16.encode_image(img[k:k + 1].contiguous()).float().cpu(), o16[k:k + 1].float().cpu()) < 2e-3
+
+
+def test_wrappers_check_operand_shapes_before_launching():
+    """mis-shaped operands raise (the library would index past them): attention pool with another map size, a conv with a weight of another
+    depth, a bias / scale / residual of another width, a qkv buffer of another sequence length"""
+    z = lambda *s, dt=torch.float32: torch.zeros(s, device=DEV, dtype=dt)
+    with pytest.raises(RuntimeError, match="positional embedding"):
+        ops.attnpool(z(2, 3, 3, 64), z(5, 64), z(64, 64), z(64), z(128, 64), z(128), z(32, 64), z(32), 1)
+    with pytest.raises(RuntimeError, match="projection shapes"):
+        ops.attnpool(z(2, 2, 2, 64), z(5, 64), z(64, 32), z(64), z(128, 64), z(128), z(32, 64), z(32), 1)
+    with pytest.raises(RuntimeError, match="packed weight"):
+        ops.conv_bn_act(z(1, 4, 4, 32), z(16, 9 * 16), None, None, 3, 3, 1, 1, ops.ACT_RELU)
+    with pytest.raises(RuntimeError, match="bias"):
+        ops.conv_bn_act(z(1, 4, 4, 32), z(16, 32), z(8), None, 1, 1, 1, 0, ops.ACT_RELU)
+    with pytest.raises(RuntimeError, match="residual"):
+        ops.conv_bn_act(z(1, 4, 4, 32), z(16, 32), None, z(1, 4, 4, 8), 1, 1, 1, 0, ops.ACT_RELU)
+    with pytest.raises(RuntimeError, match="gemm"):
+        ops.gemm(z(8, 32), z(16, 64))
+    with pytest.raises(RuntimeError, match="residual"):
+        ops.gemm(z(8, 32), z(16, 32), residual=z(8, 8))
+    with pytest.raises(RuntimeError, match="scale"):
+        ops.conv1x1_f16(z(8, 64, dt=torch.float16), z(64, 64, dt=torch.float16), z(32), z(64))
+    with pytest.raises(RuntimeError, match="input channels"):
+        ops.conv1x1_f16(z(8, 32, dt=torch.float16), z(64, 64, dt=torch.float16), z(64), z(64))
+    with pytest.raises(RuntimeError, match="packed weight"):
+        ops.conv3x3_f16(z(1, 4, 4, 32, dt=torch.float16), z(32, 9 * 64, dt=torch.float16), z(32), z(32))
+    with pytest.raises(RuntimeError, match="qkv"):
+        ops.mha_core(z(10, 3 * 64), 2, 7, 64, 1, False)
+    with pytest.raises(RuntimeError, match="qkv"):
+        ops.mha_core_f16(z(10, 3 * 64, dt=torch.float16), 2, 7, 64, 1, False)
+    with pytest.raises(RuntimeError, match="layernorm"):
+        ops.layernorm(z(4, 64), z(64), z(32))
+    with pytest.raises(RuntimeError, match="tokens per prompt"):
+        ops.embed_gather(torch.zeros((2, 9), device=DEV, dtype=torch.int32), z(100, 64), z(77, 64))
+    torch.cuda.synchronize()
