@@ -362,3 +362,32 @@ def test_wrappers_check_operand_shapes_before_launching():
     with pytest.raises(RuntimeError, match="tokens per prompt"):
         ops.embed_gather(torch.zeros((2, 9), device=DEV, dtype=torch.int32), z(100, 64), z(77, 64))
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("mode", ["f16", "f32"])
+def test_rn50_at_the_headline_batch_inside_guard_zones(mode, monkeypatch):
+    """the RN50 tower at B = 1024 (the size bench.py's headline and rn50_f16_bs1024 legs run) in both modes with every tensor the library
+    allocates between sentinel zones; rows 0 / 511 / 1023 == the same images in a batch of three (fp16 mode: bit for bit -- every kernel's
+    rows are independent; fp32-accurate mode: to rounding -- the per-tensor fp16 scales depend on the batch maximum)"""
+    from test_gpu_headline import GuardedAlloc
+    from dbmm_amd import synth
+    from dbmm_amd.clip.model import build_model, convert_weights
+    model = build_model(synth.clip_state_dict(5, "RN50")).cuda()
+    if mode == "f16":
+        model = convert_weights(model)
+    base = synth.images(977, 64, 224)
+    scale = torch.linspace(0.7, 1.3, 16).repeat_interleave(64).view(-1, 1, 1, 1)
+    img = (base.repeat(16, 1, 1, 1) * scale).contiguous().cuda()
+    ga = GuardedAlloc()
+    monkeypatch.setattr(ops, "_empty", ga)
+    out = model.encode_image(img)
+    torch.cuda.synchronize()
+    ga.check()
+    assert tuple(out.shape) == (1024, 1024) and torch.isfinite(out.float()).all()
+    pick = torch.tensor([0, 511, 1023], device=DEV)
+    ga.bufs.clear()
+    small = model.encode_image(img[pick].contiguous())
+    if mode == "f16":
+        assert out.dtype == torch.float16 and torch.equal(small, out[pick]), (small != out[pick]).sum().item()
+    else:
+        assert relerr(small.cpu(), out[pick].cpu()) < 1e-5

@@ -195,6 +195,7 @@ class GuardedAlloc:
         shape = (shape,) if isinstance(shape, int) else tuple(shape)
         n = math.prod(shape)
         pad = max(1 << 16, 288 * (shape[-1] if shape else 1))
+        pad = min(pad, 1 << 24)                                         # (a flat workspace of 10^8 elements is not "288 rows" of itself)
         pad = (pad + 63) // 64 * 64                                     # keeps 16-byte alignment of the payload
         raw = torch.empty(n + 2 * pad, device=device, dtype=dtype)
         raw[:pad] = self.S; raw[pad + n:] = self.S
