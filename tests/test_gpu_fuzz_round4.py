@@ -391,3 +391,28 @@ def test_rn50_at_the_headline_batch_inside_guard_zones(mode, monkeypatch):
         assert out.dtype == torch.float16 and torch.equal(small, out[pick]), (small != out[pick]).sum().item()
     else:
         assert relerr(small.cpu(), out[pick].cpu()) < 1e-5
+
+
+@pytest.mark.parametrize("mode", ["f16", "f32"])
+def test_vit_b32_and_text_tower_inside_guard_zones(mode, monkeypatch):
+    """ViT-B/32 at 512 images (the size bench.py's vit_b32 legs run) and the text tower on 8 prompts, both modes, every tensor the library
+    allocates between sentinel zones; a random batch size too (ragged GEMM tiles and attention blocks in every layer)"""
+    from test_gpu_headline import GuardedAlloc
+    from dbmm_amd import synth
+    from dbmm_amd.clip.model import build_model, convert_weights
+    model = build_model(synth.clip_state_dict(5, "ViT-B/32")).cuda()
+    if mode == "f16":
+        model = convert_weights(model)
+    img = synth.images(31, 64, 224).repeat(8, 1, 1, 1).contiguous().cuda()
+    ga = GuardedAlloc()
+    monkeypatch.setattr(ops, "_empty", ga)
+    out = model.encode_image(img)
+    odd = model.encode_image(img[:37].contiguous())
+    tok = torch.randint(1, 49000, (8, 77), device=DEV, dtype=torch.int32)
+    tok[:, 0] = 49406; tok[:, 20] = 49407; tok[:, 21:] = 0
+    txt = model.encode_text(tok)
+    torch.cuda.synchronize()
+    ga.check()
+    assert tuple(out.shape) == (512, 512) and torch.isfinite(out.float()).all() and torch.isfinite(txt.float()).all()
+    tol = 2e-3 if mode == "f16" else 1e-5
+    assert relerr(odd.float().cpu(), out[:37].float().cpu()) < tol
